@@ -1,0 +1,177 @@
+"""Generate golden vectors by running the REFERENCE's own functions.
+
+Run only in the build container (needs /root/reference, which never travels):
+
+    python tests/golden/make_golden.py            # G1-G6  -> tests/golden/*.npz
+    /opt/conda/bin/python3.9 tests/golden/make_golden.py --h5   # G7 (h5py 3.3.0 lives there)
+
+The reference modules are imported unmodified; only third-party imports that
+the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
+stubbed, pyfftw's numpy interface is aliased to numpy.fft (the reference's own
+fallback, tensorflow_recon/util.py:7-14) and autograd.numpy to numpy.
+The fixtures are data only (inputs + outputs); no reference source is stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference/cnn_propagator'
+
+
+def _import_reference():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    stub('dxchange')
+    stub('h5py')
+    stub('tensorflow')
+    import matplotlib
+    matplotlib.use = lambda *a, **k: None
+    pyfftw = stub('pyfftw')
+    interfaces = stub('pyfftw.interfaces')
+    nfft = stub('pyfftw.interfaces.numpy_fft', fft2=np.fft.fft2, ifft2=np.fft.ifft2, fftn=np.fft.fftn,
+                ifftn=np.fft.ifftn, fftshift=np.fft.fftshift, ifftshift=np.fft.ifftshift)
+    pyfftw.interfaces = interfaces
+    interfaces.numpy_fft = nfft
+    autograd = stub('autograd')
+    sys.modules['autograd.numpy'] = np
+    autograd.numpy = np
+    if not hasattr(np, 'int'):
+        np.int = int                      # cnn_propagator/util.py:326-327 uses the removed alias
+    sys.path.insert(0, REF)
+    import util as ref_util
+    import np_funcs as ref_np_funcs
+    return ref_util, ref_np_funcs
+
+
+def main():
+    ref_util, ref_np = _import_reference()
+    out = {}
+
+    # G1: get_kernel
+    g1 = {}
+    for (Y, X) in [(8, 8), (9, 12), (64, 64)]:
+        for dist in [1.0, 1000.0]:
+            g1['H_{}_{}_{}'.format(Y, X, int(dist))] = ref_util.get_kernel(dist, 0.248, [1., 1., 1.], [Y, X, 4])
+    np.savez_compressed(os.path.join(HERE, 'g1_get_kernel.npz'), **g1)
+
+    # G2a: forward on a 16x16x6 random object, three detector modes, B=2
+    rng = np.random.default_rng(0)
+    delta = rng.uniform(0, 1e-5, size=(2, 16, 16, 6))
+    beta = 0.1 * delta
+    pr = np.ones((16, 16))
+    pi_ = np.zeros((16, 16))
+    g2 = {'delta': delta, 'beta': beta}
+    for name, fp in [('none', None), ('near', 1e-4), ('inf', 'inf')]:
+        w, pa = ref_np.multislice_propagate_batch_numpy(delta, beta, pr, pi_, 5000., 1e-7, free_prop_cm=fp,
+                                                        obj_batch_shape=delta.shape)
+        g2['wave_' + name] = w
+        if name == 'none':
+            g2['probe_array'] = pa
+    # non-trivial probe
+    prr = rng.normal(size=(16, 16))
+    pii = rng.normal(size=(16, 16))
+    w, _ = ref_np.multislice_propagate_batch_numpy(delta, beta, prr, pii, 5000., 1e-7, free_prop_cm=1e-4,
+                                                   obj_batch_shape=delta.shape)
+    g2['probe_real'] = prr
+    g2['probe_imag'] = pii
+    g2['wave_near_probe'] = w
+    np.savez_compressed(os.path.join(HERE, 'g2_forward_16.npz'), **g2)
+
+    # G2b: cfg1 — 64^3 tube phantom (tensorflow_recon/grid_delta.npy), first 32 slices, beta := 0.1 delta
+    gd = np.load('/root/reference/tensorflow_recon/grid_delta.npy')[..., :32]
+    gd = gd.reshape(1, *gd.shape)
+    gb = 0.1 * gd
+    g2b = {'delta': gd.astype(np.float64)}
+    for name, fp in [('none', None), ('near', 1e-4), ('inf', 'inf')]:
+        w, pa = ref_np.multislice_propagate_batch_numpy(gd, gb, np.ones((64, 64)), np.zeros((64, 64)), 5000., 1e-7,
+                                                        free_prop_cm=fp, obj_batch_shape=gd.shape)
+        g2b['wave_' + name] = w
+        if name == 'none':
+            g2b['probe_array_abs_sum'] = np.abs(pa).sum(axis=(1, 2, 3))
+            g2b['probe_array_last'] = pa[-1]
+    np.savez_compressed(os.path.join(HERE, 'g2_forward_cfg1.npz'), **g2b)
+
+    # G3: rotation tables + apply_rotation
+    import tempfile
+    g3 = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            for size, n_theta in [([8, 8, 8], 5), ([64, 64, 64], 4), ([6, 10, 10], 7)]:
+                folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(*size, n_theta)
+                ref_util.save_rotation_lookup(size, n_theta)
+                coords = ref_util.read_all_origin_coords(folder, n_theta)
+                key = 'x'.join(map(str, size)) + '_n{}'.format(n_theta)
+                g3['coords_' + key] = np.stack(coords)
+                if size[0] <= 8:
+                    rngo = np.random.default_rng(3)
+                    obj = rngo.normal(size=(size[0], size[1], size[2], 2))
+                    g3['obj_' + key] = obj
+                    g3['rot_' + key] = np.stack([ref_util.apply_rotation(obj, c, folder) for c in coords])
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, 'g3_rotation.npz'), **g3)
+
+    # G4: three Adam steps incl. the m = v = None start.
+    # NB util.py:285 does np.zeros_like(v) with v=None -> 0-d object array; arithmetic still works.
+    rng = np.random.default_rng(4)
+    x = rng.uniform(0, 1e-6, size=(2, 4, 5, 6))
+    g4 = {'x0': x}
+    m = v = None
+    for it in range(3):
+        g = rng.normal(size=x.shape) * 1e-3
+        x, m, v = ref_util.apply_gradient_adam(x, g, it, m, v, step_size=1e-7)
+        g4['g{}'.format(it)] = g
+        g4['x{}'.format(it + 1)] = np.asarray(x, dtype=np.float64)
+        g4['m{}'.format(it + 1)] = np.asarray(m, dtype=np.float64)
+        g4['v{}'.format(it + 1)] = np.asarray(v, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, 'g4_adam.npz'), **g4)
+
+    # G5: total_variation_3d
+    rng = np.random.default_rng(5)
+    arr = rng.normal(size=(6, 7, 8))
+    np.savez_compressed(os.path.join(HERE, 'g5_tv.npz'), arr=arr, tv=ref_util.total_variation_3d(arr))
+
+    # G6: split_tasks
+    arr = np.arange(23)
+    parts = ref_util.split_tasks(arr, 5)
+    np.savez_compressed(os.path.join(HERE, 'g6_split_tasks.npz'), arr=arr, split_size=5,
+                        lengths=np.array([len(p) for p in parts]), concat=np.concatenate(parts))
+    print('golden vectors written to', HERE)
+
+
+def main_h5():
+    """G7: exchange/data files written by h5py 3.3.0 (run under /opt/conda/bin/python3.9)."""
+    import h5py
+    rng = np.random.default_rng(7)
+    dat = (rng.normal(size=(3, 8, 8)) + 1j * rng.normal(size=(3, 8, 8))).astype('complex64')
+    path = os.path.join(HERE, 'g7_fullfield_3x8x8.h5')
+    with h5py.File(path, 'w') as f:          # same calls as cnn_propagator/simulation.py:124-126,159
+        grp = f.create_group('exchange')
+        d = grp.create_dataset('data', (3, 8, 8), dtype='complex64')
+        d[...] = dat
+    np.save(os.path.join(HERE, 'g7_fullfield_3x8x8.npy'), dat)
+    dat4 = (rng.normal(size=(2, 3, 4, 6)) + 1j * rng.normal(size=(2, 3, 4, 6))).astype('complex64')
+    path = os.path.join(HERE, 'g7_ptycho_2x3x4x6.h5')
+    with h5py.File(path, 'w') as f:          # cnn_propagator/simulation.py:363
+        grp = f.create_group('exchange')
+        d = grp.create_dataset('data', (2, 3, 4, 6), dtype='complex64')
+        for i in range(2):
+            d[i] = dat4[i]
+    np.save(os.path.join(HERE, 'g7_ptycho_2x3x4x6.npy'), dat4)
+    print('h5 fixtures written with h5py', h5py.__version__)
+
+
+if __name__ == '__main__':
+    if '--h5' in sys.argv:
+        main_h5()
+    else:
+        main()

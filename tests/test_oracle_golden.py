@@ -1,0 +1,89 @@
+"""The CPU oracle (oracle/bdof_oracle.py) replayed against vectors captured from the
+reference's own functions (tests/golden/make_golden.py).  float64: tolerances are
+round-off only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bdof_oracle as orc
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_g1_get_kernel(golden_dir):
+    g = _load(golden_dir, 'g1_get_kernel.npz')
+    for key in g.files:
+        _, Y, X, dist = key.split('_')
+        H = orc.get_kernel(float(dist), 0.248, [1., 1., 1.], [int(Y), int(X), 4])
+        assert H.shape == (int(Y), int(X))
+        np.testing.assert_allclose(H, g[key], rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize('name,fp', [('none', None), ('near', 1e-4), ('inf', 'inf')])
+def test_g2_forward_16(golden_dir, name, fp):
+    g = _load(golden_dir, 'g2_forward_16.npz')
+    w, pa = orc.multislice_propagate_batch_numpy(g['delta'], g['beta'], np.ones((16, 16)), np.zeros((16, 16)),
+                                                 5000., 1e-7, free_prop_cm=fp, obj_batch_shape=g['delta'].shape)
+    ref = g['wave_' + name]
+    np.testing.assert_allclose(w, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    if name == 'none':
+        np.testing.assert_allclose(pa, g['probe_array'], rtol=0, atol=1e-12)
+
+
+def test_g2_forward_16_probe(golden_dir):
+    g = _load(golden_dir, 'g2_forward_16.npz')
+    w, _ = orc.multislice_propagate_batch_numpy(g['delta'], g['beta'], g['probe_real'], g['probe_imag'], 5000., 1e-7,
+                                                free_prop_cm=1e-4, obj_batch_shape=g['delta'].shape)
+    np.testing.assert_allclose(w, g['wave_near_probe'], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize('name,fp', [('none', None), ('near', 1e-4), ('inf', 'inf')])
+def test_g2_forward_cfg1(golden_dir, name, fp):
+    """cfg1: 64^3 tube phantom, 1 angle, 32 slices (BASELINE.json configs[0])."""
+    g = _load(golden_dir, 'g2_forward_cfg1.npz')
+    delta = g['delta']
+    w, pa = orc.multislice_propagate_batch_numpy(delta, 0.1 * delta, np.ones((64, 64)), np.zeros((64, 64)), 5000.,
+                                                 1e-7, free_prop_cm=fp, obj_batch_shape=delta.shape)
+    ref = g['wave_' + name]
+    np.testing.assert_allclose(w, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    if name == 'none':
+        np.testing.assert_allclose(np.abs(pa).sum(axis=(1, 2, 3)), g['probe_array_abs_sum'], rtol=1e-13)
+        np.testing.assert_allclose(pa[-1], g['probe_array_last'], rtol=0, atol=1e-12)
+
+
+def test_g3_rotation(golden_dir):
+    g = _load(golden_dir, 'g3_rotation.npz')
+    for size, n in [((8, 8, 8), 5), ((64, 64, 64), 4), ((6, 10, 10), 7)]:
+        key = 'x'.join(map(str, size)) + '_n{}'.format(n)
+        coords = orc.rotation_lookup(list(size), n)
+        assert np.array_equal(np.stack(coords), g['coords_' + key])        # integer tables: bit exact
+        if 'obj_' + key in g.files:
+            obj = g['obj_' + key]
+            rot = np.stack([orc.apply_rotation(obj, c) for c in coords])
+            assert np.array_equal(rot, g['rot_' + key])
+
+
+def test_g4_adam(golden_dir):
+    g = _load(golden_dir, 'g4_adam.npz')
+    x = g['x0']
+    m = v = None
+    for it in range(3):
+        x, m, v = orc.apply_gradient_adam(x, g['g{}'.format(it)], it, m, v, step_size=1e-7)
+        np.testing.assert_allclose(x, g['x{}'.format(it + 1)], rtol=1e-14)
+        np.testing.assert_allclose(m, g['m{}'.format(it + 1)], rtol=1e-14)
+        np.testing.assert_allclose(v, g['v{}'.format(it + 1)], rtol=1e-14)
+
+
+def test_g5_tv(golden_dir):
+    g = _load(golden_dir, 'g5_tv.npz')
+    np.testing.assert_allclose(orc.total_variation_3d(g['arr']), g['tv'], rtol=1e-14)
+
+
+def test_g6_split_tasks(golden_dir):
+    g = _load(golden_dir, 'g6_split_tasks.npz')
+    parts = orc.split_tasks(g['arr'], int(g['split_size']))
+    assert [len(p) for p in parts] == list(g['lengths'])
+    assert np.array_equal(np.concatenate(parts), g['concat'])
