@@ -1,0 +1,173 @@
+"""ctypes binding of libbdof.so (C ABI: include/bdof.h).  No fallback: if the HIP library is
+missing or no GPU is present, using the product path raises."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libbdof.so')
+
+DET_NONE, DET_NEAR, DET_FAR = 0, 1, 2
+VARIANT_NUMPY_SKIP_LAST, VARIANT_TF_ALL = 0, 1
+K_ROW_FWD, K_COL_PROP, K_ROW_BWD, K_LOSS, K_ROT_ADJ, K_ADAM = range(6)
+KERNEL_CLASS_NAMES = ['row_fwd', 'col_prop', 'row_bwd', 'loss', 'rot_adjoint', 'adam']
+
+_c_int_p = ctypes.POINTER(ctypes.c_int)
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/bdof.h one to one
+_SIGNATURES = {
+    'bdof_ctx_create': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, _vp]),
+    'bdof_ctx_destroy': (None, [_vp]),
+    'bdof_last_error': (ctypes.c_char_p, [_vp]),
+    'bdof_sync': (ctypes.c_int, [_vp]),
+    'bdof_device_count': (ctypes.c_int, []),
+    'bdof_configure': (ctypes.c_int, [_vp] + [ctypes.c_int] * 5),
+    'bdof_set_physics': (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp, ctypes.c_int, ctypes.c_int]),
+    'bdof_set_probe': (ctypes.c_int, [_vp, _vp]),
+    'bdof_set_object': (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int]),
+    'bdof_set_rotation_adjoint': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
+    'bdof_forward': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int]),
+    'bdof_tape_to_real': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
+    'bdof_loss_grad': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
+    'bdof_get_loss': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double)]),
+    'bdof_grot': (_vp, [_vp]),
+    'bdof_rotation_adjoint': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float]),
+    'bdof_adam_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+                       + [ctypes.c_float] * 8 + [ctypes.c_int, ctypes.c_int]),
+    'bdof_profile_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'bdof_profile_read': (ctypes.c_int, [_vp, ctypes.c_int, _c_int_p, ctypes.POINTER(ctypes.c_double)]),
+    'bdof_malloc': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
+    'bdof_free': (ctypes.c_int, [_vp]),
+    'bdof_memcpy_h2d': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    'bdof_memcpy_d2h': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
+    'bdof_memset': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_size_t]),
+}
+EXPORTED_SYMBOLS = sorted(_SIGNATURES)
+
+_lib = None
+
+
+class BdofError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libbdof.so (build it with `python -c "import __graft_entry__ as g; g.build()"`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BdofError('HIP extension not built: {} is missing (run __graft_entry__.build())'.format(LIB_PATH))
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if isinstance(x, int):
+        return x
+    if hasattr(x, 'data_ptr'):       # torch tensor on the device
+        return x.data_ptr()
+    raise TypeError('expected DeviceBuffer / device pointer, got {}'.format(type(x)))
+
+
+class DeviceBuffer(object):
+    """A caller-owned device allocation (hipMalloc through the C ABI)."""
+
+    def __init__(self, ctx, nbytes, dtype=np.uint8, shape=None):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(shape) if shape is not None else (self.nbytes // self.dtype.itemsize,)
+        p = _vp()
+        rc = ctx.lib.bdof_malloc(ctypes.byref(p), max(self.nbytes, 1))
+        if rc != 0 or not p.value:
+            raise BdofError('bdof_malloc({} bytes) failed with hip error {}'.format(nbytes, rc))
+        self.ptr = p.value
+
+    @classmethod
+    def from_host(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = cls(ctx, arr.nbytes, arr.dtype, arr.shape)
+        buf.upload(arr)
+        return buf
+
+    @classmethod
+    def zeros(cls, ctx, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        buf = cls(ctx, n, dtype, shape)
+        ctx.check(ctx.lib.bdof_memset(ctx.handle, buf.ptr, 0, buf.nbytes))
+        return buf
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes == self.nbytes, (arr.nbytes, self.nbytes)
+        self.ctx.check(self.ctx.lib.bdof_memcpy_h2d(self.ctx.handle, self.ptr, arr.ctypes.data, arr.nbytes))
+
+    def download(self, shape=None, dtype=None):
+        dtype = np.dtype(dtype or self.dtype)
+        shape = tuple(shape) if shape is not None else self.shape
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx.check(self.ctx.lib.bdof_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    @property
+    def __cuda_array_interface__(self):
+        return {'shape': self.shape, 'typestr': self.dtype.str, 'data': (self.ptr, False), 'version': 2}
+
+    def free(self):
+        if getattr(self, 'ptr', None):
+            self.ctx.lib.bdof_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context(object):
+    """Owns one bdof_ctx (one device, one stream)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        if self.lib.bdof_device_count() < 1:
+            raise BdofError('no HIP device visible: the multislice engine has no CPU fallback')
+        h = _vp()
+        rc = self.lib.bdof_ctx_create(ctypes.byref(h), int(device), stream)
+        if rc != 0:
+            raise BdofError('bdof_ctx_create(device={}) failed: {}'.format(device, rc))
+        self.handle = h.value
+        self.device = device
+
+    def check(self, rc):
+        if rc != 0:
+            msg = self.lib.bdof_last_error(self.handle)
+            raise BdofError('libbdof error {}: {}'.format(rc, msg.decode() if msg else ''))
+
+    def sync(self):
+        self.check(self.lib.bdof_sync(self.handle))
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.bdof_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

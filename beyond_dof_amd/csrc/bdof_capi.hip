@@ -1,0 +1,534 @@
+// libbdof.so — host side of the C ABI declared in include/bdof.h.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bdof.h"
+#include "bdof_kernels.h"
+
+#define BDOF_ERR_ARG (-1)
+#define BDOF_ERR_STATE (-2)
+#define BDOF_ERR_SIZE (-3)
+
+struct bdof_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int ncu = 256;
+    int NY = 0, NX = 0, S = 0, Bmax = 0;
+    bool with_grad = false;
+    cf *twY = nullptr, *twX = nullptr;
+    cf *hs = nullptr, *hdet = nullptr, *probe = nullptr;
+    cf *bufA = nullptr, *bufB = nullptr, *tape = nullptr;
+    float2* grot = nullptr;
+    double *partial = nullptr, *loss_dev = nullptr;
+    int npartial = 0;
+    float k = 0.f;
+    int det_mode = BDOF_DET_NONE, variant = BDOF_VARIANT_NUMPY_SKIP_LAST;
+    bool have_physics = false, have_probe = false, tape_valid = false, last_valid = false;
+    ObjView obj{};
+    int n_angles = 0;
+    const int *adj_off = nullptr, *adj_order = nullptr;
+    int adj_ndest = 0;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<std::pair<int, int>> ev_used;   // (class, index of start event)
+    size_t ev_next = 0;
+    double prof_ms[BDOF_K_COUNT] = {0};
+    int prof_n[BDOF_K_COUNT] = {0};
+    std::string err;
+};
+
+static int fail(bdof_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIPC(c, call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            return fail((c), (int)e_, std::string(#call) + ": " + hipGetErrorString(e_));          \
+        }                                                                                          \
+    } while (0)
+
+static bool supported_n(int n) { return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
+
+// ---- profiling helpers -----------------------------------------------------------------------
+struct ProfScope {
+    bdof_ctx* c;
+    int cls;
+    bool on;
+    size_t idx = 0;
+    ProfScope(bdof_ctx* c_, int cls_) : c(c_), cls(cls_), on(c_->prof) {
+        if (!on) return;
+        if (c->ev_next + 2 > c->ev_pool.size()) {
+            size_t old = c->ev_pool.size();
+            c->ev_pool.resize(old + 4096);
+            for (size_t i = old; i < c->ev_pool.size(); ++i) (void)hipEventCreate(&c->ev_pool[i]);
+        }
+        idx = c->ev_next;
+        c->ev_next += 2;
+        (void)hipEventRecord(c->ev_pool[idx], c->stream);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(c->ev_pool[idx + 1], c->stream);
+        c->ev_used.emplace_back(cls, (int)idx);
+    }
+};
+
+static void prof_collect(bdof_ctx* c) {
+    for (auto& u : c->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[u.second], c->ev_pool[u.second + 1]) == hipSuccess) {
+            c->prof_ms[u.first] += ms;
+            c->prof_n[u.first] += 1;
+        }
+    }
+    c->ev_used.clear();
+    c->ev_next = 0;
+}
+
+// ---- launches --------------------------------------------------------------------------------
+template <int NY> static int rows_grid(const bdof_ctx* c, int B, int NX) {
+    constexpr int RPW = BDOF_ROW_THREADS / (NY / 8);
+    int need = (B * NX + RPW - 1) / RPW;
+    int cap = c->ncu * 8;
+    return need < cap ? need : cap;
+}
+template <int NX> static int cols_grid(const bdof_ctx* c, int B, int NY) {
+    int need = B * (NY / ColTile<NX>::W);
+    int cap = c->ncu * 2;
+    return need < cap ? need : cap;
+}
+
+#define DISPATCH_N(n, EXPR)                                    \
+    switch (n) {                                               \
+        case 64: { constexpr int N_ = 64; EXPR; } break;       \
+        case 128: { constexpr int N_ = 128; EXPR; } break;     \
+        case 256: { constexpr int N_ = 256; EXPR; } break;     \
+        case 512: { constexpr int N_ = 512; EXPR; } break;     \
+        case 1024: { constexpr int N_ = 1024; EXPR; } break;   \
+        default: break;                                        \
+    }
+
+static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out) {
+    ProfScope ps(c, BDOF_K_ROW_FWD);
+    RowFwdArgs a{in, c->probe, out, c->obj, B, c->NX, z, c->k, c->twY};
+    DISPATCH_N(c->NY, {
+        int grid = rows_grid<N_>(c, B, c->NX);
+        if (z == 0) hipLaunchKernelGGL((k_row_fwd<N_, true>), dim3(grid), dim3(BDOF_ROW_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_row_fwd<N_, false>), dim3(grid), dim3(BDOF_ROW_THREADS), 0, c->stream, a);
+    });
+}
+
+static void launch_col_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf* h, float scale, int conj_h) {
+    ProfScope ps(c, BDOF_K_COL_PROP);
+    ColPropArgs a{in, out, h, B, c->NY, scale, conj_h, c->twX};
+    DISPATCH_N(c->NX, {
+        int grid = cols_grid<N_>(c, B, c->NY);
+        hipLaunchKernelGGL((k_col_prop<N_>), dim3(grid), dim3((N_ / 8) * ColTile<N_>::W), 0, c->stream, a);
+    });
+}
+
+static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout) {
+    ProfScope ps(c, BDOF_K_ROW_BWD);
+    RowBwdArgs a{gin, tape, c->probe, gout, c->grot, c->obj, B, c->NX, z, c->k, c->twY};
+    DISPATCH_N(c->NY, {
+        int grid = rows_grid<N_>(c, B, c->NX);
+        if (z == 0) hipLaunchKernelGGL((k_row_bwd<N_, true>), dim3(grid), dim3(BDOF_ROW_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_row_bwd<N_, false>), dim3(grid), dim3(BDOF_ROW_THREADS), 0, c->stream, a);
+    });
+}
+
+// returns the grid used (number of partial sums written when meas != null)
+static int launch_row_loss(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* out_wave, const float* meas, float in_scale,
+                           float out_scale, float seed_scale) {
+    ProfScope ps(c, BDOF_K_LOSS);
+    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NX, c->NY, in_scale, out_scale, seed_scale, c->twY};
+    int grid = 0;
+    DISPATCH_N(c->NY, {
+        grid = rows_grid<N_>(c, B, c->NX);
+        hipLaunchKernelGGL((k_row_loss<N_>), dim3(grid), dim3(BDOF_ROW_THREADS), 0, c->stream, a);
+    });
+    return grid;
+}
+
+static int launch_col_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* out_wave, const float* meas, float in_scale,
+                               float out_scale, float seed_scale) {
+    ProfScope ps(c, BDOF_K_LOSS);
+    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NX, c->NY, in_scale, out_scale, seed_scale, c->twX};
+    int grid = 0;
+    DISPATCH_N(c->NX, {
+        grid = cols_grid<N_>(c, B, c->NY);
+        hipLaunchKernelGGL((k_col_loss_far<N_>), dim3(grid), dim3((N_ / 8) * ColTile<N_>::W), 0, c->stream, a);
+    });
+    return grid;
+}
+
+// ---- the forward sweep.  On return *cur points at the last field and *cur_unnorm tells whether it is
+// R phi_{S-1} (un-normalised, numpy_skip_last) or psi_hat_S (normalised hybrid, tf_all). ------------
+static void forward_sweep(bdof_ctx* c, int B, bool use_tape, cf** cur, bool* cur_unnorm) {
+    const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+    for (int z = 0; z < c->S; ++z) {
+        const cf* in = nullptr;
+        if (z > 0) in = use_tape ? c->tape + (size_t)(z - 1) * fld : c->bufB;
+        launch_row_fwd(c, B, z, in, c->bufA);
+        const bool last = z == c->S - 1;
+        if (!last || c->variant == BDOF_VARIANT_TF_ALL) {
+            cf* out = (use_tape && !last) ? c->tape + (size_t)z * fld : c->bufB;
+            launch_col_prop(c, B, c->bufA, out, c->hs, 1.f, 0);
+        }
+    }
+    if (c->variant == BDOF_VARIANT_TF_ALL) { *cur = c->bufB; *cur_unnorm = false; }
+    else { *cur = c->bufA; *cur_unnorm = true; }
+}
+
+static int check_ready(bdof_ctx* c, int B) {
+    if (!c) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    if (!c->have_physics) return fail(c, BDOF_ERR_STATE, "bdof_set_physics has not been called");
+    if (!c->have_probe) return fail(c, BDOF_ERR_STATE, "bdof_set_probe has not been called");
+    if (!c->obj.vol) return fail(c, BDOF_ERR_STATE, "bdof_set_object has not been called");
+    if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
+    return 0;
+}
+
+extern "C" {
+
+int bdof_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int bdof_ctx_create(bdof_ctx** out, int device, void* stream) {
+    if (!out) return BDOF_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return e != hipSuccess ? (int)e : (int)hipErrorNoDevice;
+    if (device < 0 || device >= n) return BDOF_ERR_ARG;
+    bdof_ctx* c = new bdof_ctx();
+    c->device = device;
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { delete c; return (int)e; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->ncu = prop.multiProcessorCount;
+    if (stream) { c->stream = (hipStream_t)stream; }
+    else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return (int)e; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return 0;
+}
+
+static void free_workspace(bdof_ctx* c) {
+    void* ptrs[] = {c->twY, c->twX, c->hs, c->hdet, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    c->twY = c->twX = c->hs = c->hdet = c->probe = c->bufA = c->bufB = c->tape = nullptr;
+    c->grot = nullptr;
+    c->partial = c->loss_dev = nullptr;
+}
+
+void bdof_ctx_destroy(bdof_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_workspace(c);
+    for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* bdof_last_error(const bdof_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int bdof_sync(bdof_ctx* c) {
+    if (!c) return BDOF_ERR_ARG;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int upload_twiddle(bdof_ctx* c, int N, cf** dst) {
+    std::vector<cf> t(N);
+    for (int j = 0; j < N; ++j) {
+        double ang = -2.0 * M_PI * (double)j / (double)N;
+        t[j] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+    HIPC(c, hipMalloc((void**)dst, sizeof(cf) * N));
+    HIPC(c, hipMemcpyAsync(*dst, t.data(), sizeof(cf) * N, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) {
+    if (!c) return BDOF_ERR_ARG;
+    if (!supported_n(NY) || !supported_n(NX))
+        return fail(c, BDOF_ERR_SIZE, "NY and NX must be powers of two in [64, 1024]");
+    if (S < 1 || Bmax < 1) return fail(c, BDOF_ERR_ARG, "S and Bmax must be >= 1");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    free_workspace(c);
+    c->NY = NY; c->NX = NX; c->S = S; c->Bmax = Bmax; c->with_grad = with_grad != 0;
+    c->have_physics = c->have_probe = c->tape_valid = false;
+    int r;
+    if ((r = upload_twiddle(c, NY, &c->twY))) return r;
+    if ((r = upload_twiddle(c, NX, &c->twX))) return r;
+    const size_t fld = (size_t)Bmax * NX * NY;
+    HIPC(c, hipMalloc((void**)&c->hs, sizeof(cf) * NX * NY));
+    HIPC(c, hipMalloc((void**)&c->hdet, sizeof(cf) * NX * NY));
+    HIPC(c, hipMalloc((void**)&c->probe, sizeof(cf) * NX * NY));
+    HIPC(c, hipMalloc((void**)&c->bufA, sizeof(cf) * fld));
+    HIPC(c, hipMalloc((void**)&c->bufB, sizeof(cf) * fld));
+    if (c->with_grad) {
+        if (S > 1) HIPC(c, hipMalloc((void**)&c->tape, sizeof(cf) * fld * (size_t)(S - 1)));
+        HIPC(c, hipMalloc((void**)&c->grot, sizeof(float2) * fld * (size_t)S));
+    }
+    c->npartial = c->ncu * 8;
+    HIPC(c, hipMalloc((void**)&c->partial, sizeof(double) * c->npartial));
+    HIPC(c, hipMalloc((void**)&c->loss_dev, sizeof(double)));
+    HIPC(c, hipMemsetAsync(c->loss_dev, 0, sizeof(double), c->stream));
+    return 0;
+}
+
+int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det, int det_mode, int variant) {
+    if (!c || !hs) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    if (det_mode < 0 || det_mode > 2 || variant < 0 || variant > 1) return fail(c, BDOF_ERR_ARG, "bad det_mode / variant");
+    if (det_mode == BDOF_DET_NEAR && !hs_det) return fail(c, BDOF_ERR_ARG, "hs_det required for BDOF_DET_NEAR");
+    const size_t bytes = sizeof(cf) * c->NX * c->NY;
+    HIPC(c, hipMemcpyAsync(c->hs, hs, bytes, hipMemcpyHostToDevice, c->stream));
+    if (hs_det) HIPC(c, hipMemcpyAsync(c->hdet, hs_det, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->k = (float)k;
+    c->det_mode = det_mode;
+    c->variant = variant;
+    c->have_physics = true;
+    return 0;
+}
+
+int bdof_set_probe(bdof_ctx* c, const float* probe) {
+    if (!c || !probe) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    HIPC(c, hipMemcpyAsync(c->probe, probe, sizeof(cf) * c->NX * c->NY, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->have_probe = true;
+    return 0;
+}
+
+int bdof_set_object(bdof_ctx* c, const void* vol, int volNY, const int* tab, int volNX, int n_angles) {
+    if (!c || !vol) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    if (volNY < 1) return fail(c, BDOF_ERR_ARG, "volNY must be >= 1");
+    if (tab && (volNX < 1 || n_angles < 1)) return fail(c, BDOF_ERR_ARG, "volNX and n_angles must be >= 1 with a table");
+    if (!tab && volNY != c->NY) return fail(c, BDOF_ERR_ARG, "without a rotation table volNY must equal NY");
+    c->obj.vol = (const float2*)vol;
+    c->obj.volNY = volNY;
+    c->obj.tab = tab;
+    c->obj.volNX = tab ? volNX : c->NX;
+    c->obj.S = c->S;
+    c->n_angles = tab ? n_angles : 0;
+    return 0;
+}
+
+int bdof_set_rotation_adjoint(bdof_ctx* c, const int* off, const int* order, int n_dest) {
+    if (!c || !off || !order || n_dest < 1) return BDOF_ERR_ARG;
+    c->adj_off = off; c->adj_order = order; c->adj_ndest = n_dest;
+    return 0;
+}
+
+static void set_batch_views(bdof_ctx* c, const int* angle_of_b, const int* xoff, const int* yoff) {
+    c->obj.angle_of_b = angle_of_b;
+    c->obj.xoff = xoff;
+    c->obj.yoff = yoff;
+}
+
+int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave, int keep_tape) {
+    int r = check_ready(c, B);
+    if (r) return r;
+    if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
+    if (keep_tape && !c->with_grad) return fail(c, BDOF_ERR_STATE, "keep_tape needs bdof_configure(with_grad=1)");
+    HIPC(c, hipSetDevice(c->device));
+    set_batch_views(c, angle_of_b, xoff, yoff);
+    cf* cur; bool unnorm;
+    forward_sweep(c, B, keep_tape != 0 && c->S > 1, &cur, &unnorm);
+    c->tape_valid = keep_tape != 0;
+    c->last_valid = true;
+    cf* other = cur == c->bufA ? c->bufB : c->bufA;
+    if (out_wave) {
+        if (c->det_mode == BDOF_DET_NONE) {
+            launch_row_loss(c, B, cur, nullptr, (cf*)out_wave, nullptr, unnorm ? 1.f / c->NY : 1.f, 1.f, 0.f);
+        } else if (c->det_mode == BDOF_DET_NEAR) {
+            launch_col_prop(c, B, cur, other, c->hdet, unnorm ? 1.f : (float)c->NY, 0);
+            launch_row_loss(c, B, other, nullptr, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f);
+        } else {
+            launch_col_loss_far(c, B, cur, nullptr, (cf*)out_wave, nullptr, unnorm ? 1.f : (float)c->NY, 1.f, 0.f);
+        }
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_tape_to_real(bdof_ctx* c, int i, int B, void* out) {
+    int r = check_ready(c, B);
+    if (r) return r;
+    if (!out) return BDOF_ERR_ARG;
+    if (!c->tape_valid) return fail(c, BDOF_ERR_STATE, "no tape: run bdof_forward(keep_tape=1) or bdof_loss_grad first");
+    if (i < 0 || i >= c->S) return fail(c, BDOF_ERR_ARG, "slice index outside [0, S)");
+    const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+    if (i < c->S - 1) {
+        launch_row_loss(c, B, c->tape + (size_t)i * fld, nullptr, (cf*)out, nullptr, 1.f, 1.f, 0.f);
+    } else if (c->variant == BDOF_VARIANT_TF_ALL) {
+        // wave after the last slice, propagated: recompute from R phi_{S-1} (bufA) without touching bufB users
+        return fail(c, BDOF_ERR_STATE, "tape_to_real(S-1) is only kept for the numpy_skip_last variant");
+    } else {
+        if (!c->last_valid) return fail(c, BDOF_ERR_STATE, "the last slice's wave is only kept after bdof_forward");
+        launch_row_loss(c, B, c->bufA, nullptr, (cf*)out, nullptr, 1.f / c->NY, 1.f, 0.f);
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, void* out_wave) {
+    int r = check_ready(c, B);
+    if (r) return r;
+    if (!meas) return BDOF_ERR_ARG;
+    if (!c->with_grad) return fail(c, BDOF_ERR_STATE, "bdof_loss_grad needs bdof_configure(with_grad=1)");
+    if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
+    HIPC(c, hipSetDevice(c->device));
+    set_batch_views(c, angle_of_b, xoff, yoff);
+    const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+    const float NYf = (float)c->NY;
+    const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
+    cf* cur; bool unnorm;
+    forward_sweep(c, B, c->S > 1, &cur, &unnorm);
+    c->tape_valid = true;
+    c->last_valid = false;
+    cf* other = cur == c->bufA ? c->bufB : c->bufA;
+    const float seed_scale = 2.f / ((float)B * (float)c->NX * (float)c->NY);
+    int npart = 0;
+    // After this block `g` holds g_hat(phi_{S-1}) (normalised hybrid).
+    cf* g;
+    if (c->det_mode == BDOF_DET_NONE) {
+        // in-place per row: every row is fully in registers before it is written back
+        npart = launch_row_loss(c, B, cur, other, (cf*)out_wave, meas, unnorm ? 1.f / NYf : 1.f, tf_all ? 1.f : 1.f / NYf, seed_scale);
+        g = other;
+        if (tf_all) { launch_col_prop(c, B, g, cur, c->hs, 1.f, 1); g = cur; }
+    } else if (c->det_mode == BDOF_DET_NEAR) {
+        launch_col_prop(c, B, cur, other, c->hdet, unnorm ? 1.f : NYf, 0);            // d_hat
+        npart = launch_row_loss(c, B, other, cur, (cf*)out_wave, meas, 1.f, 1.f, seed_scale);   // R G(d)
+        launch_col_prop(c, B, cur, other, c->hdet, 1.f, 1);                            // g_hat(psi_S)
+        g = other;
+        if (tf_all) { launch_col_prop(c, B, g, cur, c->hs, NYf, 1); g = cur; }
+    } else {
+        npart = launch_col_loss_far(c, B, cur, other, (cf*)out_wave, meas, unnorm ? 1.f : NYf, tf_all ? NYf : 1.f, seed_scale);
+        g = other;
+        if (tf_all) { launch_col_prop(c, B, g, cur, c->hs, 1.f, 1); g = cur; }
+    }
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, npart,
+                       1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
+    // backward sweep
+    for (int z = c->S - 1; z >= 0; --z) {
+        cf* gout = g == c->bufA ? c->bufB : c->bufA;
+        const cf* tape = z > 0 ? c->tape + (size_t)(z - 1) * fld : nullptr;
+        launch_row_bwd(c, B, z, g, tape, z > 0 ? gout : nullptr);
+        if (z > 0) launch_col_prop(c, B, gout, g, c->hs, 1.f, 1);   // g_hat(phi_{z-1}) back into g
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_get_loss(bdof_ctx* c, double* loss) {
+    if (!c || !loss) return BDOF_ERR_ARG;
+    HIPC(c, hipMemcpyAsync(loss, c->loss_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void* bdof_grot(bdof_ctx* c) { return c ? (void*)c->grot : nullptr; }
+
+int bdof_rotation_adjoint(bdof_ctx* c, int B, const int* angle_of_b, void* gvol, int accumulate, float scale) {
+    if (!c || !gvol || !angle_of_b) return BDOF_ERR_ARG;
+    if (!c->grot) return fail(c, BDOF_ERR_STATE, "no gradient workspace (configure with_grad=1)");
+    if (!c->adj_off) return fail(c, BDOF_ERR_STATE, "bdof_set_rotation_adjoint has not been called");
+    if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
+    if (c->NY % 2) return fail(c, BDOF_ERR_SIZE, "NY must be even");
+    HIPC(c, hipSetDevice(c->device));
+    ProfScope ps(c, BDOF_K_ROT_ADJ);
+    RotAdjArgs a{c->grot, (float2*)gvol, c->adj_off, c->adj_order, angle_of_b, B, c->S * c->NX, c->adj_ndest, c->NY, accumulate, scale};
+    int grid = c->adj_ndest < c->ncu * 16 ? c->adj_ndest : c->ncu * 16;
+    int threads = c->NY / 2 < 256 ? (c->NY / 2 < 64 ? 64 : c->NY / 2) : 256;
+    hipLaunchKernelGGL(k_rot_adjoint, dim3(grid), dim3(threads), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_adam_step(bdof_ctx* c, const void* x_old, void* x_new, const void* g, void* m, void* v, const float* mask,
+                   int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
+                   float lr, float b1, float b2, float eps, int i_batch, int clip) {
+    if (!c || !x_old || !x_new || !g || !m || !v) return BDOF_ERR_ARG;
+    if (x_old == x_new) return fail(c, BDOF_ERR_ARG, "x_new must not alias x_old (the TV stencil reads pre-update neighbours)");
+    if (NXv < 1 || NZv < 1 || NYv < 1 || i_batch < 0) return fail(c, BDOF_ERR_ARG, "bad volume shape / i_batch");
+    HIPC(c, hipSetDevice(c->device));
+    ProfScope ps(c, BDOF_K_ADAM);
+    const double bc1 = 1.0 - std::pow((double)b1, (double)(i_batch + 1));
+    const double bc2 = 1.0 - std::pow((double)b2, (double)(i_batch + 1));
+    AdamArgs a{(const float2*)x_old, (float2*)x_new, (const float2*)g, (float2*)m, (float2*)v, mask, NXv, NZv, NYv,
+               g_scale, alpha_d, alpha_b, gamma, lr, b1, b2, eps, (float)(1.0 / bc1), (float)(1.0 / bc2), clip};
+    const size_t n = (size_t)NXv * NZv * NYv;
+    size_t need = (n + 255) / 256;
+    int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
+    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_profile_enable(bdof_ctx* c, int enable) {
+    if (!c) return BDOF_ERR_ARG;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (enable) { for (int i = 0; i < BDOF_K_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; } }
+    c->prof = enable != 0;
+    return 0;
+}
+
+int bdof_profile_read(bdof_ctx* c, int kernel_class, int* n_launches, double* total_ms) {
+    if (!c || kernel_class < 0 || kernel_class >= BDOF_K_COUNT) return BDOF_ERR_ARG;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    if (n_launches) *n_launches = c->prof_n[kernel_class];
+    if (total_ms) *total_ms = c->prof_ms[kernel_class];
+    return 0;
+}
+
+int bdof_malloc(void** ptr, size_t bytes) {
+    if (!ptr) return BDOF_ERR_ARG;
+    return (int)hipMalloc(ptr, bytes);
+}
+int bdof_free(void* ptr) { return (int)hipFree(ptr); }
+int bdof_memcpy_h2d(bdof_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return BDOF_ERR_ARG;
+    HIPC(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int bdof_memcpy_d2h(bdof_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return BDOF_ERR_ARG;
+    HIPC(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+int bdof_memset(bdof_ctx* c, void* dst, int value, size_t bytes) {
+    if (!c) return BDOF_ERR_ARG;
+    HIPC(c, hipMemsetAsync(dst, value, bytes, c->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,168 @@
+// Device-side 1-D FFT building blocks for the multislice kernels (gfx950, wave64).
+//
+// One "line" (a wavefield row along y, or a column along x) of N = 2^n complex points is
+// transformed by T = N/8 threads, 8 points per thread, with a Stockham autosort plan
+// [8, mid..., 8] (mid = radix 2/4/8 stages).  Invariant at BOTH ends of every transform:
+// register u[m] of thread `tid` holds the point at natural position tid + m*T.  That is what
+// lets the kernels chain inverse-FFT -> pointwise physics -> forward-FFT with no exchange in
+// between, and lets global loads/stores stay coalesced (lane-contiguous for fixed m).
+// Exchanges between stages go through LDS (index math validated by tools/fft_plan_model.py).
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float2 cf;
+
+__device__ __forceinline__ cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a * conj(b)
+__device__ __forceinline__ cf cmulc(cf a, cf b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+__device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s, a.y * s); }
+
+// multiply by SIGN*i
+template <int SIGN> __device__ __forceinline__ cf mul_si(cf a) {
+    return SIGN > 0 ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+
+template <int SIGN> __device__ __forceinline__ void dft2(cf& a, cf& b) {
+    cf t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+
+// natural-order outputs X0..X3 left in a0..a3
+template <int SIGN> __device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2, cf& a3) {
+    cf s0 = cadd(a0, a2), s1 = csub(a0, a2), s2 = cadd(a1, a3), s3 = mul_si<SIGN>(csub(a1, a3));
+    a0 = cadd(s0, s2);
+    a2 = csub(s0, s2);
+    a1 = cadd(s1, s3);
+    a3 = csub(s1, s3);
+}
+
+template <int SIGN> __device__ __forceinline__ void dft8(cf& a0, cf& a1, cf& a2, cf& a3, cf& a4, cf& a5, cf& a6, cf& a7) {
+    dft4<SIGN>(a0, a2, a4, a6);   // E0..E3 -> a0,a2,a4,a6
+    dft4<SIGN>(a1, a3, a5, a7);   // O0..O3 -> a1,a3,a5,a7
+    const float h = 0.70710678118654752f;
+    const float s = (float)SIGN;
+    cf o0 = a1;
+    cf o1 = make_float2(h * (a3.x - s * a3.y), h * (a3.y + s * a3.x));      // * (1 + s i)/sqrt2
+    cf o2 = mul_si<SIGN>(a5);                                              // * s i
+    cf o3 = make_float2(h * (-a7.x - s * a7.y), h * (-a7.y + s * a7.x));    // * (-1 + s i)/sqrt2
+    cf e0 = a0, e1 = a2, e2 = a4, e3 = a6;
+    a0 = cadd(e0, o0); a4 = csub(e0, o0);
+    a1 = cadd(e1, o1); a5 = csub(e1, o1);
+    a2 = cadd(e2, o2); a6 = csub(e2, o2);
+    a3 = cadd(e3, o3); a7 = csub(e3, o3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Plans.  radix of stage s and p = product of earlier radices.
+// ---------------------------------------------------------------------------------------------
+template <int N> struct FftPlan;
+template <> struct FftPlan<64>   { static constexpr int NS = 2, R0 = 8, R1 = 8, R2 = 1, R3 = 1; };
+template <> struct FftPlan<128>  { static constexpr int NS = 3, R0 = 8, R1 = 2, R2 = 8, R3 = 1; };
+template <> struct FftPlan<256>  { static constexpr int NS = 3, R0 = 8, R1 = 4, R2 = 8, R3 = 1; };
+template <> struct FftPlan<512>  { static constexpr int NS = 3, R0 = 8, R1 = 8, R2 = 8, R3 = 1; };
+template <> struct FftPlan<1024> { static constexpr int NS = 4, R0 = 8, R1 = 2, R2 = 8, R3 = 8; };
+
+template <int N> struct FftTw {
+    typedef FftPlan<N> P;
+    static constexpr int n1 = (8 / P::R1) * (P::R1 - 1);
+    static constexpr int n2 = P::NS > 2 ? (8 / P::R2) * (P::R2 - 1) : 0;
+    static constexpr int n3 = P::NS > 3 ? (8 / P::R3) * (P::R3 - 1) : 0;
+    static constexpr int OFF1 = 0, OFF2 = n1, OFF3 = n1 + n2, COUNT = n1 + n2 + n3;
+    cf w[COUNT];   // forward (exp(-i..)) twiddles, thread-private, loaded once per kernel
+
+    template <int R, int PP, int OFF> __device__ __forceinline__ void load_stage(const cf* __restrict__ table, int tid) {
+        constexpr int T = N / 8, NB = 8 / R;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            int k = (tid + j * T) % PP;
+#pragma unroll
+            for (int m = 1; m < R; ++m) w[OFF + j * (R - 1) + m - 1] = table[m * k * (N / (PP * R))];
+        }
+    }
+    // table[j] = exp(-2 pi i j / N), j in [0, N)
+    __device__ __forceinline__ void load(const cf* __restrict__ table, int tid) {
+        load_stage<P::R1, P::R0, OFF1>(table, tid);
+        if constexpr (P::NS > 2) load_stage<P::R2, P::R0 * P::R1, OFF2>(table, tid);
+        if constexpr (P::NS > 3) load_stage<P::R3, P::R0 * P::R1 * P::R2, OFF3>(table, tid);
+    }
+};
+
+template <int R, int SIGN> __device__ __forceinline__ void dftR(cf (&u)[8], int j) {
+    if constexpr (R == 8) dft8<SIGN>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+    else if constexpr (R == 4) {
+        if (j == 0) dft4<SIGN>(u[0], u[1], u[2], u[3]); else dft4<SIGN>(u[4], u[5], u[6], u[7]);
+    } else {
+        if (j == 0) dft2<SIGN>(u[0], u[1]); else if (j == 1) dft2<SIGN>(u[2], u[3]);
+        else if (j == 2) dft2<SIGN>(u[4], u[5]); else dft2<SIGN>(u[6], u[7]);
+    }
+}
+
+// One stage, split in its three phases.  L provides ld(idx), st(idx, v) on the line's LDS image.
+template <int N, int R, class L> __device__ __forceinline__ void stage_read(cf (&u)[8], int tid, L& lds) {
+    constexpr int T = N / 8, NB = 8 / R, TT = N / R;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int m = 0; m < R; ++m) u[j * R + m] = lds.ld(tid + j * T + m * TT);
+}
+
+template <int N, int SIGN, int R, int PP, int TWOFF>
+__device__ __forceinline__ void stage_compute(cf (&u)[8], const FftTw<N>& tw) {
+    constexpr int NB = 8 / R;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if constexpr (PP > 1) {
+#pragma unroll
+            for (int m = 1; m < R; ++m) {
+                cf w = tw.w[TWOFF + j * (R - 1) + m - 1];
+                if (SIGN > 0) w.y = -w.y;
+                u[j * R + m] = cmul(u[j * R + m], w);
+            }
+        }
+        dftR<R, SIGN>(u, j);
+    }
+}
+
+template <int N, int R, int PP, class L> __device__ __forceinline__ void stage_write(const cf (&u)[8], int tid, L& lds) {
+    constexpr int T = N / 8, NB = 8 / R;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        int i = tid + j * T;
+        int k = i % PP;
+        int base = (i - k) * R + k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) lds.st(base + q * PP, u[j * R + q]);
+    }
+}
+
+// Full transform of one line.  u[m] <-> position tid + m*T on entry and on exit.
+// Unnormalised; SIGN = -1 forward DFT, +1 inverse.  lds.sync_w2r() orders a stage's stores
+// before the next stage's loads; lds.sync_r2w() orders loads before the stores that reuse the image.
+template <int N, int SIGN, class L>
+__device__ __forceinline__ void line_fft(cf (&u)[8], const FftTw<N>& tw, int tid, L& lds) {
+    typedef FftPlan<N> P;
+    typedef FftTw<N> TW;
+    stage_compute<N, SIGN, P::R0, 1, 0>(u, tw);
+    lds.sync_r2w();
+    stage_write<N, P::R0, 1>(u, tid, lds);
+    lds.sync_w2r();
+    stage_read<N, P::R1>(u, tid, lds);
+    stage_compute<N, SIGN, P::R1, P::R0, TW::OFF1>(u, tw);
+    if constexpr (P::NS > 2) {
+        lds.sync_r2w();
+        stage_write<N, P::R1, P::R0>(u, tid, lds);
+        lds.sync_w2r();
+        stage_read<N, P::R2>(u, tid, lds);
+        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, TW::OFF2>(u, tw);
+    }
+    if constexpr (P::NS > 3) {
+        lds.sync_r2w();
+        stage_write<N, P::R2, P::R0 * P::R1>(u, tid, lds);
+        lds.sync_w2r();
+        stage_read<N, P::R3>(u, tid, lds);
+        stage_compute<N, SIGN, P::R3, P::R0 * P::R1 * P::R2, TW::OFF3>(u, tw);
+    }
+}

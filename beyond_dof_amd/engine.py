@@ -1,0 +1,159 @@
+"""Python host of the multislice engine: owns a libbdof context and converts between the reference's
+array conventions ((B, Y, X, S) objects, (B, Y, X) waves, (Y, X, Z) volumes) and the device layout.
+All arithmetic of the hot path runs in libbdof.so; there is no CPU fallback."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import DeviceBuffer
+from . import util
+
+_DET = {None: _lib.DET_NONE, 'inf': _lib.DET_FAR}
+_VARIANT = {'numpy_skip_last': _lib.VARIANT_NUMPY_SKIP_LAST, 'tf_all': _lib.VARIANT_TF_ALL}
+
+
+def _idx_buf(ctx, values):
+    return DeviceBuffer.from_host(ctx, np.asarray(values, dtype=np.int32))
+
+
+class MultisliceEngine(object):
+    """One wavefield geometry (NY x NX x S) on one GPU."""
+
+    def __init__(self, ny, nx, n_slice, batch_max, with_grad=True, device=0, stream=None):
+        self.ctx = _lib.Context(device, stream)
+        self.lib = self.ctx.lib
+        self.h = self.ctx.handle
+        self.ny, self.nx, self.n_slice, self.batch_max = int(ny), int(nx), int(n_slice), int(batch_max)
+        self.with_grad = bool(with_grad)
+        self.ctx.check(self.lib.bdof_configure(self.h, self.ny, self.nx, self.n_slice, self.batch_max, int(with_grad)))
+        self.det_mode = _lib.DET_NONE
+        self._keep = {}          # device buffers that must outlive the calls that registered them
+        self._tables = None
+
+    # ---- physics -------------------------------------------------------------------------------
+    def set_physics(self, energy_ev, psize_cm, free_prop_cm=None, variant='numpy_skip_last', pi=util.PI):
+        """k and H exactly as cnn_propagator/np_funcs.py:19-32,45-57 derive them from energy / pixel size."""
+        voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
+        lmbda_nm = 1240. / energy_ev
+        delta_nm = voxel_nm[-1]
+        k = 2. * pi * delta_nm / lmbda_nm
+        hs = util.device_transfer_function(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi)
+        hdet = None
+        if free_prop_cm is None:
+            det = _lib.DET_NONE
+        elif isinstance(free_prop_cm, str):
+            if free_prop_cm != 'inf':
+                raise ValueError("free_prop_cm must be None, a distance in cm or 'inf'")
+            det = _lib.DET_FAR
+        else:
+            det = _lib.DET_NEAR
+            hdet = util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi)
+        self.det_mode = det
+        self.k = k
+        self.ctx.check(self.lib.bdof_set_physics(self.h, k, hs.ctypes.data, hdet.ctypes.data if hdet is not None else None,
+                                                 det, _VARIANT[variant]))
+
+    def set_probe(self, probe_real, probe_imag):
+        probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.ny, self.nx))
+        p = np.ascontiguousarray(probe.T.astype(np.complex64))     # the reference rounds to complex64 too (np_funcs.py:20)
+        self.ctx.check(self.lib.bdof_set_probe(self.h, p.ctypes.data))
+
+    # ---- object --------------------------------------------------------------------------------
+    def set_object_batch(self, grid_delta_batch, grid_beta_batch):
+        """Already rotated objects, (B, Y, X, S) each (the np_funcs.py:15 argument convention)."""
+        rows = util.batch_to_rows(grid_delta_batch, grid_beta_batch)
+        buf = DeviceBuffer.from_host(self.ctx, rows)
+        self._keep['obj'] = buf
+        self.ctx.check(self.lib.bdof_set_object(self.h, buf.ptr, self.ny, None, 0, 0))
+        return buf
+
+    def set_volume(self, vol_buf, vol_ny, tab_buf, vol_nx, n_angles):
+        """Un-rotated volume rows [X*Z][vol_ny] pairs + rotation table [n_angles][S][vol_nx] (device)."""
+        self._keep['obj'] = vol_buf
+        self._keep['tab'] = tab_buf
+        self.ctx.check(self.lib.bdof_set_object(self.h, _lib._ptr(vol_buf), int(vol_ny), _lib._ptr(tab_buf), int(vol_nx), int(n_angles)))
+
+    def set_rotation_adjoint(self, off_buf, order_buf, n_dest):
+        self._keep['off'] = off_buf
+        self._keep['order'] = order_buf
+        self.ctx.check(self.lib.bdof_set_rotation_adjoint(self.h, _lib._ptr(off_buf), _lib._ptr(order_buf), int(n_dest)))
+
+    # ---- forward -------------------------------------------------------------------------------
+    def _wave_to_host(self, buf, B):
+        w = buf.download((B, self.nx, self.ny), np.complex64).transpose(0, 2, 1)
+        if self.det_mode == _lib.DET_FAR:
+            w = np.fft.fftshift(w, axes=(1, 2))          # np_funcs.py:48
+        return np.ascontiguousarray(w)
+
+    def _meas_to_device(self, meas_abs):
+        m = np.asarray(meas_abs, dtype=np.float32)
+        if self.det_mode == _lib.DET_FAR:
+            m = np.fft.ifftshift(m, axes=(1, 2))
+        return DeviceBuffer.from_host(self.ctx, np.ascontiguousarray(m.transpose(0, 2, 1)))
+
+    def forward(self, B, angle_idx=None, xoff=None, yoff=None, keep_tape=False, to_host=True):
+        out = DeviceBuffer(self.ctx, B * self.nx * self.ny * 8, np.complex64, (B, self.nx, self.ny))
+        a = _idx_buf(self.ctx, angle_idx) if angle_idx is not None else None
+        xo = _idx_buf(self.ctx, xoff) if xoff is not None else None
+        yo = _idx_buf(self.ctx, yoff) if yoff is not None else None
+        self.ctx.check(self.lib.bdof_forward(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), out.ptr, int(keep_tape)))
+        self.ctx.sync()
+        return self._wave_to_host(out, B) if to_host else out
+
+    def probe_array(self, B):
+        """Per-slice wavefields, (S, B, Y, X) — the second return value of np_funcs.py:65."""
+        out = DeviceBuffer(self.ctx, B * self.nx * self.ny * 8, np.complex64, (B, self.nx, self.ny))
+        res = np.empty((self.n_slice, B, self.ny, self.nx), dtype=np.complex64)
+        for i in range(self.n_slice):
+            self.ctx.check(self.lib.bdof_tape_to_real(self.h, i, B, out.ptr))
+            res[i] = out.download((B, self.nx, self.ny), np.complex64).transpose(0, 2, 1)
+        return res
+
+    # ---- loss + gradient -----------------------------------------------------------------------
+    def loss_grad(self, B, meas_abs, angle_idx=None, xoff=None, yoff=None, meas_on_device=False):
+        """Runs forward + loss + adjoint; returns the loss.  The gradient stays on the device."""
+        m = meas_abs if meas_on_device else self._meas_to_device(meas_abs)
+        a = _idx_buf(self.ctx, angle_idx) if angle_idx is not None else None
+        xo = _idx_buf(self.ctx, xoff) if xoff is not None else None
+        yo = _idx_buf(self.ctx, yoff) if yoff is not None else None
+        self.ctx.check(self.lib.bdof_loss_grad(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), _lib._ptr(m), None))
+        loss = ctypes.c_double(0)
+        self.ctx.check(self.lib.bdof_get_loss(self.h, ctypes.byref(loss)))
+        self._keep['last_idx'] = (a, xo, yo, m)
+        return loss.value
+
+    def grad_batch_to_host(self, B):
+        """Gradient w.r.t. the rotated object batch: (g_delta, g_beta), each (B, Y, X, S)."""
+        n = B * self.n_slice * self.nx * self.ny
+        out = np.empty((B, self.n_slice, self.nx, self.ny, 2), dtype=np.float32)
+        self.ctx.check(self.lib.bdof_memcpy_d2h(self.h, out.ctypes.data, self.lib.bdof_grot(self.h), n * 8))
+        return util.rows_to_batch(out)
+
+    def rotation_adjoint(self, B, angle_idx, gvol_buf, accumulate=False, scale=1.0):
+        a = _idx_buf(self.ctx, angle_idx)
+        self.ctx.check(self.lib.bdof_rotation_adjoint(self.h, B, a.ptr, _lib._ptr(gvol_buf), int(accumulate), float(scale)))
+        self.ctx.sync()
+
+    def adam_step(self, x_old, x_new, g, m, v, mask, shape_xzy, i_batch, lr, g_scale=1.0, alpha_d=0.0, alpha_b=0.0,
+                  gamma=0.0, b1=0.9, b2=0.999, eps=1e-8, clip=True):
+        nxv, nzv, nyv = [int(s) for s in shape_xzy]
+        self.ctx.check(self.lib.bdof_adam_step(self.h, _lib._ptr(x_old), _lib._ptr(x_new), _lib._ptr(g), _lib._ptr(m),
+                                               _lib._ptr(v), _lib._ptr(mask), nxv, nzv, nyv, g_scale, alpha_d, alpha_b, gamma,
+                                               lr, b1, b2, eps, int(i_batch), int(clip)))
+
+    # ---- profiling -----------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self.ctx.check(self.lib.bdof_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        res = {}
+        for cls, name in enumerate(_lib.KERNEL_CLASS_NAMES):
+            n = ctypes.c_int(0)
+            ms = ctypes.c_double(0)
+            self.ctx.check(self.lib.bdof_profile_read(self.h, cls, ctypes.byref(n), ctypes.byref(ms)))
+            res[name] = (n.value, ms.value)
+        return res
+
+    def sync(self):
+        self.ctx.sync()

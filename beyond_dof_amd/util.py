@@ -1,0 +1,146 @@
+"""Host-side helpers of the hot path, mirroring the names of the reference's cnn_propagator/util.py.
+
+Everything here is set-up work that runs once per reconstruction (transfer functions, rotation
+lookup tables, task splitting); the per-step arithmetic lives in libbdof.so.  Tables are computed in
+float64 exactly as the reference does so that the integer lookups are bit-identical.
+"""
+import os
+import sys
+
+import numpy as np
+
+PI = 3.1415927   # the reference's literal (cnn_propagator/util.py:20); it enters k and H
+
+
+def get_kernel(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=PI):
+    """Fresnel transfer function H(u, v) on the reference's inclusive linspace mesh
+    (cnn_propagator/util.py:73-102).  Returns a centred (Y, X) complex128 array."""
+    ny, nx = int(grid_shape[0]), int(grid_shape[1])
+    v = np.linspace(-1. / (2. * voxel_nm[1]), 1. / (2. * voxel_nm[1]), ny)     # rows: v_max = 1/(2 voxel[1])
+    u = np.linspace(-1. / (2. * voxel_nm[0]), 1. / (2. * voxel_nm[0]), nx)     # cols: u_max = 1/(2 voxel[0])
+    uu, vv = np.meshgrid(u, v)
+    k = 2 * pi / lmbda_nm
+    return np.exp(1j * k * dist_nm) * np.exp(-1j * pi * lmbda_nm * dist_nm * (uu ** 2 + vv ** 2))
+
+
+def device_transfer_function(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI):
+    """H prepared for libbdof: un-shifted, transposed to [kx][ky], 1/(NX*NY) folded in, complex64."""
+    h = get_kernel(dist_nm, lmbda_nm, voxel_nm, (ny, nx), pi=pi)
+    hs = np.fft.ifftshift(h).T / float(nx * ny)
+    return np.ascontiguousarray(hs.astype(np.complex64))
+
+
+def rotation_lookup(array_size, n_theta):
+    """Nearest-neighbour rotation source coordinates for every angle, as save_rotation_lookup builds
+    them (cnn_propagator/util.py:294-332) but kept in memory: list of (X*Z, 2) int arrays.  Angles are
+    linspace(0, 2*pi, n_theta) whatever theta_st/theta_end say (reference behaviour)."""
+    ny, nx, nz = [int(a) for a in array_size]
+    cx, cz = np.floor(nx / 2), np.floor(nz / 2)
+    xs = np.repeat(np.arange(nx), nz) - cx
+    zs = np.tile(np.arange(nz), nx) - cz
+    new = np.stack([xs, zs]).astype(np.float32)
+    out = []
+    for theta in np.linspace(0, 2 * np.pi, n_theta):
+        rot = np.array([[np.cos(theta), -np.sin(theta)], [np.sin(theta), np.cos(theta)]])
+        old = np.matmul(rot, new)
+        c1 = np.clip(np.round(old[0] + cx).astype(int), 0, nx - 1)
+        c2 = np.clip(np.round(old[1] + cz).astype(int), 0, nz - 1)
+        out.append(np.stack([c1, c2], axis=1))
+    return out
+
+
+def save_rotation_lookup(array_size, n_theta, dest_folder=None):
+    """Drop-in for cnn_propagator/util.py:294-347: writes the same .npy files and returns the tables."""
+    coords = rotation_lookup(array_size, n_theta)
+    if dest_folder is None:
+        dest_folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(array_size[0], array_size[1], array_size[2], n_theta)
+    if not os.path.exists(dest_folder):
+        os.mkdir(dest_folder)
+    for i, arr in enumerate(coords):
+        np.save(os.path.join(dest_folder, '{:04}'.format(i)), arr)
+    ny, nx, nz = [int(a) for a in array_size]
+    coord0 = np.repeat(np.arange(ny), nx * nz)
+    coord1 = np.tile(np.repeat(np.arange(nx), nz), ny).astype(float)
+    coord2 = np.tile(np.tile(np.arange(nz), nx), ny).astype(float)
+    for i, coord in enumerate([coord0, coord1, coord2]):
+        np.save(os.path.join(dest_folder, 'coord{}_vec'.format(i)), coord)
+    return coords
+
+
+def read_all_origin_coords(src_folder, n_theta):
+    """cnn_propagator/util.py:369-374."""
+    return [np.load(os.path.join(src_folder, '{:04}.npy'.format(i))) for i in range(n_theta)]
+
+
+def device_rotation_tables(coords, nx, nz):
+    """int32 tables for libbdof from the reference-style coordinate lists.
+
+    tab[a][z][x]   = source row (x' * Z + z') of the [X][Z][Y] volume feeding rotated row (x, z)
+    off/order      = per-angle inverse (CSR): for every volume row the rotated rows (z*X + x) it feeds
+    """
+    n = len(coords)
+    tab = np.empty((n, nz, nx), dtype=np.int32)
+    off = np.empty((n, nx * nz + 1), dtype=np.int32)
+    order = np.empty((n, nz * nx), dtype=np.int32)
+    for a, c in enumerate(coords):
+        src = (c[:, 0] * nz + c[:, 1]).reshape(nx, nz)       # indexed [x][z]
+        t = np.ascontiguousarray(src.T)                       # [z][x]
+        tab[a] = t
+        dest = t.reshape(-1)                                  # indexed by s = z*X + x
+        order[a] = np.argsort(dest, kind='stable')
+        off[a, 0] = 0
+        np.cumsum(np.bincount(dest, minlength=nx * nz), out=off[a, 1:])
+    return tab, off, order
+
+
+def split_tasks(arr, split_size):
+    """cnn_propagator/util.py:271-277."""
+    return [arr[i:i + split_size] for i in range(0, len(arr), split_size)]
+
+
+def mag_phase_to_real_imag(mag, phase):
+    """cnn_propagator/util.py:265-268."""
+    a = mag * np.exp(1j * phase)
+    return a.real, a.imag
+
+
+def gaussian_probe(shape, probe_mag_sigma, probe_phase_sigma, probe_phase_max):
+    """Gaussian probe of cnn_propagator/fullfield.py:299-310 / ptychography.py:212-222."""
+    py = np.arange(shape[0]) - (shape[0] - 1.) / 2
+    px = np.arange(shape[1]) - (shape[1] - 1.) / 2
+    pxx, pyy = np.meshgrid(px, py)
+    mag = np.exp(-(pxx ** 2 + pyy ** 2) / (2 * probe_mag_sigma ** 2))
+    phase = probe_phase_max * np.exp(-(pxx ** 2 + pyy ** 2) / (2 * probe_phase_sigma ** 2))
+    return mag_phase_to_real_imag(mag, phase)
+
+
+def print_flush(a, designate_rank=None, this_rank=None):
+    """cnn_propagator/util.py:248-256."""
+    if designate_rank is None or this_rank == designate_rank:
+        print(a)
+    sys.stdout.flush()
+
+
+# ---- layout conversion between the reference's arrays and libbdof's device layout ------------------
+def volume_to_rows(obj_delta, obj_beta):
+    """(Y, X, Z) delta and beta -> [X][Z][Y] (delta, beta) pairs, float32."""
+    pair = np.stack([obj_delta, obj_beta], axis=-1)
+    return np.ascontiguousarray(pair.transpose(1, 2, 0, 3).astype(np.float32))
+
+
+def rows_to_volume(rows):
+    """Inverse of volume_to_rows: [X][Z][Y][2] -> (delta, beta) each (Y, X, Z)."""
+    v = rows.transpose(2, 0, 1, 3)
+    return np.ascontiguousarray(v[..., 0]), np.ascontiguousarray(v[..., 1])
+
+
+def batch_to_rows(grid_delta_batch, grid_beta_batch):
+    """(B, Y, X, S) rotated object batches -> [b][z][x][y] pairs, float32."""
+    pair = np.stack([grid_delta_batch, grid_beta_batch], axis=-1)
+    return np.ascontiguousarray(pair.transpose(0, 3, 2, 1, 4).astype(np.float32))
+
+
+def rows_to_batch(rows):
+    """[b][z][x][y][2] -> (g_delta, g_beta) each (B, Y, X, S)."""
+    v = rows.transpose(0, 3, 2, 1, 4)
+    return np.ascontiguousarray(v[..., 0]), np.ascontiguousarray(v[..., 1])

@@ -1,0 +1,111 @@
+/* bdof.h — C ABI of libbdof.so: MI355X-native multislice Fresnel forward + adjoint + Adam.
+ *
+ * The reference (mdw771/beyond_dof) has no FFI layer; its only seam is a set of Python call
+ * signatures.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference checkout).  The Python host in beyond_dof_amd/ binds these
+ * with ctypes and re-exposes the reference's own function names.
+ *
+ * Conventions
+ *   - every call returns int: 0 ok, <0 bdof argument/state error, >0 hipError_t; text via
+ *     bdof_last_error(ctx).
+ *   - device buffers passed in are caller-owned raw device pointers; the library never frees them.
+ *   - one ctx <-> one device <-> one stream; calls are asynchronous on that stream until
+ *     bdof_sync / bdof_get_loss; a ctx is not thread-safe.
+ *   - complex = interleaved float (re, im); "pair" = interleaved float (delta, beta).
+ *
+ * Internal data layout:
+ *   wavefields        [b][x][y]            y fastest (y = tomographic rotation axis, reference axis 0)
+ *   object rows       [row][y]   of pairs  full-field: row = x*Z + z of the un-rotated volume
+ *   rotated gradient  [b][z][x][y] of pairs
+ */
+#ifndef BDOF_H
+#define BDOF_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bdof_ctx bdof_ctx;
+
+enum { BDOF_DET_NONE = 0, BDOF_DET_NEAR = 1, BDOF_DET_FAR = 2 };      /* free_prop_cm None / float / 'inf'  (np_funcs.py:45-61) */
+enum { BDOF_VARIANT_NUMPY_SKIP_LAST = 0, BDOF_VARIANT_TF_ALL = 1 };   /* np_funcs.py:41 vs tensorflow_recon/util.py:465-483 */
+enum { BDOF_K_ROW_FWD = 0, BDOF_K_COL_PROP = 1, BDOF_K_ROW_BWD = 2, BDOF_K_LOSS = 3, BDOF_K_ROT_ADJ = 4, BDOF_K_ADAM = 5, BDOF_K_COUNT = 6 };
+
+/* lifecycle.  `stream` is a hipStream_t (NULL: the library creates its own). */
+int bdof_ctx_create(bdof_ctx** out, int device, void* stream);
+void bdof_ctx_destroy(bdof_ctx* ctx);
+const char* bdof_last_error(const bdof_ctx* ctx);
+int bdof_sync(bdof_ctx* ctx);
+int bdof_device_count(void);
+
+/* Workspace for wavefields of NY x NX (powers of two, 64..1024), S slices, up to Bmax wavefields per
+ * launch.  with_grad != 0 also allocates the tape (S-1 hybrid fields per wavefield) and the
+ * rotated-frame gradient.  Replaces the per-call allocations of multislice_propagate_batch_numpy
+ * (cnn_propagator/np_funcs.py:20,43) and of autograd's tape (cnn_propagator/fullfield.py:329). */
+int bdof_configure(bdof_ctx* ctx, int NY, int NX, int S, int Bmax, int with_grad);
+
+/* Physics.  k = 2*PI*delta_nm/lambda_nm (np_funcs.py:32).  hs / hs_det: HOST arrays [NX][NY] complex,
+ * hs[kx][ky] = ifftshift(get_kernel(...))[ky][kx] / (NX*NY)   (cnn_propagator/util.py:82-102, np_funcs.py:42);
+ * the host computes them in float64 exactly as the reference does and rounds once to float32.
+ * hs_det may be NULL unless det_mode == BDOF_DET_NEAR. */
+int bdof_set_physics(bdof_ctx* ctx, double k, const float* hs, const float* hs_det, int det_mode, int variant);
+
+/* Probe wavefront, HOST [NX][NY] complex (np_funcs.py:20-21; cnn_propagator/fullfield.py:276-314). */
+int bdof_set_probe(bdof_ctx* ctx, const float* probe);
+
+/* Object.  vol: device rows of volNY pairs.  tab == NULL: row(b,z,x) = (b*S+z)*NX+x, i.e. the caller
+ * supplies already rotated objects (the grid_delta_batch/grid_beta_batch arguments of
+ * multislice_propagate_batch_numpy).  tab != NULL (device, [n_angles][S][volNX] int32): fused
+ * nearest-neighbour rotation gather, row = tab[angle][z][x]  (apply_rotation, cnn_propagator/util.py:377-402
+ * with the tables of save_rotation_lookup, util.py:294-347). */
+int bdof_set_object(bdof_ctx* ctx, const void* vol, int volNY, const int* tab, int volNX, int n_angles);
+
+/* Inverse rotation tables for the gradient (device): off [n_angles][n_dest+1], order [n_angles][S*volNX]. */
+int bdof_set_rotation_adjoint(bdof_ctx* ctx, const int* off, const int* order, int n_dest);
+
+/* Forward model only: replaces multislice_propagate_batch_numpy (np_funcs.py:15-65).
+ * angle_of_b / xoff / yoff: device int32 [B] or NULL.  out_wave: device [B][NX][NY] complex, detector
+ * wave (far field: un-shifted fft2, the caller applies fftshift).  keep_tape != 0 keeps the per-slice
+ * hybrid fields for bdof_tape_to_real (needs with_grad). */
+int bdof_forward(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave, int keep_tape);
+
+/* probe_array[i] of np_funcs.py:43 (wave after slice i), device out [B][NX][NY]; valid after a
+ * bdof_forward(keep_tape=1) or bdof_loss_grad. */
+int bdof_tape_to_real(bdof_ctx* ctx, int i, int B, void* out);
+
+/* Loss + gradient: replaces loss_grad = autograd.grad(calculate_loss,[0,1]) for the multislice part
+ * (cnn_propagator/fullfield.py:93-106,329,345; cnn_propagator/ptychography.py:30-81,248,301).
+ * meas: device float [B][NX][NY] = |measured| in this library's index order (far field: un-shifted).
+ * loss = mean((|d|-meas)^2) is left on the device (bdof_get_loss); the gradient w.r.t. the rotated /
+ * windowed (delta,beta) is left in the ctx (bdof_grot). out_wave may be NULL. */
+int bdof_loss_grad(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, void* out_wave);
+int bdof_get_loss(bdof_ctx* ctx, double* loss);
+void* bdof_grot(bdof_ctx* ctx);      /* device [B][S][NX][NY] pairs */
+
+/* Adjoint of the rotation gather: gvol[dest][y] (+)= scale * sum over the batch of the rows gathered
+ * from dest.  gvol: device [n_dest][NY] pairs. */
+int bdof_rotation_adjoint(bdof_ctx* ctx, int B, const int* angle_of_b, void* gvol, int accumulate, float scale);
+
+/* Fused regulariser gradient + Adam + mask + clip on a volume [NXv][NZv][NYv] of pairs.
+ * Replaces cnn_propagator/fullfield.py:109-118 (gradient of the L1 + TV terms), apply_gradient_adam
+ * (cnn_propagator/util.py:280-291) and the constraints of fullfield.py:359-362.  g is the data-term
+ * gradient summed over ranks; g_scale = 1/size (fullfield.py:351). */
+int bdof_adam_step(bdof_ctx* ctx, const void* x_old, void* x_new, const void* g, void* m, void* v, const float* mask,
+                   int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
+                   float lr, float b1, float b2, float eps, int i_batch, int clip);
+
+/* Per-kernel-class timing with HIP events on the ctx stream (bench.py roofline leg). */
+int bdof_profile_enable(bdof_ctx* ctx, int enable);
+int bdof_profile_read(bdof_ctx* ctx, int kernel_class, int* n_launches, double* total_ms);
+
+/* Device memory helpers for hosts without an allocator of their own. */
+int bdof_malloc(void** ptr, size_t bytes);
+int bdof_free(void* ptr);
+int bdof_memcpy_h2d(bdof_ctx* ctx, void* dst, const void* src, size_t bytes);
+int bdof_memcpy_d2h(bdof_ctx* ctx, void* dst, const void* src, size_t bytes);
+int bdof_memset(bdof_ctx* ctx, void* dst, int value, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
