@@ -1,0 +1,156 @@
+#!/usr/bin/env python
+"""bench.py — Adam iterations of the full-field multislice reconstruction on synthetic data.
+
+One "step" = one Adam iteration of cnn_propagator/fullfield.py:340-362 on this rank's minibatch of
+projection angles: fused rotation + multislice forward, magnitude loss, hand-derived adjoint, rotation
+adjoint, (RCCL all-reduce of the volume gradient when N > 1), fused regulariser + Adam + mask + clip.
+Workload (BASELINE.json configs[2] per GPU, weak scaling): 512^3 charcoal-like random (delta, beta)
+volume, 25 angles per GPU per step, 5 keV, 1 nm voxels, free_prop_cm = 1e-4.
+
+Prints ONE JSON line (rank 0).  value = slice-steps/s = n_gpus * angles_per_gpu * slices * steps / time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per pixel per launch (they sum to SURVEY §8(d)'s 104 B per slice-step)
+BYTES_PER_PX = {'row_fwd': 24.0, 'col_prop': 16.0, 'row_bwd': 40.0, 'rot_adjoint': 8.0}
+HBM_PEAK = 8.0e12
+
+
+def make_phantom(n, seed=3):
+    """'charcoal-like': U(0, 2e-6) box-smoothed over 3 voxels, beta = 0.1 delta."""
+    from scipy.ndimage import uniform_filter
+    rng = np.random.default_rng(seed)
+    d = rng.random((n, n, n), dtype=np.float32) * np.float32(2e-6)
+    d = uniform_filter(d, size=3, mode='wrap')
+    return d, (0.1 * d).astype(np.float32)
+
+
+def cpu_baseline(size, n_slice, seed=11):
+    """Oracle (numpy restatement of np_funcs.py + adjoint) forward+adjoint on one host core."""
+    from oracle import bdof_oracle as orc
+    rng = np.random.default_rng(seed)
+    delta = rng.uniform(0, 2e-6, size=(1, size, size, n_slice))
+    beta = 0.1 * delta
+    pr, pi = np.ones((size, size)), np.zeros((size, size))
+    meas = np.ones((1, size, size))
+    t0 = time.perf_counter()
+    orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, 1e-4)
+    dt = time.perf_counter() - t0
+    return {'value': n_slice / dt, 'unit': 'slice-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': '{0}x{0} wavefield, {1} slices, 1 angle, fwd+adjoint, complex128 numpy ({2:.1f} s)'.format(size, n_slice, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--angles-per-gpu', type=int, default=25)
+    ap.add_argument('--n-theta', type=int, default=200)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-slices', type=int, default=96)
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
+
+    from beyond_dof_amd.comm import PseudoComm, TorchComm, minibatch_schedule
+    from beyond_dof_amd.solver import FullfieldSolver
+
+    comm = PseudoComm()
+    if world > 1:
+        import torch
+        torch.cuda.set_device(local_rank)
+        comm = TorchComm('nccl')
+
+    n, mb, n_theta = args.size, args.angles_per_gpu, args.n_theta
+    sched = minibatch_schedule(n_theta, world, mb, rng=np.random.default_rng(1234))
+    my_batches = [chunk[rank * mb:(rank + 1) * mb] for chunk in sched]
+    my_angles = np.unique(np.concatenate(my_batches[:min(len(my_batches), args.steps + args.warmup)]))
+
+    t_setup = time.time()
+    solver = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, comm=comm, device=local_rank)
+    true_d, true_b = make_phantom(n)
+    solver.set_volume(true_d, true_b)
+    meas = np.zeros((n_theta, n, n), dtype=np.float32)
+    meas[my_angles] = np.abs(solver.forward_angles(my_angles))       # synthetic data from our own forward model
+    solver.set_measurements(meas)
+    del meas
+    rng = np.random.default_rng(100)                                   # same initial guess on every rank
+    init_d = np.clip(rng.normal(8.7e-7, 1e-7, size=(n, n, n)), 0, None).astype(np.float32)   # fullfield.py:250-253
+    init_b = np.clip(rng.normal(5.1e-8, 1e-8, size=(n, n, n)), 0, None).astype(np.float32)
+    solver.set_volume(init_d, init_b)
+    solver.set_mask(np.ones((n, n, n), dtype=np.float32))
+    del true_d, true_b, init_d, init_b
+    hyper = dict(learning_rate=1e-7, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)     # params_cone, reconstruct_fullfield.py:50-56
+    if rank == 0:
+        print('[bench] setup {:.1f} s'.format(time.time() - t_setup), file=sys.stderr)
+
+    def run(i):
+        solver.step(i % len(my_batches), my_batches[i % len(my_batches)], want_loss=False, **hyper)
+
+    for i in range(args.warmup):
+        run(i)
+    solver.ctx.sync()
+    comm.Barrier()
+    if not args.no_profile:
+        solver.eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        run(i)
+    solver.ctx.sync()
+    comm.Barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        elapsed = float(comm.allreduce_sum_host(np.array([elapsed if r == rank else 0.0 for r in range(world)])).max())
+    prof = solver.eng.profile_read() if not args.no_profile else {}
+    loss = solver.loss_and_grad(my_batches[0], want_loss=True)
+
+    if rank == 0:
+        S = n
+        slice_steps = world * mb * S * args.steps
+        px = mb * n * n
+        roof = None
+        if prof:
+            per_class = {}
+            for name, bpp in BYTES_PER_PX.items():
+                cnt, ms = prof[name]
+                if cnt:
+                    npx = px * (S if name == 'rot_adjoint' else 1)
+                    per_class[name] = {'launches': cnt, 'avg_ms': ms / cnt, 'GBps': bpp * npx / (ms / cnt * 1e-3) / 1e9}
+            dom = max(per_class, key=lambda k: per_class[k]['avg_ms'] * per_class[k]['launches'])
+            ach = per_class[dom]['GBps']
+            roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                    'frac': ach * 1e9 / HBM_PEAK, 'traffic': None, 'per_kernel': per_class,
+                    'whole_step_frac': 104.0 * n * n * (slice_steps / world) / elapsed / HBM_PEAK}
+        out = {'metric': 'multislice fwd+adjoint slice-steps/s (full Adam iteration: rotation, forward, loss, adjoint, '
+                         'gradient all-reduce, regulariser+Adam)',
+               'value': slice_steps / elapsed, 'unit': 'slice-steps/s', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'adam_iters_per_s': args.steps / elapsed, 'final_loss': loss,
+               'config': {'workload': 'cfg3: {0}^3 charcoal-like random (delta,beta) volume, {1} of {2} angles per GPU per '
+                                      'Adam step, {0} slices, 5 keV, 1 nm, free_prop_cm=1e-4, plane probe'.format(n, mb, n_theta),
+                          'global_batch_angles': world * mb, 'parallelism': 'angle-sharded dp{}'.format(world)},
+               'roofline': roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(n, args.cpu_slices)
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

@@ -44,6 +44,7 @@ _SIGNATURES = {
     'bdof_memcpy_h2d': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     'bdof_memcpy_d2h': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     'bdof_memset': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_size_t]),
+    'bdof_memcpy_d2d': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
 }
 EXPORTED_SYMBOLS = sorted(_SIGNATURES)
 

@@ -1,0 +1,101 @@
+"""Process group used by the reconstruction loops: one process per GPU.
+
+The reference uses mpi4py COMM_WORLD (Allreduce / Barrier, cnn_propagator/fullfield.py:124-134,348-351)
+and degrades to a single fake rank when MPI is absent (cnn_propagator/pseudo.py:27-33).  Here the group
+is torch.distributed — backend "nccl" (= RCCL over xGMI) for device buffers, "gloo" in CPU tests — with
+the same single-rank fallback."""
+import os
+
+import numpy as np
+
+
+class PseudoComm(object):
+    """size-1 stand-in, the counterpart of cnn_propagator/pseudo.py:Mpi."""
+    size = 1
+    rank = 0
+    local_rank = 0
+
+    def Barrier(self):
+        pass
+
+    def allreduce_sum_device(self, buf, stream_sync=None):
+        return buf
+
+    def allreduce_sum_host(self, arr):
+        return arr
+
+    def bcast_host(self, arr, root=0):
+        return arr
+
+
+class TorchComm(object):
+    """torch.distributed group.  Device buffers are all-reduced in place through RCCL."""
+
+    def __init__(self, backend=None):
+        import torch
+        import torch.distributed as dist
+        self.torch = torch
+        self.dist = dist
+        if not dist.is_initialized():
+            if backend is None:
+                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            dist.init_process_group(backend=backend)
+        self.size = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.local_rank = int(os.environ.get('LOCAL_RANK', self.rank))
+        self.backend = dist.get_backend()
+
+    def Barrier(self):
+        self.dist.barrier()
+
+    def as_tensor(self, buf):
+        """Zero-copy torch view of a DeviceBuffer (or pass a tensor through)."""
+        if isinstance(buf, self.torch.Tensor):
+            return buf
+        return self.torch.as_tensor(buf, device='cuda:{}'.format(self.torch.cuda.current_device()))
+
+    def allreduce_sum_device(self, buf, stream_sync=None):
+        """SUM all-reduce of the volume gradient (cnn_propagator/fullfield.py:350).  `stream_sync` is
+        called first so that the producer stream has finished writing `buf`."""
+        if stream_sync is not None:
+            stream_sync()
+        t = self.as_tensor(buf)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        if t.is_cuda:
+            self.torch.cuda.current_stream().synchronize()
+        return buf
+
+    def allreduce_sum_host(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr))
+        if self.backend == 'nccl':
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def bcast_host(self, arr, root=0):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr))
+        if self.backend == 'nccl':
+            t = t.cuda()
+        self.dist.broadcast(t, src=root)
+        return t.cpu().numpy()
+
+
+def get_comm(backend=None):
+    """TorchComm when launched under torch.distributed.run (WORLD_SIZE set), else the single-rank fallback."""
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        return TorchComm(backend)
+    return PseudoComm()
+
+
+def minibatch_schedule(n_theta, size, minibatch_size, rng=None, shuffle=True):
+    """Index lists of one epoch (cnn_propagator/fullfield.py:196-203): shuffle, pad to a multiple of
+    size*minibatch with the first indices (the evident intent of the malformed np.concatenate at :200,
+    SURVEY quirk Q7), split, sort each chunk.  Rank r then takes chunk[r*mb:(r+1)*mb] (fullfield.py:343)."""
+    ind = np.arange(n_theta)
+    if shuffle:
+        (rng or np.random).shuffle(ind)
+    n_tot = size * minibatch_size
+    if n_theta % n_tot > 0:
+        ind = np.concatenate([ind, ind[:n_tot - n_theta % n_tot]])
+    return [np.sort(ind[i:i + n_tot]) for i in range(0, len(ind), n_tot)]

@@ -531,4 +531,10 @@ int bdof_memset(bdof_ctx* c, void* dst, int value, size_t bytes) {
     return 0;
 }
 
+int bdof_memcpy_d2d(bdof_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return BDOF_ERR_ARG;
+    HIPC(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
 }  // extern "C"

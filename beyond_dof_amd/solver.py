@@ -1,0 +1,128 @@
+"""Device-resident state of a full-field reconstruction: the (delta, beta) volume, its Adam moments,
+the rotation tables and the measured amplitudes, plus the Adam iteration built from libbdof calls.
+This is the loop body of cnn_propagator/fullfield.py:340-362 with every array kept in HBM."""
+import numpy as np
+
+from . import _lib
+from ._lib import DeviceBuffer
+from . import util
+from .comm import PseudoComm
+from .engine import MultisliceEngine
+
+
+class FullfieldSolver(object):
+    def __init__(self, dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm, free_prop_cm=None,
+                 probe_real=None, probe_imag=None, variant='numpy_skip_last', comm=None, device=0, stream=None,
+                 coord_ls=None):
+        self.dim_y, self.dim_x, self.dim_z = int(dim_y), int(dim_x), int(dim_z)
+        self.n_theta, self.mb = int(n_theta), int(minibatch_size)
+        self.comm = comm or PseudoComm()
+        self.eng = MultisliceEngine(self.dim_y, self.dim_x, self.dim_z, self.mb, with_grad=True, device=device, stream=stream)
+        self.ctx = self.eng.ctx
+        self.eng.set_physics(energy_ev, psize_cm, free_prop_cm, variant=variant)
+        if probe_real is None:
+            probe_real, probe_imag = np.ones((dim_y, dim_x)), np.zeros((dim_y, dim_x))   # 'plane', fullfield.py:276-278
+        self.eng.set_probe(probe_real, probe_imag)
+        # rotation lookup tables (cnn_propagator/util.py:294-347), uploaded once
+        if coord_ls is None:
+            coord_ls = util.rotation_lookup([dim_y, dim_x, dim_z], n_theta)
+        tab, off, order = util.device_rotation_tables(coord_ls, self.dim_x, self.dim_z)
+        self.tab = DeviceBuffer.from_host(self.ctx, tab)
+        self.off = DeviceBuffer.from_host(self.ctx, off)
+        self.order = DeviceBuffer.from_host(self.ctx, order)
+        nvox = self.dim_x * self.dim_z * self.dim_y
+        shape = (self.dim_x, self.dim_z, self.dim_y, 2)
+        self.x = [DeviceBuffer.zeros(self.ctx, shape, np.float32), DeviceBuffer.zeros(self.ctx, shape, np.float32)]
+        self.cur = 0
+        self.g = DeviceBuffer.zeros(self.ctx, shape, np.float32)
+        self.m = DeviceBuffer.zeros(self.ctx, shape, np.float32)
+        self.v = DeviceBuffer.zeros(self.ctx, shape, np.float32)
+        self.mask = None
+        self.meas = None
+        self.meas_stage = DeviceBuffer(self.ctx, self.mb * self.dim_x * self.dim_y * 4, np.float32,
+                                       (self.mb, self.dim_x, self.dim_y))
+        self.angle_buf = DeviceBuffer(self.ctx, self.mb * 4, np.int32, (self.mb,))
+        self.nvox = nvox
+        self._bind_volume()
+        self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
+
+    def _bind_volume(self):
+        self.eng.set_volume(self.x[self.cur], self.dim_y, self.tab, self.dim_x, self.n_theta)
+
+    # ---- state -------------------------------------------------------------------------------
+    def set_volume(self, obj_delta, obj_beta):
+        self.x[self.cur].upload(util.volume_to_rows(obj_delta, obj_beta))
+
+    def get_volume(self):
+        self.ctx.sync()
+        return util.rows_to_volume(self.x[self.cur].download())
+
+    def set_mask(self, mask):
+        self.mask = None if mask is None else DeviceBuffer.from_host(
+            self.ctx, np.ascontiguousarray(np.asarray(mask, dtype=np.float32).transpose(1, 2, 0)))
+
+    def set_measurements(self, prj_abs):
+        """|prj| for every angle, (n_theta, Y, X) (loss uses np.abs(this_prj_batch), fullfield.py:106)."""
+        m = np.asarray(prj_abs, dtype=np.float32)
+        if self.eng.det_mode == _lib.DET_FAR:
+            m = np.fft.ifftshift(m, axes=(1, 2))
+        self.meas = DeviceBuffer.from_host(self.ctx, np.ascontiguousarray(m.transpose(0, 2, 1)))
+
+    def reset_moments(self):
+        """m, v = (None, None) at the start of every epoch (fullfield.py:338, quirk Q10)."""
+        lib, h = self.ctx.lib, self.ctx.handle
+        self.ctx.check(lib.bdof_memset(h, self.m.ptr, 0, self.m.nbytes))
+        self.ctx.check(lib.bdof_memset(h, self.v.ptr, 0, self.v.nbytes))
+
+    # ---- one Adam iteration ------------------------------------------------------------------
+    def _stage_batch(self, angle_idx):
+        lib, h = self.ctx.lib, self.ctx.handle
+        idx = np.asarray(angle_idx, dtype=np.int32)
+        assert len(idx) == self.mb
+        self.angle_buf.upload(idx)
+        per = self.dim_x * self.dim_y * 4
+        for b, j in enumerate(idx):
+            self.ctx.check(lib.bdof_memcpy_d2d(h, self.meas_stage.ptr + b * per, self.meas.ptr + int(j) * per, per))
+
+    def loss_and_grad(self, angle_idx, want_loss=True):
+        """Data-term loss and its gradient w.r.t. the volume for this rank's angles (left in self.g)."""
+        lib, h = self.ctx.lib, self.ctx.handle
+        self._stage_batch(angle_idx)
+        self.ctx.check(lib.bdof_loss_grad(h, self.mb, self.angle_buf.ptr, None, None, self.meas_stage.ptr, None))
+        self.ctx.check(lib.bdof_rotation_adjoint(h, self.mb, self.angle_buf.ptr, self.g.ptr, 0, 1.0))
+        if want_loss:
+            import ctypes
+            loss = ctypes.c_double(0)
+            self.ctx.check(lib.bdof_get_loss(h, ctypes.byref(loss)))
+            return loss.value
+        return None
+
+    def adam_update(self, i_batch, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, clip=True, use_mask=True):
+        lib, h = self.ctx.lib, self.ctx.handle
+        new = 1 - self.cur
+        self.eng.adam_step(self.x[self.cur], self.x[new], self.g, self.m, self.v, self.mask if use_mask else None,
+                           (self.dim_x, self.dim_z, self.dim_y), i_batch, learning_rate, g_scale=1.0 / self.comm.size,
+                           alpha_d=alpha_d, alpha_b=alpha_b, gamma=gamma, clip=clip)
+        self.cur = new
+        self._bind_volume()
+
+    def step(self, i_batch, angle_idx, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, want_loss=False):
+        """grads = loss_grad(...); Allreduce; /size; Adam; mask; clip   (fullfield.py:345-362)."""
+        loss = self.loss_and_grad(angle_idx, want_loss=want_loss)
+        if self.comm.size > 1:
+            self.comm.allreduce_sum_device(self.g, stream_sync=self.ctx.sync)
+        self.adam_update(i_batch, learning_rate, alpha_d, alpha_b, gamma)
+        return loss
+
+    def gradient_to_host(self):
+        self.ctx.sync()
+        return util.rows_to_volume(self.g.download())
+
+    def forward_angles(self, angle_idx):
+        """Detector waves (len(idx), Y, X) of the current volume — the forward_pass of fullfield.py:79-91."""
+        idx = np.asarray(angle_idx, dtype=np.int32)
+        out = []
+        for i in range(0, len(idx), self.mb):
+            chunk = idx[i:i + self.mb]
+            out.append(self.eng.forward(len(chunk), angle_idx=chunk))
+        return np.concatenate(out, axis=0)

@@ -104,6 +104,7 @@ int bdof_free(void* ptr);
 int bdof_memcpy_h2d(bdof_ctx* ctx, void* dst, const void* src, size_t bytes);
 int bdof_memcpy_d2h(bdof_ctx* ctx, void* dst, const void* src, size_t bytes);
 int bdof_memset(bdof_ctx* ctx, void* dst, int value, size_t bytes);
+int bdof_memcpy_d2d(bdof_ctx* ctx, void* dst, const void* src, size_t bytes);   /* asynchronous on the ctx stream */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,50 @@
+"""CPU-side checks of the drop-in boundary: libbdof.so loads and exports every symbol that
+include/bdof.h declares; the product path refuses to run without a GPU (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+import __graft_entry__ as entry
+from beyond_dof_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    entry.build()
+    return _lib.load()
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'bdof.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(bdof_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    assert _header_symbols() == _lib.EXPORTED_SYMBOLS
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    for name in _header_symbols():
+        assert hasattr(built_lib, name), name
+
+
+def test_no_cpu_fallback(built_lib):
+    """Without a HIP device the engine must fail loudly (bdof_device_count() == 0 here)."""
+    if built_lib.bdof_device_count() > 0:
+        pytest.skip('a GPU is present')
+    from beyond_dof_amd.engine import MultisliceEngine
+    with pytest.raises(_lib.BdofError):
+        MultisliceEngine(64, 64, 4, 1)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'beyond_dof_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('no CPU fallback', ''), os.path.join(dirpath, f)

@@ -1,0 +1,255 @@
+"""Parity of the HIP path (through the C ABI, libbdof.so) with the CPU oracle and with the golden
+vectors captured from the reference.  Tolerances are float32-vs-float64 and written per test:
+
+  * forward intensities: relative L2 error <= 1e-5 (BASELINE.json north_star)
+  * loss: relative 1e-5;  gradients: relative L2 <= 2e-4 — the seed 2(|d|-|m|)d/|d| subtracts two
+    float32 numbers of size ~1, so the gradient's relative error is (forward error ~1e-6)/(relative
+    residual ~5e-2); the float64 oracle does not have this cancellation.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bdof_oracle as orc
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope='module')
+def engine_mod():
+    import __graft_entry__ as entry
+    entry.build()
+    from beyond_dof_amd import engine
+    return engine
+
+
+def _case(engine_mod, B, Y, X, S, fp, variant, seed=0, dmax=2e-5, probe='random', bmax=None):
+    rng = np.random.default_rng(seed)
+    delta = rng.uniform(0, dmax, size=(B, Y, X, S))
+    beta = 0.1 * delta
+    if probe == 'plane':
+        pr, pi = np.ones((Y, X)), np.zeros((Y, X))
+    elif probe == 'gaussian':
+        pr, pi = orc.gaussian_probe((Y, X), Y / 10., Y / 10., 0.5)
+    else:
+        pr, pi = 1 + 0.1 * rng.normal(size=(Y, X)), 0.1 * rng.normal(size=(Y, X))
+    eng = engine_mod.MultisliceEngine(Y, X, S, bmax or B, with_grad=True)
+    eng.set_physics(5000., 1e-7, fp, variant=variant)
+    eng.set_probe(pr, pi)
+    eng.set_object_batch(delta, beta)
+    return eng, delta, beta, pr, pi, rng
+
+
+@pytest.mark.parametrize('name,fp', [('none', None), ('near', 1e-4), ('inf', 'inf')])
+def test_forward_golden_cfg1(engine_mod, golden_dir, name, fp):
+    """BASELINE.json configs[0]: 64^3 tube phantom, 1 angle, 32 slices — against the reference's own output."""
+    g = np.load(os.path.join(golden_dir, 'g2_forward_cfg1.npz'))
+    delta = g['delta']
+    from beyond_dof_amd import np_funcs
+    wave, probe_array = np_funcs.multislice_propagate_batch_numpy(
+        delta, 0.1 * delta, np.ones((64, 64)), np.zeros((64, 64)), 5000., 1e-7, free_prop_cm=fp,
+        obj_batch_shape=delta.shape)
+    ref = g['wave_' + name]
+    assert wave.shape == ref.shape
+    assert rel(np.abs(wave) ** 2, np.abs(ref) ** 2) <= 1e-5
+    assert rel(wave, ref) <= 5e-6
+    if name == 'none':
+        assert probe_array.shape == (32, 1, 64, 64)
+        np.testing.assert_allclose(np.abs(probe_array).sum(axis=(1, 2, 3)), g['probe_array_abs_sum'], rtol=1e-5)
+        assert rel(probe_array[-1], g['probe_array_last']) <= 5e-6
+
+
+@pytest.mark.parametrize('Y,X', [(64, 64), (128, 128), (64, 256), (256, 128)])
+@pytest.mark.parametrize('fp', [None, 1e-4, 'inf'])
+@pytest.mark.parametrize('variant', ['numpy_skip_last', 'tf_all'])
+def test_forward_and_gradient_vs_oracle(engine_mod, Y, X, fp, variant):
+    B, S = 2, 5
+    eng, delta, beta, pr, pi, rng = _case(engine_mod, B, Y, X, S, fp, variant, probe='gaussian' if fp == 'inf' else 'random')
+    wave = eng.forward(B)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, fp, delta.shape, variant=variant,
+                                                  return_probe_array=False)
+    assert rel(np.abs(wave) ** 2, np.abs(ref) ** 2) <= 1e-5
+    assert rel(wave, ref) <= 5e-6
+    meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
+    loss = eng.loss_grad(B, meas)
+    gd, gb = eng.grad_batch_to_host(B)
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, fp, variant)
+    assert abs(loss - rl) <= 1e-5 * abs(rl)
+    assert rel(gd, rgd) <= 2e-4
+    assert rel(gb, rgb) <= 2e-4
+
+
+@pytest.mark.parametrize('B,Y,X,S,fp', [(3, 256, 256, 16, 1e-4), (2, 512, 512, 8, 1e-4), (1, 1024, 1024, 3, None),
+                                        (1, 512, 1024, 3, 'inf')])
+def test_larger_sizes_vs_oracle(engine_mod, B, Y, X, S, fp):
+    eng, delta, beta, pr, pi, rng = _case(engine_mod, B, Y, X, S, fp, 'numpy_skip_last', probe='gaussian' if fp == 'inf' else 'random')
+    wave = eng.forward(B)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, fp, delta.shape, return_probe_array=False)
+    assert rel(np.abs(wave) ** 2, np.abs(ref) ** 2) <= 1e-5
+    meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
+    loss = eng.loss_grad(B, meas)
+    gd, gb = eng.grad_batch_to_host(B)
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, fp)
+    assert abs(loss - rl) <= 1e-5 * abs(rl)
+    assert rel(gd, rgd) <= 2e-4 and rel(gb, rgb) <= 2e-4
+
+
+def test_probe_array_history(engine_mod):
+    B, Y, X, S = 2, 64, 128, 6
+    eng, delta, beta, pr, pi, _ = _case(engine_mod, B, Y, X, S, None, 'numpy_skip_last')
+    eng.forward(B, keep_tape=True)
+    pa = eng.probe_array(B)
+    _, ref = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, None, delta.shape)
+    assert pa.shape == ref.shape
+    for i in range(S):
+        assert rel(pa[i], ref[i]) <= 5e-6
+
+
+def test_edge_cases(engine_mod):
+    # single slice, batch smaller than the workspace, strong absorption, zero measurement
+    eng, delta, beta, pr, pi, rng = _case(engine_mod, 1, 64, 64, 1, 1e-4, 'tf_all', bmax=4)
+    wave = eng.forward(1)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, 1e-4, delta.shape, variant='tf_all')
+    assert rel(wave, ref) <= 5e-6
+    eng, delta, beta, pr, pi, rng = _case(engine_mod, 3, 64, 64, 4, None, 'numpy_skip_last', dmax=5e-3, bmax=5)
+    beta = 5.0 * delta                                   # k*beta up to 0.6: strong absorption
+    eng.set_object_batch(delta, beta)
+    wave = eng.forward(3)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, None, delta.shape)
+    assert rel(np.abs(wave) ** 2, np.abs(ref) ** 2) <= 1e-5
+    meas = np.zeros_like(np.abs(ref))                    # |m| = 0: seed 2|d| d/|d| / n
+    loss = eng.loss_grad(3, meas)
+    gd, gb = eng.grad_batch_to_host(3)
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, None)
+    assert abs(loss - rl) <= 1e-5 * rl
+    assert rel(gb, rgb) <= 1e-5                          # no cancellation here: tight
+    # zero probe: |d| = 0 everywhere -> finite (zero) gradient, not NaN
+    eng.set_probe(np.zeros((64, 64)), np.zeros((64, 64)))
+    loss = eng.loss_grad(3, np.abs(ref))
+    gd, gb = eng.grad_batch_to_host(3)
+    assert np.isfinite(loss) and np.all(gd == 0) and np.all(gb == 0)
+
+
+def test_error_behaviour(engine_mod):
+    from beyond_dof_amd import _lib
+    with pytest.raises(_lib.BdofError):
+        engine_mod.MultisliceEngine(72, 72, 4, 1)                 # not a supported FFT length
+    eng = engine_mod.MultisliceEngine(64, 64, 4, 2, with_grad=False)
+    eng.set_physics(5000., 1e-7, None)
+    eng.set_probe(np.ones((64, 64)), np.zeros((64, 64)))
+    eng.set_object_batch(np.zeros((2, 64, 64, 4)), np.zeros((2, 64, 64, 4)))
+    with pytest.raises(_lib.BdofError):
+        eng.loss_grad(2, np.ones((2, 64, 64)))                    # no gradient workspace
+    with pytest.raises(_lib.BdofError):
+        eng.forward(3)                                            # B > Bmax
+    with pytest.raises(ValueError):
+        eng.set_physics(5000., 1e-7, 'far')
+
+
+def test_fullfield_fused_rotation_and_adjoint(engine_mod):
+    """apply_rotation fused into the row kernels + CSR adjoint vs the oracle's gather / scatter-add."""
+    from beyond_dof_amd.solver import FullfieldSolver
+    n, n_theta, mb, fp = 64, 8, 3, 1e-4
+    rng = np.random.default_rng(0)
+    od = rng.uniform(0, 2e-6, size=(n, n, n))
+    ob = 0.1 * od
+    coords = orc.rotation_lookup([n, n, n], n_theta)
+    idx = np.array([1, 4, 6])
+    rot = np.stack([orc.apply_rotation(np.stack([od, ob], axis=3), coords[j]) for j in idx])
+    one, zero = np.ones((n, n)), np.zeros((n, n))
+    ref_wave, _ = orc.multislice_propagate_batch_numpy(rot[..., 0], rot[..., 1], one, zero, 5000., 1e-7, fp,
+                                                       rot[..., 0].shape, return_probe_array=False)
+    prj = np.zeros((n_theta, n, n))
+    prj[idx] = np.abs(ref_wave) * (1 + 0.05 * rng.normal(size=ref_wave.shape))
+    s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=fp)
+    s.set_volume(od, ob)
+    s.set_measurements(prj)
+    w = s.forward_angles(idx)
+    assert rel(np.abs(w) ** 2, np.abs(ref_wave) ** 2) <= 1e-5
+    loss = s.loss_and_grad(idx)
+    gd, gb = s.gradient_to_host()
+    rl, rgd, rgb = orc.fullfield_loss_and_grad(od, ob, coords, idx, prj[idx], one, zero, 5000., 1e-7,
+                                               free_prop_cm=fp, with_reg=False)
+    assert abs(loss - rl) <= 1e-5 * rl
+    assert rel(gd, rgd) <= 2e-4 and rel(gb, rgb) <= 2e-4
+    # rotation adjoint alone is exact index work: feed the oracle's rotated-frame gradient through it
+    _, gd_rot, gb_rot = orc.multislice_loss_and_grad(rot[..., 0], rot[..., 1], one, zero, 5000., 1e-7, prj[idx], fp)
+    g_dev_d, g_dev_b = s.eng.grad_batch_to_host(mb)
+    assert rel(g_dev_d, gd_rot) <= 2e-4
+    acc_d = sum(orc.apply_rotation_adjoint(g_dev_d[b].astype(np.float64), coords[j]) for b, j in enumerate(idx))
+    assert rel(gd, acc_d) <= 1e-6            # summation order only
+
+
+def test_adam_kernel_vs_oracle(engine_mod):
+    """bdof_adam_step alone (identical gradients in): regulariser gradient + Adam + mask + clip."""
+    from beyond_dof_amd import util
+    from beyond_dof_amd._lib import DeviceBuffer
+    eng = engine_mod.MultisliceEngine(64, 64, 2, 1, with_grad=False)
+    rng = np.random.default_rng(4)
+    Y, X, Z = 10, 12, 9
+    od = rng.uniform(0, 2e-6, size=(Y, X, Z))
+    ob = 0.1 * od
+    od[rng.uniform(size=od.shape) < 0.1] = 0.0            # exercise sign(0) = 0
+    mask = (rng.uniform(size=(Y, X, Z)) > 0.2).astype(np.float32)
+    kw = dict(alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-9)
+    x = [DeviceBuffer.from_host(eng.ctx, util.volume_to_rows(od, ob)), DeviceBuffer.zeros(eng.ctx, (X, Z, Y, 2), np.float32)]
+    m = DeviceBuffer.zeros(eng.ctx, (X, Z, Y, 2), np.float32)
+    v = DeviceBuffer.zeros(eng.ctx, (X, Z, Y, 2), np.float32)
+    mk = DeviceBuffer.from_host(eng.ctx, np.ascontiguousarray(mask.transpose(1, 2, 0)))
+    xr = np.array([od, ob])
+    mr = vr = None
+    cur = 0
+    for it in range(4):
+        gdat = rng.normal(size=(2, Y, X, Z)) * 1e-4
+        g = DeviceBuffer.from_host(eng.ctx, util.volume_to_rows(gdat[0], gdat[1]))
+        eng.adam_step(x[cur], x[1 - cur], g, m, v, mk, (X, Z, Y), it, 1e-7, g_scale=0.5, **kw)
+        cur = 1 - cur
+        rd, rb = orc.regularizer_grad(xr[0], xr[1], **kw)
+        xr, mr, vr = orc.apply_gradient_adam(xr, np.array([0.5 * gdat[0] + rd, 0.5 * gdat[1] + rb]), it, mr, vr, step_size=1e-7)
+        xr = np.clip(xr * mask, 0, None)
+        eng.sync()
+        d, b = util.rows_to_volume(x[cur].download())
+        assert np.abs(d - xr[0]).max() <= 2e-6 * xr[0].max()
+        assert np.abs(b - xr[1]).max() <= 2e-6 * xr[1].max()
+
+
+def test_full_size_properties_512(engine_mod):
+    """Size-independent properties at the benchmark's wavefield size (512 x 512, 64 slices)."""
+    B, Y, X, S = 2, 512, 512, 64
+    rng = np.random.default_rng(9)
+    delta = rng.uniform(0, 2e-6, size=(B, Y, X, S)).astype(np.float32)
+    beta = np.zeros_like(delta)
+    eng = engine_mod.MultisliceEngine(Y, X, S, B, with_grad=True)
+    eng.set_physics(5000., 1e-7, 1e-4)
+    p1 = orc.gaussian_probe((Y, X), 40., 40., 0.5)
+    p2 = (rng.normal(size=(Y, X)), rng.normal(size=(Y, X)))
+    eng.set_object_batch(delta, beta)
+    outs = []
+    for pr, pi in (p1, p2, (2 * p1[0] - 3 * p2[0], 2 * p1[1] - 3 * p2[1])):
+        eng.set_probe(pr, pi)
+        outs.append(eng.forward(B))
+    # (1) pure phase object + unitary propagation conserves energy
+    e_in = np.sum(p1[0] ** 2 + p1[1] ** 2)
+    for b in range(B):
+        assert abs(np.sum(np.abs(outs[0][b]) ** 2) - e_in) <= 2e-5 * e_in
+    # (2) linear in the probe
+    assert rel(outs[2], 2 * outs[0] - 3 * outs[1]) <= 1e-5
+    # (3) gradient is a descent direction: a small step along -g lowers the loss by ~ |g|^2 * step
+    beta = (0.1 * delta).astype(np.float32)
+    eng.set_object_batch(delta, beta)
+    eng.set_probe(*p1)
+    w = eng.forward(B)
+    meas = np.abs(w) * (1 + 0.05 * rng.normal(size=w.shape))
+    l0 = eng.loss_grad(B, meas)
+    gd, gb = eng.grad_batch_to_host(B)
+    gnorm2 = float(np.sum(gd.astype(np.float64) ** 2) + np.sum(gb.astype(np.float64) ** 2))
+    step = 1e-3 * l0 / gnorm2
+    eng.set_object_batch(delta - step * gd, beta - step * gb)
+    l1 = eng.loss_grad(B, meas)
+    assert abs((l0 - l1) - step * gnorm2) <= 0.05 * step * gnorm2

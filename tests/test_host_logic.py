@@ -1,0 +1,109 @@
+"""Host-side set-up code of the product (beyond_dof_amd/util.py, comm.py) against the golden vectors
+captured from the reference and against the oracle.  No GPU needed."""
+import os
+
+import numpy as np
+
+from beyond_dof_amd import util
+from beyond_dof_amd.comm import minibatch_schedule, PseudoComm
+from oracle import bdof_oracle as orc
+
+
+def test_get_kernel_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g1_get_kernel.npz'))
+    for key in g.files:
+        _, Y, X, dist = key.split('_')
+        H = util.get_kernel(float(dist), 0.248, [1., 1., 1.], [int(Y), int(X), 4])
+        np.testing.assert_allclose(H, g[key], rtol=0, atol=1e-13)
+
+
+def test_get_kernel_anisotropic_voxels_match_oracle():
+    H = util.get_kernel(3.0, 0.3, [1.5, 2.5, 1.0], [10, 12])
+    np.testing.assert_allclose(H, orc.get_kernel(3.0, 0.3, [1.5, 2.5, 1.0], [10, 12, 1]), rtol=0, atol=1e-14)
+
+
+def test_device_transfer_function_is_the_fft_domain_multiplier():
+    ny, nx = 8, 16
+    hs = util.device_transfer_function(1.0, 0.248, [1., 1., 1.], ny, nx)
+    rng = np.random.default_rng(0)
+    w = rng.normal(size=(1, ny, nx)) + 1j * rng.normal(size=(1, ny, nx))
+    ref = orc._propagate(w, orc.get_kernel(1.0, 0.248, [1., 1., 1.], (ny, nx, 1)))
+    mine = np.fft.fft2(w[0]) * (hs.T * nx * ny)
+    mine = np.fft.ifft2(mine)
+    np.testing.assert_allclose(mine, ref[0], rtol=0, atol=5e-7)
+
+
+def test_rotation_lookup_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g3_rotation.npz'))
+    for size, n in [((8, 8, 8), 5), ((64, 64, 64), 4), ((6, 10, 10), 7)]:
+        key = 'x'.join(map(str, size)) + '_n{}'.format(n)
+        assert np.array_equal(np.stack(util.rotation_lookup(list(size), n)), g['coords_' + key])
+
+
+def test_save_rotation_lookup_files(tmp_path, golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g3_rotation.npz'))
+    folder = str(tmp_path / 'tables')
+    util.save_rotation_lookup([8, 8, 8], 5, dest_folder=folder)
+    coords = util.read_all_origin_coords(folder, 5)
+    assert np.array_equal(np.stack(coords), g['coords_8x8x8_n5'])
+    c0, c1, c2 = [np.load(os.path.join(folder, 'coord{}_vec.npy'.format(i))) for i in range(3)]
+    # the flat (i0, i1, i2) enumeration apply_rotation relies on (cnn_propagator/util.py:386-396)
+    assert np.array_equal(c0, np.repeat(np.arange(8), 64))
+    assert np.array_equal(c1, np.tile(np.repeat(np.arange(8), 8), 8))
+    assert np.array_equal(c2, np.tile(np.arange(8), 64))
+
+
+def test_device_rotation_tables_gather_and_inverse():
+    ny, nx, nz, n_theta = 4, 9, 9, 6
+    coords = util.rotation_lookup([ny, nx, nz], n_theta)
+    tab, off, order = util.device_rotation_tables(coords, nx, nz)
+    rng = np.random.default_rng(0)
+    obj = rng.normal(size=(ny, nx, nz, 2))
+    rows = util.volume_to_rows(obj[..., 0], obj[..., 1]).reshape(nx * nz, ny, 2)
+    for a in range(n_theta):
+        rot = orc.apply_rotation(obj, coords[a])                    # (Y, X, Z, 2)
+        mine = rows[tab[a]]                                         # [z][x][y][2]
+        np.testing.assert_array_equal(mine.transpose(2, 1, 0, 3), rot.astype(np.float32))
+        # inverse table: every destination lists exactly the rotated rows gathered from it
+        dest = tab[a].reshape(-1)
+        for d in range(nx * nz):
+            src = order[a][off[a][d]:off[a][d + 1]]
+            assert np.array_equal(np.sort(src), np.flatnonzero(dest == d))
+        assert off[a][-1] == nx * nz
+
+
+def test_layout_round_trips():
+    rng = np.random.default_rng(1)
+    d, b = rng.normal(size=(3, 4, 5)), rng.normal(size=(3, 4, 5))
+    d2, b2 = util.rows_to_volume(util.volume_to_rows(d, b))
+    np.testing.assert_array_equal(d2, d.astype(np.float32))
+    np.testing.assert_array_equal(b2, b.astype(np.float32))
+    gd, gb = rng.normal(size=(2, 3, 4, 5)), rng.normal(size=(2, 3, 4, 5))
+    r = util.batch_to_rows(gd, gb)
+    assert r.shape == (2, 5, 4, 3, 2)
+    gd2, gb2 = util.rows_to_batch(r)
+    np.testing.assert_array_equal(gd2, gd.astype(np.float32))
+
+
+def test_split_tasks_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g6_split_tasks.npz'))
+    parts = util.split_tasks(g['arr'], int(g['split_size']))
+    assert [len(p) for p in parts] == list(g['lengths'])
+
+
+def test_minibatch_schedule_pads_and_partitions():
+    rng = np.random.default_rng(0)
+    sched = minibatch_schedule(23, size=2, minibatch_size=4, rng=rng)
+    assert all(len(c) == 8 for c in sched) and len(sched) == 3
+    assert all(np.all(np.diff(c) >= 0) for c in sched)
+    flat = np.concatenate(sched)
+    assert set(flat.tolist()) == set(range(23))          # every angle is visited, one is repeated as padding
+    assert len(flat) == 24
+    assert PseudoComm().size == 1
+
+
+def test_gaussian_probe_matches_oracle():
+    a = util.gaussian_probe((7, 9), 2.0, 3.0, 0.5)
+    b = orc.gaussian_probe((7, 9), 2.0, 3.0, 0.5)
+    np.testing.assert_allclose(a[0], b[0])
+    np.testing.assert_allclose(a[1], b[1])
