@@ -21,7 +21,7 @@ struct bdof_ctx {
     int NY = 0, NX = 0, S = 0, Bmax = 0;
     bool with_grad = false;
     cf *twY = nullptr, *twX = nullptr;
-    cf *hs = nullptr, *hdet = nullptr, *probe = nullptr;
+    cf *hs = nullptr, *hdet = nullptr, *hcomb = nullptr, *probe = nullptr;
     cf *bufA = nullptr, *bufB = nullptr, *tape = nullptr;
     float2* grot = nullptr;
     double *partial = nullptr, *loss_dev = nullptr;
@@ -95,16 +95,15 @@ static void prof_collect(bdof_ctx* c) {
 }
 
 // ---- launches --------------------------------------------------------------------------------
-template <int NY> static int rows_grid(const bdof_ctx* c, int B, int NX) {
-    constexpr int RPW = BDOF_ROW_THREADS / (NY / 8);
-    int need = (B * NX + RPW - 1) / RPW;
-    int cap = c->ncu * 8;
-    return need < cap ? need : cap;
+// Persistent grids: at most `per_cu` workgroups per CU, and every workgroup gets the same number of tiles.
+static int balanced_grid(const bdof_ctx* c, int tiles, int per_cu) {
+    const int cap = c->ncu * per_cu;
+    if (tiles <= cap) return tiles;
+    const int rounds = (tiles + cap - 1) / cap;
+    return (tiles + rounds - 1) / rounds;
 }
-template <int NX> static int cols_grid(const bdof_ctx* c, int B, int NY) {
-    int need = B * (NY / ColTile<NX>::W);
-    int cap = c->ncu * 2;
-    return need < cap ? need : cap;
+template <int N> static int rows_grid(const bdof_ctx* c, int B, int R) {
+    return balanced_grid(c, B * R / RowCfg<N>::TILE, N >= 1024 ? 1 : 2);
 }
 
 #define DISPATCH_N(n, EXPR)                                    \
@@ -117,76 +116,97 @@ template <int NX> static int cols_grid(const bdof_ctx* c, int B, int NY) {
         default: break;                                        \
     }
 
-static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out) {
+// A_z: L1 (or the probe) -> L2 (tstore) or L1 (plain)
+static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore) {
     ProfScope ps(c, BDOF_K_ROW_FWD);
     RowFwdArgs a{in, c->probe, out, c->obj, B, c->NX, z, c->k, c->twY};
     DISPATCH_N(c->NY, {
-        int grid = rows_grid<N_>(c, B, c->NX);
-        if (z == 0) hipLaunchKernelGGL((k_row_fwd<N_, true>), dim3(grid), dim3(BDOF_ROW_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_row_fwd<N_, false>), dim3(grid), dim3(BDOF_ROW_THREADS), 0, c->stream, a);
+        const dim3 grid(rows_grid<N_>(c, B, c->NX));
+        const dim3 blk(BDOF_THREADS);
+        if (z == 0) {
+            if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, true, true>), grid, blk, 0, c->stream, a);
+            else hipLaunchKernelGGL((k_row_fwd<N_, true, false>), grid, blk, 0, c->stream, a);
+        } else {
+            if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, false, true>), grid, blk, 0, c->stream, a);
+            else hipLaunchKernelGGL((k_row_fwd<N_, false, false>), grid, blk, 0, c->stream, a);
+        }
     });
 }
 
-static void launch_col_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf* h, float scale, int conj_h) {
+// B: L2 -> L1
+static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf* h, float scale, int conj_h) {
     ProfScope ps(c, BDOF_K_COL_PROP);
-    ColPropArgs a{in, out, h, B, c->NY, scale, conj_h, c->twX};
+    RowPropArgs a{in, out, h, B, c->NY, scale, conj_h, c->twX};
     DISPATCH_N(c->NX, {
-        int grid = cols_grid<N_>(c, B, c->NY);
-        hipLaunchKernelGGL((k_col_prop<N_>), dim3(grid), dim3((N_ / 8) * ColTile<N_>::W), 0, c->stream, a);
+        hipLaunchKernelGGL((k_row_prop<N_>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->stream, a);
     });
 }
 
+// A'_z: L1 (g) + L1 (tape) -> L2 (g)
 static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout) {
     ProfScope ps(c, BDOF_K_ROW_BWD);
     RowBwdArgs a{gin, tape, c->probe, gout, c->grot, c->obj, B, c->NX, z, c->k, c->twY};
     DISPATCH_N(c->NY, {
-        int grid = rows_grid<N_>(c, B, c->NX);
-        if (z == 0) hipLaunchKernelGGL((k_row_bwd<N_, true>), dim3(grid), dim3(BDOF_ROW_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_row_bwd<N_, false>), dim3(grid), dim3(BDOF_ROW_THREADS), 0, c->stream, a);
+        const dim3 grid(rows_grid<N_>(c, B, c->NX));
+        const dim3 blk(BDOF_THREADS);
+        if (z == 0) hipLaunchKernelGGL((k_row_bwd<N_, true>), grid, blk, 0, c->stream, a);
+        else hipLaunchKernelGGL((k_row_bwd<N_, false>), grid, blk, 0, c->stream, a);
     });
 }
 
-// returns the grid used (number of partial sums written when meas != null)
-static int launch_row_loss(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* out_wave, const float* meas, float in_scale,
-                           float out_scale, float seed_scale) {
+// Real-space detector on L1 rows.  Returns the grid (= number of partial sums when meas != null).
+static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool tstore, cf* out_wave, const float* meas,
+                            float in_scale, float out_scale, float seed_scale) {
     ProfScope ps(c, BDOF_K_LOSS);
-    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NX, c->NY, in_scale, out_scale, seed_scale, c->twY};
+    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NX, in_scale, out_scale, seed_scale, c->twY};
     int grid = 0;
     DISPATCH_N(c->NY, {
         grid = rows_grid<N_>(c, B, c->NX);
-        hipLaunchKernelGGL((k_row_loss<N_>), dim3(grid), dim3(BDOF_ROW_THREADS), 0, c->stream, a);
+        if (tstore) hipLaunchKernelGGL((k_row_loss<N_, false, true>), dim3(grid), dim3(BDOF_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_row_loss<N_, false, false>), dim3(grid), dim3(BDOF_THREADS), 0, c->stream, a);
     });
     return grid;
 }
 
-static int launch_col_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* out_wave, const float* meas, float in_scale,
-                               float out_scale, float seed_scale) {
+// Far-field detector on L2 rows; the seed goes back transposed into L1.
+static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* out_wave, const float* meas, float in_scale,
+                           float out_scale, float seed_scale) {
     ProfScope ps(c, BDOF_K_LOSS);
-    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NX, c->NY, in_scale, out_scale, seed_scale, c->twX};
+    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NY, in_scale, out_scale, seed_scale, c->twX};
     int grid = 0;
     DISPATCH_N(c->NX, {
-        grid = cols_grid<N_>(c, B, c->NY);
-        hipLaunchKernelGGL((k_col_loss_far<N_>), dim3(grid), dim3((N_ / 8) * ColTile<N_>::W), 0, c->stream, a);
+        grid = rows_grid<N_>(c, B, c->NY);
+        hipLaunchKernelGGL((k_row_loss<N_, true, true>), dim3(grid), dim3(BDOF_THREADS), 0, c->stream, a);
     });
     return grid;
 }
 
-// ---- the forward sweep.  On return *cur points at the last field and *cur_unnorm tells whether it is
-// R phi_{S-1} (un-normalised, numpy_skip_last) or psi_hat_S (normalised hybrid, tf_all). ------------
-static void forward_sweep(bdof_ctx* c, int B, bool use_tape, cf** cur, bool* cur_unnorm) {
+// ---- the forward sweep ---------------------------------------------------------------------------
+// bufA is the L2-type scratch (row kernels' transposed output), bufB the L1-type scratch.
+// On return the field the detector step starts from is
+//   DET_NONE, numpy_skip_last : bufA = R phi_{S-1} in L1 order (plain store), un-normalised
+//   DET_NONE, tf_all          : bufB = psi_hat_S (L1)
+//   DET_NEAR                  : bufB = d_hat (L1)    (tf_all: one step with the combined transfer function)
+//   DET_FAR                   : bufA = R phi_{S-1} in L2 order, un-normalised (|fft2| is unchanged by the
+//                               unit-modulus transfer function, so tf_all needs no extra step here)
+static void forward_sweep(bdof_ctx* c, int B, bool use_tape) {
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+    const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
     for (int z = 0; z < c->S; ++z) {
         const cf* in = nullptr;
         if (z > 0) in = use_tape ? c->tape + (size_t)(z - 1) * fld : c->bufB;
-        launch_row_fwd(c, B, z, in, c->bufA);
         const bool last = z == c->S - 1;
-        if (!last || c->variant == BDOF_VARIANT_TF_ALL) {
-            cf* out = (use_tape && !last) ? c->tape + (size_t)z * fld : c->bufB;
-            launch_col_prop(c, B, c->bufA, out, c->hs, 1.f, 0);
+        if (!last) {
+            launch_row_fwd(c, B, z, in, c->bufA, true);
+            launch_row_prop(c, B, c->bufA, use_tape ? c->tape + (size_t)z * fld : c->bufB, c->hs, 1.f, 0);
+        } else if (c->det_mode == BDOF_DET_NONE && !tf_all) {
+            launch_row_fwd(c, B, z, in, c->bufA, false);
+        } else {
+            launch_row_fwd(c, B, z, in, c->bufA, true);
+            if (c->det_mode == BDOF_DET_NONE) launch_row_prop(c, B, c->bufA, c->bufB, c->hs, 1.f, 0);
+            else if (c->det_mode == BDOF_DET_NEAR) launch_row_prop(c, B, c->bufA, c->bufB, tf_all ? c->hcomb : c->hdet, 1.f, 0);
         }
     }
-    if (c->variant == BDOF_VARIANT_TF_ALL) { *cur = c->bufB; *cur_unnorm = false; }
-    else { *cur = c->bufA; *cur_unnorm = true; }
 }
 
 static int check_ready(bdof_ctx* c, int B) {
@@ -231,9 +251,9 @@ int bdof_ctx_create(bdof_ctx** out, int device, void* stream) {
 }
 
 static void free_workspace(bdof_ctx* c) {
-    void* ptrs[] = {c->twY, c->twX, c->hs, c->hdet, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
+    void* ptrs[] = {c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    c->twY = c->twX = c->hs = c->hdet = c->probe = c->bufA = c->bufB = c->tape = nullptr;
+    c->twY = c->twX = c->hs = c->hdet = c->hcomb = c->probe = c->bufA = c->bufB = c->tape = nullptr;
     c->grot = nullptr;
     c->partial = c->loss_dev = nullptr;
 }
@@ -284,6 +304,7 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     const size_t fld = (size_t)Bmax * NX * NY;
     HIPC(c, hipMalloc((void**)&c->hs, sizeof(cf) * NX * NY));
     HIPC(c, hipMalloc((void**)&c->hdet, sizeof(cf) * NX * NY));
+    HIPC(c, hipMalloc((void**)&c->hcomb, sizeof(cf) * NX * NY));
     HIPC(c, hipMalloc((void**)&c->probe, sizeof(cf) * NX * NY));
     HIPC(c, hipMalloc((void**)&c->bufA, sizeof(cf) * fld));
     HIPC(c, hipMalloc((void**)&c->bufB, sizeof(cf) * fld));
@@ -291,7 +312,7 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
         if (S > 1) HIPC(c, hipMalloc((void**)&c->tape, sizeof(cf) * fld * (size_t)(S - 1)));
         HIPC(c, hipMalloc((void**)&c->grot, sizeof(float2) * fld * (size_t)S));
     }
-    c->npartial = c->ncu * 8;
+    c->npartial = c->ncu * 2 + 64;
     HIPC(c, hipMalloc((void**)&c->partial, sizeof(double) * c->npartial));
     HIPC(c, hipMalloc((void**)&c->loss_dev, sizeof(double)));
     HIPC(c, hipMemsetAsync(c->loss_dev, 0, sizeof(double), c->stream));
@@ -305,7 +326,19 @@ int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det
     if (det_mode == BDOF_DET_NEAR && !hs_det) return fail(c, BDOF_ERR_ARG, "hs_det required for BDOF_DET_NEAR");
     const size_t bytes = sizeof(cf) * c->NX * c->NY;
     HIPC(c, hipMemcpyAsync(c->hs, hs, bytes, hipMemcpyHostToDevice, c->stream));
-    if (hs_det) HIPC(c, hipMemcpyAsync(c->hdet, hs_det, bytes, hipMemcpyHostToDevice, c->stream));
+    if (hs_det) {
+        HIPC(c, hipMemcpyAsync(c->hdet, hs_det, bytes, hipMemcpyHostToDevice, c->stream));
+        // tf_all + near detector: the two consecutive steps F^-1 hdet F F^-1 hs F collapse into one
+        std::vector<float> comb((size_t)2 * c->NX * c->NY);
+        const double n = (double)c->NX * c->NY;
+        for (size_t i = 0; i < (size_t)c->NX * c->NY; ++i) {
+            const double ar = hs[2 * i], ai = hs[2 * i + 1], br = hs_det[2 * i], bi = hs_det[2 * i + 1];
+            comb[2 * i] = (float)((ar * br - ai * bi) * n);
+            comb[2 * i + 1] = (float)((ar * bi + ai * br) * n);
+        }
+        HIPC(c, hipMemcpyAsync(c->hcomb, comb.data(), bytes, hipMemcpyHostToDevice, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+    }
     HIPC(c, hipStreamSynchronize(c->stream));
     c->k = (float)k;
     c->det_mode = det_mode;
@@ -357,20 +390,26 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
     if (keep_tape && !c->with_grad) return fail(c, BDOF_ERR_STATE, "keep_tape needs bdof_configure(with_grad=1)");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
-    cf* cur; bool unnorm;
-    forward_sweep(c, B, keep_tape != 0 && c->S > 1, &cur, &unnorm);
+    const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
+    forward_sweep(c, B, keep_tape != 0 && c->S > 1);
     c->tape_valid = keep_tape != 0;
-    c->last_valid = true;
-    cf* other = cur == c->bufA ? c->bufB : c->bufA;
+    c->last_valid = false;
     if (out_wave) {
-        if (c->det_mode == BDOF_DET_NONE) {
-            launch_row_loss(c, B, cur, nullptr, (cf*)out_wave, nullptr, unnorm ? 1.f / c->NY : 1.f, 1.f, 0.f);
-        } else if (c->det_mode == BDOF_DET_NEAR) {
-            launch_col_prop(c, B, cur, other, c->hdet, unnorm ? 1.f : (float)c->NY, 0);
-            launch_row_loss(c, B, other, nullptr, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f);
-        } else {
-            launch_col_loss_far(c, B, cur, nullptr, (cf*)out_wave, nullptr, unnorm ? 1.f : (float)c->NY, 1.f, 0.f);
+        if (c->det_mode == BDOF_DET_FAR)
+            launch_loss_far(c, B, c->bufA, nullptr, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f);
+        else if (c->det_mode == BDOF_DET_NONE && !tf_all)
+            launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out_wave, nullptr, 1.f / c->NY, 1.f, 0.f);
+        else
+            launch_loss_real(c, B, c->bufB, nullptr, false, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f);
+    }
+    if (keep_tape && !tf_all) {
+        // probe_array[S-1] = phi_{S-1} (np_funcs.py:41-43): keep R phi_{S-1} in L1 order in bufA
+        if (!(c->det_mode == BDOF_DET_NONE)) {
+            const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+            const cf* in = c->S > 1 ? c->tape + (size_t)(c->S - 2) * fld : nullptr;
+            launch_row_fwd(c, B, c->S - 1, in, c->bufA, false);
         }
+        c->last_valid = true;
     }
     HIPC(c, hipGetLastError());
     return 0;
@@ -384,13 +423,11 @@ int bdof_tape_to_real(bdof_ctx* c, int i, int B, void* out) {
     if (i < 0 || i >= c->S) return fail(c, BDOF_ERR_ARG, "slice index outside [0, S)");
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     if (i < c->S - 1) {
-        launch_row_loss(c, B, c->tape + (size_t)i * fld, nullptr, (cf*)out, nullptr, 1.f, 1.f, 0.f);
-    } else if (c->variant == BDOF_VARIANT_TF_ALL) {
-        // wave after the last slice, propagated: recompute from R phi_{S-1} (bufA) without touching bufB users
-        return fail(c, BDOF_ERR_STATE, "tape_to_real(S-1) is only kept for the numpy_skip_last variant");
+        launch_loss_real(c, B, c->tape + (size_t)i * fld, nullptr, false, (cf*)out, nullptr, 1.f, 1.f, 0.f);
     } else {
-        if (!c->last_valid) return fail(c, BDOF_ERR_STATE, "the last slice's wave is only kept after bdof_forward");
-        launch_row_loss(c, B, c->bufA, nullptr, (cf*)out, nullptr, 1.f / c->NY, 1.f, 0.f);
+        if (!c->last_valid)
+            return fail(c, BDOF_ERR_STATE, "the last slice's wave is only kept after bdof_forward(keep_tape=1) with the numpy_skip_last variant");
+        launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out, nullptr, 1.f / c->NY, 1.f, 0.f);
     }
     HIPC(c, hipGetLastError());
     return 0;
@@ -407,39 +444,29 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     const float NYf = (float)c->NY;
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
-    cf* cur; bool unnorm;
-    forward_sweep(c, B, c->S > 1, &cur, &unnorm);
+    forward_sweep(c, B, c->S > 1);
     c->tape_valid = true;
     c->last_valid = false;
-    cf* other = cur == c->bufA ? c->bufB : c->bufA;
     const float seed_scale = 2.f / ((float)B * (float)c->NX * (float)c->NY);
     int npart = 0;
-    // After this block `g` holds g_hat(phi_{S-1}) (normalised hybrid).
-    cf* g;
-    if (c->det_mode == BDOF_DET_NONE) {
-        // in-place per row: every row is fully in registers before it is written back
-        npart = launch_row_loss(c, B, cur, other, (cf*)out_wave, meas, unnorm ? 1.f / NYf : 1.f, tf_all ? 1.f : 1.f / NYf, seed_scale);
-        g = other;
-        if (tf_all) { launch_col_prop(c, B, g, cur, c->hs, 1.f, 1); g = cur; }
-    } else if (c->det_mode == BDOF_DET_NEAR) {
-        launch_col_prop(c, B, cur, other, c->hdet, unnorm ? 1.f : NYf, 0);            // d_hat
-        npart = launch_row_loss(c, B, other, cur, (cf*)out_wave, meas, 1.f, 1.f, seed_scale);   // R G(d)
-        launch_col_prop(c, B, cur, other, c->hdet, 1.f, 1);                            // g_hat(psi_S)
-        g = other;
-        if (tf_all) { launch_col_prop(c, B, g, cur, c->hs, NYf, 1); g = cur; }
+    // Detector + seed.  Afterwards bufB holds g_hat(phi_{S-1}) (L1 order, normalised hybrid).
+    if (c->det_mode == BDOF_DET_FAR) {
+        npart = launch_loss_far(c, B, c->bufA, c->bufB, (cf*)out_wave, meas, 1.f, 1.f, seed_scale);
+    } else if (c->det_mode == BDOF_DET_NONE && !tf_all) {
+        npart = launch_loss_real(c, B, c->bufA, c->bufB, false, (cf*)out_wave, meas, 1.f / NYf, 1.f / NYf, seed_scale);
     } else {
-        npart = launch_col_loss_far(c, B, cur, other, (cf*)out_wave, meas, unnorm ? 1.f : NYf, tf_all ? NYf : 1.f, seed_scale);
-        g = other;
-        if (tf_all) { launch_col_prop(c, B, g, cur, c->hs, 1.f, 1); g = cur; }
+        // the detector wave came out of a transfer-function step: seed -> R (transposed) -> adjoint step
+        const cf* h = c->det_mode == BDOF_DET_NONE ? c->hs : (tf_all ? c->hcomb : c->hdet);
+        npart = launch_loss_real(c, B, c->bufB, c->bufA, true, (cf*)out_wave, meas, 1.f, 1.f, seed_scale);
+        launch_row_prop(c, B, c->bufA, c->bufB, h, 1.f, 1);
     }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, npart,
                        1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
-    // backward sweep
+    // backward sweep: A'_z (L1 -> L2), then the adjoint transfer-function step (L2 -> L1)
     for (int z = c->S - 1; z >= 0; --z) {
-        cf* gout = g == c->bufA ? c->bufB : c->bufA;
         const cf* tape = z > 0 ? c->tape + (size_t)(z - 1) * fld : nullptr;
-        launch_row_bwd(c, B, z, g, tape, z > 0 ? gout : nullptr);
-        if (z > 0) launch_col_prop(c, B, gout, g, c->hs, 1.f, 1);   // g_hat(phi_{z-1}) back into g
+        launch_row_bwd(c, B, z, c->bufB, tape, z > 0 ? c->bufA : nullptr);
+        if (z > 0) launch_row_prop(c, B, c->bufA, c->bufB, c->hs, 1.f, 1);
     }
     HIPC(c, hipGetLastError());
     return 0;
@@ -464,8 +491,8 @@ int bdof_rotation_adjoint(bdof_ctx* c, int B, const int* angle_of_b, void* gvol,
     ProfScope ps(c, BDOF_K_ROT_ADJ);
     RotAdjArgs a{c->grot, (float2*)gvol, c->adj_off, c->adj_order, angle_of_b, B, c->S * c->NX, c->adj_ndest, c->NY, accumulate, scale};
     int grid = c->adj_ndest < c->ncu * 16 ? c->adj_ndest : c->ncu * 16;
-    int threads = c->NY / 2 < 256 ? (c->NY / 2 < 64 ? 64 : c->NY / 2) : 256;
-    hipLaunchKernelGGL(k_rot_adjoint, dim3(grid), dim3(threads), 0, c->stream, a);
+    if (B > 256) return fail(c, BDOF_ERR_ARG, "rotation adjoint handles at most 256 batch elements per call");
+    hipLaunchKernelGGL(k_rot_adjoint, dim3(grid), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;
 }

@@ -100,13 +100,18 @@ template <int R, int SIGN> __device__ __forceinline__ void dftR(cf (&u)[8], int 
     }
 }
 
-// One stage, split in its three phases.  L provides ld(idx), st(idx, v) on the line's LDS image.
+// One stage, split in its three phases.  L provides slot(idx) = idx + idx/16 and ld_at / st_at(base_slot, c),
+// which address slot(base + c) as base_slot + c + c/16: for every (base, c) pair the plans generate the low
+// four bits never carry (checked exhaustively in tools/fft_plan_model.py), so each access is one base register
+// plus an instruction-immediate offset.
 template <int N, int R, class L> __device__ __forceinline__ void stage_read(cf (&u)[8], int tid, L& lds) {
     constexpr int T = N / 8, NB = 8 / R, TT = N / R;
 #pragma unroll
-    for (int j = 0; j < NB; ++j)
+    for (int j = 0; j < NB; ++j) {
+        const int bs = lds.slot(tid + j * T);
 #pragma unroll
-        for (int m = 0; m < R; ++m) u[j * R + m] = lds.ld(tid + j * T + m * TT);
+        for (int m = 0; m < R; ++m) u[j * R + m] = lds.ld_at(bs, m * TT);
+    }
 }
 
 template <int N, int SIGN, int R, int PP, int TWOFF>
@@ -130,11 +135,11 @@ template <int N, int R, int PP, class L> __device__ __forceinline__ void stage_w
     constexpr int T = N / 8, NB = 8 / R;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        int i = tid + j * T;
-        int k = i % PP;
-        int base = (i - k) * R + k;
+        const int i = tid + j * T;
+        const int k = i % PP;
+        const int bs = lds.slot((i - k) * R + k);
 #pragma unroll
-        for (int q = 0; q < R; ++q) lds.st(base + q * PP, u[j * R + q]);
+        for (int q = 0; q < R; ++q) lds.st_at(bs, q * PP, u[j * R + q]);
     }
 }
 
@@ -165,4 +170,46 @@ __device__ __forceinline__ void line_fft(cf (&u)[8], const FftTw<N>& tw, int tid
         stage_read<N, P::R3>(u, tid, lds);
         stage_compute<N, SIGN, P::R3, P::R0 * P::R1 * P::R2, TW::OFF3>(u, tw);
     }
+}
+
+// All stages but the last; the last stage's inputs are left in the line's LDS image (no sync after the
+// final store: the caller's workgroup barrier orders it before the transposed readers).
+template <int N, int SIGN, class L>
+__device__ __forceinline__ void line_fft_partial(cf (&u)[8], const FftTw<N>& tw, int tid, L& lds) {
+    typedef FftPlan<N> P;
+    typedef FftTw<N> TW;
+    stage_compute<N, SIGN, P::R0, 1, 0>(u, tw);
+    lds.sync_r2w();
+    stage_write<N, P::R0, 1>(u, tid, lds);
+    if constexpr (P::NS > 2) {
+        lds.sync_w2r();
+        stage_read<N, P::R1>(u, tid, lds);
+        stage_compute<N, SIGN, P::R1, P::R0, TW::OFF1>(u, tw);
+        lds.sync_r2w();
+        stage_write<N, P::R1, P::R0>(u, tid, lds);
+    }
+    if constexpr (P::NS > 3) {
+        lds.sync_w2r();
+        stage_read<N, P::R2>(u, tid, lds);
+        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, TW::OFF2>(u, tw);
+        lds.sync_r2w();
+        stage_write<N, P::R2, P::R0 * P::R1>(u, tid, lds);
+    }
+}
+
+// The last stage (radix 8, p = N/8) for butterfly j of a line whose image is `lds`; the twiddles come
+// from the global table (exp(-2 pi i q / N)).  On exit u[q] is the output at position j + q*N/8.
+template <int N, int SIGN, class L>
+__device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* __restrict__ table) {
+    cf w[7];
+#pragma unroll
+    for (int m = 1; m < 8; ++m) w[m - 1] = table[m * j];
+    stage_read<N, 8>(u, j, lds);
+#pragma unroll
+    for (int m = 1; m < 8; ++m) {
+        cf t = w[m - 1];
+        if (SIGN > 0) t.y = -t.y;
+        u[m] = cmul(u[m], t);
+    }
+    dft8<SIGN>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
 }

@@ -1,29 +1,45 @@
 // Multislice hot-path kernels (gfx950).  See DESIGN.md for the data layout and the byte model.
 //
-// Layout: a wavefield is psi[b][x][y], y fastest ("rows" run along y, the tomographic rotation
-// axis, so that a rotated object row is a contiguous row of the un-rotated volume).
-// "Hybrid" fields are transformed along y only:  psi_hat = R psi / NY  (R = unnormalised DFT along y).
-//   row kernel  A_i : psi = R^-1' psi_hat ; phi = c_i psi ; out = R phi          (24 B/px)
-//   col kernel  B   : out = C^-1' ( hs * C in ),  hs = ifftshift(H)^T / (NX NY)   (16 B/px)
-// so one slice is two launches and 40 B/px; B's output is directly the tape entry psi_hat_{i+1}.
+// Two wavefield layouts alternate so that EVERY kernel reads whole contiguous rows:
+//   L1[b][x][ky]  rows along the rotation axis y (ky: DFT index along y);  psi_hat = R psi / NY
+//   L2[b][ky][x]  rows along x
+//   A_i (k_row_fwd) : L1 -> L2   psi = R^-1' psi_hat ; phi = c_i psi ; out = R phi         24 B/px
+//   B   (k_row_prop): L2 -> L1   out = C^-1'( h * C in ),  h = ifftshift(H)/(NX NY)        16 B/px
+//   A'_i(k_row_bwd) : L1 -> L2   adjoint of A_i, writes the (delta,beta) gradient rows     40 B/px
+// A row is transformed by one wave (N <= 512) with LDS exchanges that need no barrier; the LAST
+// stage of each kernel's final FFT is executed with a transposed thread mapping (16 rows x N/8
+// butterflies), so the transposition costs no extra LDS pass and only one workgroup barrier per
+// 16-row tile, and the stores are 128-byte segments.  B's output is directly the tape entry.
 #pragma once
 #include "bdof_fft.h"
 
-#define BDOF_ROW_THREADS 256
+#define BDOF_THREADS 512
+
+template <int N> struct RowCfg {
+    static constexpr int T = N / 8;                          // lanes per row
+    static constexpr int RPP = BDOF_THREADS / T;             // rows per pass
+    static constexpr int TILE = RPP > 16 ? RPP : 16;         // rows per tile = transposed segment length
+    static constexpr int PASSES = TILE / RPP;
+    static constexpr int NPAD = N + N / 16;
+    static constexpr int RS = ((NPAD + 29) / 32) * 32 + 2;   // LDS row stride (cf), == 2 mod 32: conflict-free transposed reads
+    static constexpr int LDS_CF = TILE * RS;
+    static constexpr int MIN_WAVES = N >= 1024 ? 2 : 4;      // waves per SIMD asked from the register allocator
+};
 
 // ---------------------------------------------------------------------------------------------
-// LDS images
+// LDS image of one row: slot(i) = i + (i >> 4)
 // ---------------------------------------------------------------------------------------------
 template <int T> struct RowLds {
-    cf* base;   // this row's image, padded: slot(i) = i + (i >> 4)
-    __device__ __forceinline__ cf ld(int i) const { return base[i + (i >> 4)]; }
-    __device__ __forceinline__ void st(int i, cf v) { base[i + (i >> 4)] = v; }
+    cf* base;
+    __device__ __forceinline__ int slot(int i) const { return i + (i >> 4); }
+    __device__ __forceinline__ cf ld_at(int base_slot, int c) const { return base[base_slot + c + (c >> 4)]; }
+    __device__ __forceinline__ void st_at(int base_slot, int c, cf v) { base[base_slot + c + (c >> 4)] = v; }
     __device__ __forceinline__ void sync_w2r() { sync(); }
     __device__ __forceinline__ void sync_r2w() { sync(); }
     __device__ __forceinline__ void sync() {
         if constexpr (T <= 64) {
-            // the line lives inside one wave: LDS ops of a wave execute in order; only the compiler
-            // must be kept from reordering across the exchange
+            // the row lives inside one wave: LDS operations of a wave execute in order, only the
+            // compiler has to be kept from reordering across the exchange
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -33,18 +49,26 @@ template <int T> struct RowLds {
     }
 };
 
-template <int W> struct ColLds {
-    cf* base;   // tile image [idx][w], w fastest: conflict-free for lanes that differ in w
-    int w;
-    __device__ __forceinline__ cf ld(int i) const { return base[i * W + w]; }
-    __device__ __forceinline__ void st(int i, cf v) { base[i * W + w] = v; }
-    __device__ __forceinline__ void sync_w2r() { __syncthreads(); }
-    __device__ __forceinline__ void sync_r2w() { __syncthreads(); }
-};
-
-template <int N> struct ColTile {   // columns per workgroup tile
-    static constexpr int W = N <= 256 ? 32 : (N == 512 ? 16 : 8);
-};
+// ---------------------------------------------------------------------------------------------
+// Transposed tail: last FFT stage of the TILE rows whose images are in `smem`, then
+//   dst[(pos) * ld + r] = scale * out(row r, position pos),  pos = j + q*T
+// Called by all threads between two workgroup barriers.
+// ---------------------------------------------------------------------------------------------
+template <int N, int SIGN>
+__device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, size_t ld, float scale,
+                                                const cf* __restrict__ table) {
+    typedef RowCfg<N> C;
+#pragma nounroll
+    for (int pass = 0; pass < C::PASSES; ++pass) {
+        const int q = threadIdx.x + pass * BDOF_THREADS;
+        const int r = q % C::TILE, j = q / C::TILE;
+        RowLds<C::T> lds{smem + r * C::RS};
+        cf u[8];
+        last_stage<N, SIGN>(u, j, lds, table);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) dst[(size_t)(j + m * C::T) * ld + r] = cscale(u[m], scale);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Object access: which (delta,beta) row feeds wavefield row (b, x) at slice z
@@ -67,109 +91,145 @@ __device__ __forceinline__ long long obj_src_row(const ObjView& o, int b, int x,
     return ((long long)b * o.S + z) * NX + x;
 }
 
+// sin/cos with a 3-term Cody-Waite reduction by pi/2 and the cephes minimax polynomials: ~1 ulp for
+// |x| < 1e5 (k*delta is the phase picked up in ONE slice), a handful of registers instead of the
+// general-purpose sincosf's large-argument path.
+__device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
+    const float n = rintf(x * 0.636619772367581343f);
+    float r = fmaf(-n, 1.5703125f, x);
+    r = fmaf(-n, 4.837512969970703125e-4f, r);
+    r = fmaf(-n, 7.54978995489188216e-8f, r);
+    const float r2 = r * r;
+    const float sp = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+    const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                          fmaf(-0.5f, r2, 1.0f));
+    const int q = (int)n;
+    const float ss = (q & 1) ? cp : sp;
+    const float cc = (q & 1) ? sp : cp;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // c = exp(i k delta) * exp(-k beta)                      cnn_propagator/np_funcs.py:39
 __device__ __forceinline__ cf slice_modulation(float2 db, float k) {
     float s, c;
-    sincosf(k * db.x, &s, &c);
-    float e = expf(-k * db.y);
+    sincos_cw(k * db.x, s, c);
+    const float e = __expf(-k * db.y);
     return make_float2(e * c, e * s);
+}
+
+__device__ __forceinline__ void load_obj_row(const ObjView& o, long long srow, int y0, int tid, int T, float2 (&db)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int yg = tid + m * T + y0;
+        db[m] = make_float2(0.f, 0.f);
+        if (srow >= 0 && yg >= 0 && yg < o.volNY) db[m] = o.vol[(size_t)srow * o.volNY + yg];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // A: forward row kernel.                              cnn_propagator/np_funcs.py:37-40 (+ FFT along y)
 // ---------------------------------------------------------------------------------------------
 struct RowFwdArgs {
-    const cf* in;      // psi_hat_i [B][NX][NY]; ignored when FIRST (probe used)
+    const cf* in;      // L1 psi_hat_i [B][NX][NY]; ignored when FIRST (probe used)
     const cf* probe;   // [NX][NY] real-space probe
-    cf* out;           // R phi_i
+    cf* out;           // TSTORE: L2 [B][NY][NX] = R phi_i ; else L1 [B][NX][NY]
     ObjView obj;
     int B, NX, z;
     float k;
     const cf* twiddle;
 };
 
-template <int NY, bool FIRST>
-__global__ __launch_bounds__(BDOF_ROW_THREADS) void k_row_fwd(RowFwdArgs a) {
-    constexpr int T = NY / 8, RPW = BDOF_ROW_THREADS / T, NPAD = NY + NY / 16;
-    __shared__ cf smem[RPW * NPAD];
-    const int tid = threadIdx.x % T, rl = threadIdx.x / T;
-    RowLds<T> lds{smem + rl * NPAD};
+template <int NY, bool FIRST, bool TSTORE>
+__global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd(RowFwdArgs a) {
+    typedef RowCfg<NY> C;
+    __shared__ cf smem[C::LDS_CF];
+    const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     FftTw<NY> tw;
     tw.load(a.twiddle, tid);
-    const int nrows = a.B * a.NX;
-    for (int rg = blockIdx.x; rg * RPW < nrows; rg += gridDim.x) {
-        const int row = rg * RPW + rl;
-        const bool valid = row < nrows;
-        const int b = valid ? row / a.NX : 0;
-        const int x = valid ? row - b * a.NX : 0;
-        cf u[8];
-        if constexpr (FIRST) {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) u[m] = a.probe[(size_t)x * NY + tid + m * T];
-        } else {
-            const cf* src = a.in + (size_t)(valid ? row : 0) * NY;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) u[m] = src[tid + m * T];
-            line_fft<NY, +1>(u, tw, tid, lds);
-        }
-        const long long srow = obj_src_row(a.obj, b, x, a.z, a.NX);
+    const int ntiles = a.B * a.NX / C::TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * C::TILE;
+        const int b = row0 / a.NX, x0 = row0 - b * a.NX;
         const int y0 = a.obj.yoff ? a.obj.yoff[b] : 0;
+#pragma nounroll
+        for (int pass = 0; pass < C::PASSES; ++pass) {
+            const int r = pass * C::RPP + rl;
+            const int x = x0 + r;
+            RowLds<C::T> lds{smem + r * C::RS};
+            cf u[8];
+            float2 db[8];
+            const cf* src = FIRST ? a.probe + (size_t)x * NY : a.in + (size_t)(row0 + r) * NY;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int yg = tid + m * T + y0;
-            float2 db = make_float2(0.f, 0.f);
-            if (srow >= 0 && yg >= 0 && yg < a.obj.volNY) db = a.obj.vol[(size_t)srow * a.obj.volNY + yg];
-            u[m] = cmul(u[m], slice_modulation(db, a.k));
+            for (int m = 0; m < 8; ++m) u[m] = src[tid + m * C::T];
+            load_obj_row(a.obj, obj_src_row(a.obj, b, x, a.z, a.NX), y0, tid, C::T, db);
+            if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) u[m] = cmul(u[m], slice_modulation(db[m], a.k));
+            if constexpr (TSTORE) {
+                line_fft_partial<NY, -1>(u, tw, tid, lds);
+            } else {
+                line_fft<NY, -1>(u, tw, tid, lds);
+                cf* dst = a.out + (size_t)(row0 + r) * NY;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) dst[tid + m * C::T] = u[m];
+            }
         }
-        line_fft<NY, -1>(u, tw, tid, lds);
-        if (valid) {
-            cf* dst = a.out + (size_t)row * NY;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) dst[tid + m * T] = u[m];
+        if constexpr (TSTORE) {
+            __syncthreads();
+            transposed_tail<NY, -1>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, a.twiddle);
+            __syncthreads();
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// B: column kernel, Fresnel transfer-function step.   cnn_propagator/np_funcs.py:42 (K3-K5)
+// B: Fresnel transfer-function step along x.          cnn_propagator/np_funcs.py:42 (K3-K5)
 // ---------------------------------------------------------------------------------------------
-struct ColPropArgs {
-    const cf* in;
-    cf* out;
-    const cf* h;     // hs[kx][ky] = ifftshift(H)[ky][kx] / (NX NY)
+struct RowPropArgs {
+    const cf* in;    // L2 [B][NY][NX]
+    cf* out;         // L1 [B][NX][NY]
+    const cf* h;     // h[ky][kx] = ifftshift(H)[ky][kx] / (NX NY)
     int B, NY;
-    float scale;     // extra factor (NY when the input is already a normalised hybrid field)
+    float scale;     // extra factor applied with h
     int conj_h;      // adjoint step uses conj(h)
     const cf* twiddle;
 };
 
 template <int NX>
-__global__ __launch_bounds__((NX / 8) * ColTile<NX>::W) void k_col_prop(ColPropArgs a) {
-    constexpr int T = NX / 8, W = ColTile<NX>::W;
-    __shared__ cf smem[NX * W];
-    const int w = threadIdx.x % W, i = threadIdx.x / W;
-    ColLds<W> lds{smem, w};
+__global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_prop(RowPropArgs a) {
+    typedef RowCfg<NX> C;
+    __shared__ cf smem[C::LDS_CF];
+    const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     FftTw<NX> tw;
-    tw.load(a.twiddle, i);
-    const int tiles_per_b = a.NY / W;
-    const int ntiles = a.B * tiles_per_b;
+    tw.load(a.twiddle, tid);
+    const int ntiles = a.B * a.NY / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_b;
-        const int y = (tile - b * tiles_per_b) * W + w;
-        const size_t base = (size_t)b * NX * a.NY + y;
-        cf u[8];
+        const int row0 = tile * C::TILE;
+        const int b = row0 / a.NY, ky0 = row0 - b * a.NY;
+#pragma nounroll
+        for (int pass = 0; pass < C::PASSES; ++pass) {
+            const int r = pass * C::RPP + rl;
+            RowLds<C::T> lds{smem + r * C::RS};
+            cf u[8], hv[8];
+            const cf* src = a.in + (size_t)(row0 + r) * NX;
+            const cf* hrow = a.h + (size_t)(ky0 + r) * NX;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) u[m] = a.in[base + (size_t)(i + m * T) * a.NY];
-        line_fft<NX, -1>(u, tw, i, lds);
+            for (int m = 0; m < 8; ++m) u[m] = src[tid + m * C::T];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            cf hv = a.h[(size_t)(i + m * T) * a.NY + y];
-            if (a.conj_h) hv.y = -hv.y;
-            u[m] = cmul(u[m], cscale(hv, a.scale));
+            for (int m = 0; m < 8; ++m) hv[m] = hrow[tid + m * C::T];
+            line_fft<NX, -1>(u, tw, tid, lds);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                cf t = hv[m];
+                if (a.conj_h) t.y = -t.y;
+                u[m] = cmul(u[m], cscale(t, a.scale));
+            }
+            line_fft_partial<NX, +1>(u, tw, tid, lds);
         }
-        line_fft<NX, +1>(u, tw, i, lds);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) a.out[base + (size_t)(i + m * T) * a.NY] = u[m];
+        __syncthreads();
+        transposed_tail<NX, +1>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, a.twiddle);
+        __syncthreads();
     }
 }
 
@@ -182,30 +242,33 @@ __device__ __forceinline__ double wave_reduce_sum(double v) {
     return v;
 }
 
-template <int NTHREADS> __device__ __forceinline__ void block_store_sum(double v, double* dst) {
-    __shared__ double wsum[NTHREADS / 64];
+__device__ __forceinline__ void block_store_sum(double v, double* dst) {
+    __shared__ double wsum[BDOF_THREADS / 64];
     v = wave_reduce_sum(v);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (lane == 0) wsum[wid] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
         double s = 0;
-        for (int j = 0; j < NTHREADS / 64; ++j) s += wsum[j];
+        for (int j = 0; j < BDOF_THREADS / 64; ++j) s += wsum[j];
         *dst = s;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Detector plane in real space (free_prop_cm None / distance): magnitude loss + adjoint seed.
+// Detector plane: magnitude loss + adjoint seed.
 //   loss: cnn_propagator/fullfield.py:106 ; seed G(d) = 2 (|d| - |m|) d/|d| / n   
+// k_row_loss   (free_prop_cm None / distance): rows of L1, d = R^-1' in * in_scale (real space).
+// k_row_loss_far (free_prop_cm 'inf'):         rows of L2, d = C in * in_scale  = un-shifted fft2;
+//   the fftshift of np_funcs.py:48 is folded into the order in which the host lays out `meas`.
 // ---------------------------------------------------------------------------------------------
 struct LossArgs {
-    const cf* in;        // hybrid field of the detector wave
-    cf* out_hyb;         // nullable: R seed * out_scale
-    cf* out_wave;        // nullable: detector wave d[b][x][y]
-    const float* meas;   // nullable: |measured| [b][x][y] (already in this kernel's index order)
+    const cf* in;
+    cf* out_hyb;         // nullable: seed transformed back (* out_scale); layout by TSTORE
+    cf* out_wave;        // nullable: detector wave, same row layout as `in`
+    const float* meas;   // nullable: |measured|, same row layout as `in`
     double* partial;     // [gridDim.x] per-workgroup sums of (|d|-|m|)^2
-    int B, NX, NY;
+    int B, R;            // R rows per batch element
     float in_scale, out_scale, seed_scale;
     const cf* twiddle;
 };
@@ -218,86 +281,63 @@ __device__ __forceinline__ cf loss_seed(cf d, float m, float seed_scale, double&
     return make_float2(d.x * f, d.y * f);
 }
 
-template <int NY>
-__global__ __launch_bounds__(BDOF_ROW_THREADS) void k_row_loss(LossArgs a) {
-    constexpr int T = NY / 8, RPW = BDOF_ROW_THREADS / T, NPAD = NY + NY / 16;
-    __shared__ cf smem[RPW * NPAD];
-    const int tid = threadIdx.x % T, rl = threadIdx.x / T;
-    RowLds<T> lds{smem + rl * NPAD};
-    FftTw<NY> tw;
+// FAR = false: inverse FFT first (rows of L1); FAR = true: forward FFT first (rows of L2).
+template <int N, bool FAR, bool TSTORE>
+__global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss(LossArgs a) {
+    typedef RowCfg<N> C;
+    constexpr int S1 = FAR ? -1 : +1;     // direction of the first transform; the second is the opposite
+    __shared__ cf smem[C::LDS_CF];
+    const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
+    FftTw<N> tw;
     tw.load(a.twiddle, tid);
-    const int nrows = a.B * a.NX;
+    const int ntiles = a.B * a.R / C::TILE;
     double acc = 0.0;
-    for (int rg = blockIdx.x; rg * RPW < nrows; rg += gridDim.x) {
-        const int row = rg * RPW + rl;
-        const bool valid = row < nrows;
-        const size_t off = (size_t)(valid ? row : 0) * NY;
-        cf u[8];
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * C::TILE;
+        const int b = row0 / a.R, r0 = row0 - b * a.R;
+#pragma nounroll
+        for (int pass = 0; pass < C::PASSES; ++pass) {
+            const int r = pass * C::RPP + rl;
+            RowLds<C::T> lds{smem + r * C::RS};
+            const size_t off = (size_t)(row0 + r) * N;
+            cf u[8];
+            float mm[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) u[m] = a.in[off + tid + m * T];
-        line_fft<NY, +1>(u, tw, tid, lds);
+            for (int m = 0; m < 8; ++m) u[m] = a.in[off + tid + m * C::T];
+            if (a.meas) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) u[m] = cscale(u[m], a.in_scale);
-        if (a.out_wave && valid) {
+                for (int m = 0; m < 8; ++m) mm[m] = a.meas[off + tid + m * C::T];
+            }
+            line_fft<N, S1>(u, tw, tid, lds);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) a.out_wave[off + tid + m * T] = u[m];
-        }
-        if (a.meas) {
+            for (int m = 0; m < 8; ++m) u[m] = cscale(u[m], a.in_scale);
+            if (a.out_wave) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                double dummy = 0.0;
-                u[m] = loss_seed(u[m], a.meas[off + tid + m * T], a.seed_scale, valid ? acc : dummy);
+                for (int m = 0; m < 8; ++m) a.out_wave[off + tid + m * C::T] = u[m];
+            }
+            if (a.meas) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) u[m] = loss_seed(u[m], mm[m], a.seed_scale, acc);
             }
             if (a.out_hyb) {
-                line_fft<NY, -1>(u, tw, tid, lds);
-                if (valid) {
+                if constexpr (TSTORE) {
+                    line_fft_partial<N, -S1>(u, tw, tid, lds);
+                } else {
+                    line_fft<N, -S1>(u, tw, tid, lds);
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) a.out_hyb[off + tid + m * T] = cscale(u[m], a.out_scale);
+                    for (int m = 0; m < 8; ++m) a.out_hyb[off + tid + m * C::T] = cscale(u[m], a.out_scale);
                 }
             }
         }
-    }
-    if (a.meas) block_store_sum<BDOF_ROW_THREADS>(acc, a.partial + blockIdx.x);
-}
-
-// Far-field detector (free_prop_cm == 'inf'): d = fftshift(fft2 psi); here un-shifted, the shift is
-// folded into the order in which the host lays out `meas` / reads `out_wave`.
-//   cnn_propagator/np_funcs.py:47-48, cnn_propagator/ptychography.py:74-79
-template <int NX>
-__global__ __launch_bounds__((NX / 8) * ColTile<NX>::W) void k_col_loss_far(LossArgs a) {
-    constexpr int T = NX / 8, W = ColTile<NX>::W;
-    __shared__ cf smem[NX * W];
-    const int w = threadIdx.x % W, i = threadIdx.x / W;
-    ColLds<W> lds{smem, w};
-    FftTw<NX> tw;
-    tw.load(a.twiddle, i);
-    const int tiles_per_b = a.NY / W;
-    const int ntiles = a.B * tiles_per_b;
-    double acc = 0.0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / tiles_per_b;
-        const int y = (tile - b * tiles_per_b) * W + w;
-        const size_t base = (size_t)b * NX * a.NY + y;
-        cf u[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) u[m] = cscale(a.in[base + (size_t)(i + m * T) * a.NY], a.in_scale);
-        line_fft<NX, -1>(u, tw, i, lds);
-        if (a.out_wave) {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) a.out_wave[base + (size_t)(i + m * T) * a.NY] = u[m];
-        }
-        if (a.meas) {
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-                u[m] = loss_seed(u[m], a.meas[base + (size_t)(i + m * T) * a.NY], a.seed_scale, acc);
+        if constexpr (TSTORE) {
             if (a.out_hyb) {
-                line_fft<NX, +1>(u, tw, i, lds);
-#pragma unroll
-                for (int m = 0; m < 8; ++m) a.out_hyb[base + (size_t)(i + m * T) * a.NY] = cscale(u[m], a.out_scale);
+                __syncthreads();
+                transposed_tail<N, -S1>(smem, a.out_hyb + (size_t)b * N * a.R + r0, a.R, a.out_scale, a.twiddle);
+                __syncthreads();
             }
         }
     }
-    if (a.meas) block_store_sum<(NX / 8) * ColTile<NX>::W>(acc, a.partial + blockIdx.x);
+    if (a.meas) block_store_sum(acc, a.partial + blockIdx.x);
 }
 
 __global__ void k_sum_partials(const double* partial, int n, double scale, double* out) {
@@ -316,10 +356,10 @@ __global__ void k_sum_partials(const double* partial, int n, double scale, doubl
 //   g_delta = k Im t ; g_beta = -k Re t ; G(psi) = conj(c) G(phi) ; out = R G(psi)
 // ---------------------------------------------------------------------------------------------
 struct RowBwdArgs {
-    const cf* gin;     // g_hat(phi_i) [B][NX][NY]
-    const cf* tape;    // psi_hat_i; ignored when FIRST (probe)
+    const cf* gin;     // L1 g_hat(phi_i) [B][NX][NY]
+    const cf* tape;    // L1 psi_hat_i; ignored when FIRST (probe)
     const cf* probe;
-    cf* gout;          // nullable: R G(psi_i)
+    cf* gout;          // nullable: L2 R G(psi_i)
     float2* grot;      // [B][S][NX][NY] (g_delta, g_beta) in the rotated / windowed frame
     ObjView obj;
     int B, NX, z;
@@ -328,52 +368,48 @@ struct RowBwdArgs {
 };
 
 template <int NY, bool FIRST>
-__global__ __launch_bounds__(BDOF_ROW_THREADS) void k_row_bwd(RowBwdArgs a) {
-    constexpr int T = NY / 8, RPW = BDOF_ROW_THREADS / T, NPAD = NY + NY / 16;
-    __shared__ cf smem[RPW * NPAD];
-    const int tid = threadIdx.x % T, rl = threadIdx.x / T;
-    RowLds<T> lds{smem + rl * NPAD};
+__global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd(RowBwdArgs a) {
+    typedef RowCfg<NY> C;
+    __shared__ cf smem[C::LDS_CF];
+    const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     FftTw<NY> tw;
     tw.load(a.twiddle, tid);
-    const int nrows = a.B * a.NX;
-    for (int rg = blockIdx.x; rg * RPW < nrows; rg += gridDim.x) {
-        const int row = rg * RPW + rl;
-        const bool valid = row < nrows;
-        const int b = valid ? row / a.NX : 0;
-        const int x = valid ? row - b * a.NX : 0;
-        const size_t off = (size_t)(valid ? row : 0) * NY;
-        cf g[8], p[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) g[m] = a.gin[off + tid + m * T];
-        if constexpr (FIRST) {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) p[m] = a.probe[(size_t)x * NY + tid + m * T];
-        } else {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) p[m] = a.tape[off + tid + m * T];
-        }
-        line_fft<NY, +1>(g, tw, tid, lds);
-        if constexpr (!FIRST) line_fft<NY, +1>(p, tw, tid, lds);
-        const long long srow = obj_src_row(a.obj, b, x, a.z, a.NX);
+    const int ntiles = a.B * a.NX / C::TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * C::TILE;
+        const int b = row0 / a.NX, x0 = row0 - b * a.NX;
         const int y0 = a.obj.yoff ? a.obj.yoff[b] : 0;
-        float2* gdst = a.grot + (((size_t)b * a.obj.S + a.z) * a.NX + x) * NY;
+#pragma nounroll
+        for (int pass = 0; pass < C::PASSES; ++pass) {
+            const int r = pass * C::RPP + rl;
+            const int x = x0 + r;
+            RowLds<C::T> lds{smem + r * C::RS};
+            const size_t off = (size_t)(row0 + r) * NY;
+            cf g[8], p[8];
+            float2 db[8];
+            const cf* psrc = FIRST ? a.probe + (size_t)x * NY : a.tape + off;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int yg = tid + m * T + y0;
-            float2 db = make_float2(0.f, 0.f);
-            if (srow >= 0 && yg >= 0 && yg < a.obj.volNY) db = a.obj.vol[(size_t)srow * a.obj.volNY + yg];
-            const cf c = slice_modulation(db, a.k);
-            const cf phi = cmul(p[m], c);
-            const cf t = cmulc(g[m], phi);          // G * conj(phi)
-            if (valid) gdst[tid + m * T] = make_float2(a.k * t.y, -a.k * t.x);
-            g[m] = cmulc(g[m], c);                  // conj(c) G
+            for (int m = 0; m < 8; ++m) g[m] = a.gin[off + tid + m * C::T];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) p[m] = psrc[tid + m * C::T];
+            load_obj_row(a.obj, obj_src_row(a.obj, b, x, a.z, a.NX), y0, tid, C::T, db);
+            line_fft<NY, +1>(g, tw, tid, lds);
+            if constexpr (!FIRST) line_fft<NY, +1>(p, tw, tid, lds);
+            float2* gdst = a.grot + (((size_t)b * a.obj.S + a.z) * a.NX + x) * NY;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const cf c = slice_modulation(db[m], a.k);
+                const cf phi = cmul(p[m], c);
+                const cf t = cmulc(g[m], phi);          // G * conj(phi)
+                gdst[tid + m * C::T] = make_float2(a.k * t.y, -a.k * t.x);
+                g[m] = cmulc(g[m], c);                  // conj(c) G
+            }
+            if (a.gout) line_fft_partial<NY, -1>(g, tw, tid, lds);
         }
         if (a.gout) {
-            line_fft<NY, -1>(g, tw, tid, lds);
-            if (valid) {
-#pragma unroll
-                for (int m = 0; m < 8; ++m) a.gout[off + tid + m * T] = g[m];
-            }
+            __syncthreads();
+            transposed_tail<NY, -1>(smem, a.gout + (size_t)b * NY * a.NX + x0, a.NX, 1.f, a.twiddle);
+            __syncthreads();
         }
     }
 }
@@ -382,6 +418,8 @@ __global__ __launch_bounds__(BDOF_ROW_THREADS) void k_row_bwd(RowBwdArgs a) {
 // Adjoint of the rotation gather (K1^T), atomics-free and deterministic: every destination row of
 // the volume gradient sums the rotated-frame gradient rows that were gathered from it, through a
 // per-angle inverse (CSR) table.                  adjoint of cnn_propagator/util.py:377-402
+// One workgroup per destination row: the (angle, source) list is first collected in LDS by one
+// thread per batch element, then all threads stream the listed rows with independent loads.
 // ---------------------------------------------------------------------------------------------
 struct RotAdjArgs {
     const float2* grot;       // [B][S][NX][NY]
@@ -393,26 +431,85 @@ struct RotAdjArgs {
     float scale;
 };
 
+#define BDOF_ROTADJ_MAXLIST 1024
+
 __global__ __launch_bounds__(256) void k_rot_adjoint(RotAdjArgs a) {
-    const int nv = a.NY / 2;   // float4 = two (delta,beta) pairs
+    __shared__ int list[BDOF_ROTADJ_MAXLIST];   // global row index into grot (b*n_src + src)
+    __shared__ int count;
+    const int nv = a.NY / 2;                    // float4 = two (delta,beta) pairs
     for (int d = blockIdx.x; d < a.n_dest; d += gridDim.x) {
-        for (int v = threadIdx.x; v < nv; v += blockDim.x) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int b = 0; b < a.B; ++b) {
-                const int ang = a.angle_of_b[b];
-                const int* off = a.off + (size_t)ang * (a.n_dest + 1);
-                const int e0 = off[d], e1 = off[d + 1];
+        if (threadIdx.x == 0) count = 0;
+        __syncthreads();
+        // deterministic list order: batch-major, then CSR order -> prefix positions via a serial scan
+        // over the (few) batch elements by thread 0 would serialise; instead every b writes into its
+        // own slot range computed from per-b counts.
+        __shared__ int cnt[256];
+        int e0 = 0, e1 = 0;
+        if (threadIdx.x < a.B) {
+            const int ang = a.angle_of_b[threadIdx.x];
+            const int* off = a.off + (size_t)ang * (a.n_dest + 1);
+            e0 = off[d];
+            e1 = off[d + 1];
+        }
+        cnt[threadIdx.x] = e1 - e0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int b = 0; b < a.B; ++b) { const int c = cnt[b]; cnt[b] = run; run += c; }
+            count = run;
+        }
+        __syncthreads();
+        const int total = count;
+        if (total <= BDOF_ROTADJ_MAXLIST) {
+            if (threadIdx.x < a.B) {
+                const int ang = a.angle_of_b[threadIdx.x];
                 const int* order = a.order + (size_t)ang * a.n_src;
-                for (int e = e0; e < e1; ++e) {
-                    const float4 s = reinterpret_cast<const float4*>(a.grot + ((size_t)b * a.n_src + order[e]) * a.NY)[v];
+                int pos = cnt[threadIdx.x];
+                for (int e = e0; e < e1; ++e) list[pos++] = threadIdx.x * a.n_src + order[e];
+            }
+            __syncthreads();
+            for (int v = threadIdx.x; v < nv; v += blockDim.x) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                int e = 0;
+                for (; e + 4 <= total; e += 4) {
+                    const float4 s0 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e] * a.NY)[v];
+                    const float4 s1 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e + 1] * a.NY)[v];
+                    const float4 s2 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e + 2] * a.NY)[v];
+                    const float4 s3 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e + 3] * a.NY)[v];
+                    acc.x += s0.x; acc.y += s0.y; acc.z += s0.z; acc.w += s0.w;
+                    acc.x += s1.x; acc.y += s1.y; acc.z += s1.z; acc.w += s1.w;
+                    acc.x += s2.x; acc.y += s2.y; acc.z += s2.z; acc.w += s2.w;
+                    acc.x += s3.x; acc.y += s3.y; acc.z += s3.z; acc.w += s3.w;
+                }
+                for (; e < total; ++e) {
+                    const float4 s = reinterpret_cast<const float4*>(a.grot + (size_t)list[e] * a.NY)[v];
                     acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
                 }
+                float4* dst = reinterpret_cast<float4*>(a.gvol + (size_t)d * a.NY) + v;
+                float4 o = make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
+                if (a.accumulate) { const float4 q = *dst; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+                *dst = o;
             }
-            float4* dst = reinterpret_cast<float4*>(a.gvol + (size_t)d * a.NY) + v;
-            float4 o = make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
-            if (a.accumulate) { const float4 q = *dst; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
-            *dst = o;
+        } else {
+            // clamped border rows of large volumes can collect more sources than the LDS list holds
+            for (int v = threadIdx.x; v < nv; v += blockDim.x) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int b = 0; b < a.B; ++b) {
+                    const int ang = a.angle_of_b[b];
+                    const int* off = a.off + (size_t)ang * (a.n_dest + 1);
+                    const int* order = a.order + (size_t)ang * a.n_src;
+                    for (int e = off[d]; e < off[d + 1]; ++e) {
+                        const float4 s = reinterpret_cast<const float4*>(a.grot + ((size_t)b * a.n_src + order[e]) * a.NY)[v];
+                        acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+                    }
+                }
+                float4* dst = reinterpret_cast<float4*>(a.gvol + (size_t)d * a.NY) + v;
+                float4 o = make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
+                if (a.accumulate) { const float4 q = *dst; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+                *dst = o;
+            }
         }
+        __syncthreads();
     }
 }
 

@@ -50,7 +50,13 @@ class MultisliceEngine(object):
             det = _lib.DET_NEAR
             hdet = util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi)
         self.det_mode = det
+        self.variant = variant
         self.k = k
+        # tf_all + far field: the last transfer-function step only multiplies the far field by the
+        # unit-modulus H (F P phi = H . F phi); libbdof skips it and the host applies it to returned waves
+        self._far_phase = None
+        if det == _lib.DET_FAR and variant == 'tf_all':
+            self._far_phase = (hs.astype(np.complex128) * (self.nx * self.ny)).astype(np.complex64)
         self.ctx.check(self.lib.bdof_set_physics(self.h, k, hs.ctypes.data, hdet.ctypes.data if hdet is not None else None,
                                                  det, _VARIANT[variant]))
 
@@ -81,16 +87,22 @@ class MultisliceEngine(object):
 
     # ---- forward -------------------------------------------------------------------------------
     def _wave_to_host(self, buf, B):
-        w = buf.download((B, self.nx, self.ny), np.complex64).transpose(0, 2, 1)
         if self.det_mode == _lib.DET_FAR:
-            w = np.fft.fftshift(w, axes=(1, 2))          # np_funcs.py:48
-        return np.ascontiguousarray(w)
+            w = buf.download((B, self.ny, self.nx), np.complex64)        # un-shifted fft2, [b][ky][kx]
+            if self._far_phase is not None:
+                w = w * self._far_phase
+            return np.ascontiguousarray(np.fft.fftshift(w, axes=(1, 2)))   # np_funcs.py:48
+        return np.ascontiguousarray(buf.download((B, self.nx, self.ny), np.complex64).transpose(0, 2, 1))
 
-    def _meas_to_device(self, meas_abs):
+    def meas_layout(self, meas_abs):
+        """|measured| (n, Y, X) in the index order libbdof's loss kernels read it."""
         m = np.asarray(meas_abs, dtype=np.float32)
         if self.det_mode == _lib.DET_FAR:
-            m = np.fft.ifftshift(m, axes=(1, 2))
-        return DeviceBuffer.from_host(self.ctx, np.ascontiguousarray(m.transpose(0, 2, 1)))
+            return np.ascontiguousarray(np.fft.ifftshift(m, axes=(1, 2)))
+        return np.ascontiguousarray(m.transpose(0, 2, 1))
+
+    def _meas_to_device(self, meas_abs):
+        return DeviceBuffer.from_host(self.ctx, self.meas_layout(meas_abs))
 
     def forward(self, B, angle_idx=None, xoff=None, yoff=None, keep_tape=False, to_host=True):
         out = DeviceBuffer(self.ctx, B * self.nx * self.ny * 8, np.complex64, (B, self.nx, self.ny))

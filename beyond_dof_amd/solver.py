@@ -63,10 +63,7 @@ class FullfieldSolver(object):
 
     def set_measurements(self, prj_abs):
         """|prj| for every angle, (n_theta, Y, X) (loss uses np.abs(this_prj_batch), fullfield.py:106)."""
-        m = np.asarray(prj_abs, dtype=np.float32)
-        if self.eng.det_mode == _lib.DET_FAR:
-            m = np.fft.ifftshift(m, axes=(1, 2))
-        self.meas = DeviceBuffer.from_host(self.ctx, np.ascontiguousarray(m.transpose(0, 2, 1)))
+        self.meas = DeviceBuffer.from_host(self.ctx, self.eng.meas_layout(prj_abs))
 
     def reset_moments(self):
         """m, v = (None, None) at the start of every epoch (fullfield.py:338, quirk Q10)."""

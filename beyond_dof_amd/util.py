@@ -24,9 +24,9 @@ def get_kernel(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=PI):
 
 
 def device_transfer_function(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI):
-    """H prepared for libbdof: un-shifted, transposed to [kx][ky], 1/(NX*NY) folded in, complex64."""
+    """H prepared for libbdof: un-shifted [ky][kx], 1/(NX*NY) folded in, complex64."""
     h = get_kernel(dist_nm, lmbda_nm, voxel_nm, (ny, nx), pi=pi)
-    hs = np.fft.ifftshift(h).T / float(nx * ny)
+    hs = np.fft.ifftshift(h) / float(nx * ny)
     return np.ascontiguousarray(hs.astype(np.complex64))
 
 

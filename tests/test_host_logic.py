@@ -28,7 +28,7 @@ def test_device_transfer_function_is_the_fft_domain_multiplier():
     rng = np.random.default_rng(0)
     w = rng.normal(size=(1, ny, nx)) + 1j * rng.normal(size=(1, ny, nx))
     ref = orc._propagate(w, orc.get_kernel(1.0, 0.248, [1., 1., 1.], (ny, nx, 1)))
-    mine = np.fft.fft2(w[0]) * (hs.T * nx * ny)
+    mine = np.fft.fft2(w[0]) * (hs * nx * ny)
     mine = np.fft.ifft2(mine)
     np.testing.assert_allclose(mine, ref[0], rtol=0, atol=5e-7)
 

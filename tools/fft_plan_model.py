@@ -101,3 +101,85 @@ if __name__ == '__main__':
             err = np.abs(y - ref).max() / np.abs(ref).max()
             assert err < 1e-12, (N, sign, err)
         print(N, PLANS[N], 'ok; worst-way LDS conflicts (row layout, pad idx>>4):', cc.stats)
+
+
+def model_tile_transposed(x_rows, sign):
+    """Emulates the tile kernels: TILE rows, all stages but the last wave-local per row, the last stage done
+    by threads mapped (r = q % TILE, j = q // TILE) and stored transposed.  Returns out[pos][r]."""
+    TILE, N = x_rows.shape
+    radices = PLANS[N]
+    T = N // 8
+    RS = ((N + N // 16 + 29) // 32) * 32 + 2
+    lds = np.zeros(TILE * RS, complex)
+    for r in range(TILE):
+        regs = np.array([[x_rows[r, tid + m * T] for m in range(8)] for tid in range(T)])
+        p = 1
+        for s, rad in enumerate(radices[:-1]):
+            nb, t = 8 // rad, N // rad
+            if s > 0:
+                for tid in range(T):
+                    for j in range(nb):
+                        for m in range(rad):
+                            regs[tid, j * rad + m] = lds[r * RS + pad_row(tid + j * T + m * t)]
+            out = np.zeros_like(regs)
+            for tid in range(T):
+                for j in range(nb):
+                    i = tid + j * T
+                    k = i % p
+                    u = regs[tid, j * rad:(j + 1) * rad] * np.exp(sign * 2j * np.pi * np.arange(rad) * k / (p * rad))
+                    v = np.array([np.sum(u * np.exp(sign * 2j * np.pi * np.arange(rad) * q / rad)) for q in range(rad)])
+                    for q in range(rad):
+                        lds[r * RS + pad_row((i - k) * rad + k + q * p)] = v[q]
+            p *= rad
+    out = np.zeros((N, TILE), complex)
+    worst = 1
+    for q0 in range(0, TILE * T, 32):            # 32-lane read groups of the transposed stage
+        slots = {}
+        for q in range(q0, q0 + 32):
+            r, j = q % TILE, q // TILE
+            for m in range(1):
+                a = r * RS + pad_row(j + m * T)
+                slots.setdefault(a % 32, set()).add(a)
+        worst = max(worst, max(len(v) for v in slots.values()))
+    for q in range(TILE * T):
+        r, j = q % TILE, q // TILE
+        u = np.array([lds[r * RS + pad_row(j + m * T)] for m in range(8)])
+        u = u * np.exp(sign * 2j * np.pi * np.arange(8) * j / N)
+        v = np.array([np.sum(u * np.exp(sign * 2j * np.pi * np.arange(8) * qq / 8)) for qq in range(8)])
+        for qq in range(8):
+            out[j + qq * T, r] = v[qq]
+    return out, worst
+
+
+def check_affine_slots():
+    """slot(base + c) == slot(base) + c + (c >> 4) for every access the plans generate."""
+    for N, radices in PLANS.items():
+        T = N // 8
+        p = 1
+        for s_, r in enumerate(radices):
+            nb, t = 8 // r, N // r
+            for tid in range(T):
+                for j in range(nb):
+                    i = tid + j * T
+                    if s_ > 0:
+                        for m in range(r):
+                            assert pad_row(i + m * t) == pad_row(i) + m * t + ((m * t) >> 4), (N, 'read', s_, i, m)
+                    if s_ < len(radices) - 1:
+                        k = i % p
+                        b = (i - k) * r + k
+                        for q in range(r):
+                            assert pad_row(b + q * p) == pad_row(b) + q * p + ((q * p) >> 4), (N, 'write', s_, i, q)
+            p *= r
+    print('affine slot property holds for all plans')
+
+
+if __name__ == '__main__':
+    check_affine_slots()
+    rng = np.random.default_rng(1)
+    for N, TILE in [(64, 64), (128, 32), (256, 16), (512, 16), (1024, 16)]:
+        x = rng.normal(size=(TILE, N)) + 1j * rng.normal(size=(TILE, N))
+        for sign in (-1, 1):
+            out, worst = model_tile_transposed(x, sign)
+            ref = (np.fft.fft(x, axis=1) if sign < 0 else np.fft.ifft(x, axis=1) * N).T
+            assert np.abs(out - ref).max() / np.abs(ref).max() < 1e-12
+        print('transposed tail ok N={} TILE={} worst read conflict {}-way'.format(N, TILE, worst))

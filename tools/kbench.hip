@@ -1,0 +1,84 @@
+// Micro-benchmark of the hot kernels in isolation (development aid; not part of the product).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -o tools/kbench tools/kbench.hip && ./tools/kbench [B] [iters]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+#include "../beyond_dof_amd/csrc/bdof_kernels.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <class F> static float time_it(F f, int iters) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms = 0; CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipGetLastError());
+    return ms / iters;
+}
+
+static int balanced(int tiles, int cap) { if (tiles <= cap) return tiles; int r = (tiles + cap - 1) / cap; return (tiles + r - 1) / r; }
+
+int main(int argc, char** argv) {
+    const int B = argc > 1 ? atoi(argv[1]) : 25;
+    constexpr int N = 512;
+    const int iters = argc > 2 ? atoi(argv[2]) : 20;
+    const int S = 8;
+    const size_t fld = (size_t)B * N * N;
+    cf *in, *out, *tape, *h, *tw, *probe; float2 *vol, *grot; int *tab, *ang;
+    CK(hipMalloc(&in, fld * 8)); CK(hipMalloc(&out, fld * 8)); CK(hipMalloc(&tape, fld * 8));
+    CK(hipMalloc(&h, (size_t)N * N * 8)); CK(hipMalloc(&tw, N * 8)); CK(hipMalloc(&probe, (size_t)N * N * 8));
+    CK(hipMalloc(&vol, (size_t)N * N * N * 8)); CK(hipMalloc(&grot, fld * S * 8));
+    CK(hipMalloc(&tab, (size_t)B * S * N * 4)); CK(hipMalloc(&ang, B * 4));
+    std::vector<cf> hw(N);
+    for (int j = 0; j < N; ++j) hw[j] = make_float2((float)cos(-2 * M_PI * j / N), (float)sin(-2 * M_PI * j / N));
+    CK(hipMemcpy(tw, hw.data(), N * 8, hipMemcpyHostToDevice));
+    std::vector<float> rnd(fld * 2);
+    for (auto& v : rnd) v = (float)(rand() % 2001 - 1000) * 1e-3f;
+    CK(hipMemcpy(in, rnd.data(), fld * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(tape, rnd.data(), fld * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(h, rnd.data(), (size_t)N * N * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(probe, rnd.data(), (size_t)N * N * 8, hipMemcpyHostToDevice));
+    {
+        std::vector<float> v((size_t)N * N * N * 2);
+        for (auto& x : v) x = 1e-9f * (float)(rand() % 1000);
+        CK(hipMemcpy(vol, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+        std::vector<int> t((size_t)B * S * N), a(B);
+        for (auto& x : t) x = rand() % (N * N);      // random source rows, like a generic rotation angle
+        for (int b = 0; b < B; ++b) a[b] = b;
+        CK(hipMemcpy(tab, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(ang, a.data(), B * 4, hipMemcpyHostToDevice));
+    }
+    ObjView obj{vol, tab, ang, nullptr, nullptr, S, N, N};
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int ncu = prop.multiProcessorCount;
+    const double px = (double)B * N * N;
+    const int tiles = B * N / RowCfg<N>::TILE;
+    for (int per_cu : {1, 2}) {
+        const int grid = balanced(tiles, ncu * per_cu);
+        printf("-- %d WG/CU cap, grid %d (tiles %d)\n", per_cu, grid, tiles);
+        {
+            RowFwdArgs a{in, probe, out, obj, B, N, 3, 25.3f, tw};
+            float ms = time_it([&] { hipLaunchKernelGGL((k_row_fwd<N, false, true>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters);
+            printf("row_fwd   %8.2f us  %7.1f GB/s (24 B/px)\n", ms * 1e3, 24 * px / ms / 1e6);
+        }
+        {
+            RowPropArgs a{in, out, h, B, N, 1.f, 0, tw};
+            float ms = time_it([&] { hipLaunchKernelGGL((k_row_prop<N>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters);
+            printf("row_prop  %8.2f us  %7.1f GB/s (16 B/px)\n", ms * 1e3, 16 * px / ms / 1e6);
+        }
+        {
+            RowBwdArgs a{in, tape, probe, out, grot, obj, B, N, 3, 25.3f, tw};
+            float ms = time_it([&] { hipLaunchKernelGGL((k_row_bwd<N, false>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters);
+            printf("row_bwd   %8.2f us  %7.1f GB/s (40 B/px)\n", ms * 1e3, 40 * px / ms / 1e6);
+        }
+    }
+    return 0;
+}
