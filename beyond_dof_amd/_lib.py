@@ -25,8 +25,8 @@ _SIGNATURES = {
     'bdof_sync': (ctypes.c_int, [_vp]),
     'bdof_device_count': (ctypes.c_int, []),
     'bdof_configure': (ctypes.c_int, [_vp] + [ctypes.c_int] * 5),
-    'bdof_set_physics': (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp, ctypes.c_int, ctypes.c_int]),
-    'bdof_set_probe': (ctypes.c_int, [_vp, _vp]),
+    'bdof_set_physics': (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
+    'bdof_set_probe': (ctypes.c_int, [_vp, _vp, ctypes.c_double, ctypes.c_double]),
     'bdof_set_object': (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int]),
     'bdof_set_rotation_adjoint': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     'bdof_forward': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int]),
@@ -37,6 +37,7 @@ _SIGNATURES = {
     'bdof_rotation_adjoint': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float]),
     'bdof_adam_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
                        + [ctypes.c_float] * 8 + [ctypes.c_int, ctypes.c_int]),
+    'bdof_mask_shrink': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_float]),
     'bdof_profile_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_profile_read': (ctypes.c_int, [_vp, ctypes.c_int, _c_int_p, ctypes.POINTER(ctypes.c_double)]),
     'bdof_malloc': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),

@@ -1,6 +1,7 @@
 // libbdof.so — host side of the C ABI declared in include/bdof.h.
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <complex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -27,6 +28,7 @@ struct bdof_ctx {
     double *partial = nullptr, *loss_dev = nullptr;
     int npartial = 0;
     float k = 0.f;
+    std::complex<double> h00{1.0, 0.0}, hdet00{1.0, 0.0}, a0{0.0, 0.0};   // carrier splitting (bdof_kernels.h)
     int det_mode = BDOF_DET_NONE, variant = BDOF_VARIANT_NUMPY_SKIP_LAST;
     bool have_physics = false, have_probe = false, tape_valid = false, last_valid = false;
     ObjView obj{};
@@ -55,6 +57,24 @@ static int fail(bdof_ctx* c, int code, const std::string& msg) {
             return fail((c), (int)e_, std::string(#call) + ": " + hipGetErrorString(e_));          \
         }                                                                                          \
     } while (0)
+
+// constant part of the wave entering slice z: a_z = a_0 * H00^z  (H00 = DC value of the transfer function)
+static cf carrier_at(const bdof_ctx* c, int z) {
+    const std::complex<double> a = c->a0 * std::pow(c->h00, z);
+    return make_float2((float)a.real(), (float)a.imag());
+}
+// constant part of the detector wave (real-space detectors) / of the wave whose fft2 is the far field
+static std::complex<double> carrier_end(const bdof_ctx* c) {
+    std::complex<double> a = c->a0 * std::pow(c->h00, c->S - 1);
+    if (c->det_mode != BDOF_DET_FAR && c->variant == BDOF_VARIANT_TF_ALL) a *= c->h00;
+    if (c->det_mode == BDOF_DET_NEAR) a *= c->hdet00;
+    return a;
+}
+static cf carrier_det(const bdof_ctx* c) {
+    std::complex<double> a = carrier_end(c);
+    if (c->det_mode == BDOF_DET_FAR) a *= (double)c->NX * (double)c->NY;
+    return make_float2((float)a.real(), (float)a.imag());
+}
 
 static bool supported_n(int n) { return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
 
@@ -119,7 +139,7 @@ template <int N> static int rows_grid(const bdof_ctx* c, int B, int R) {
 // A_z: L1 (or the probe) -> L2 (tstore) or L1 (plain)
 static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore) {
     ProfScope ps(c, BDOF_K_ROW_FWD);
-    RowFwdArgs a{in, c->probe, out, c->obj, B, c->NX, z, c->k, c->twY};
+    RowFwdArgs a{in, c->probe, out, c->obj, B, c->NX, z, c->k, carrier_at(c, z), c->twY};
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
@@ -145,7 +165,7 @@ static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf*
 // A'_z: L1 (g) + L1 (tape) -> L2 (g)
 static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout) {
     ProfScope ps(c, BDOF_K_ROW_BWD);
-    RowBwdArgs a{gin, tape, c->probe, gout, c->grot, c->obj, B, c->NX, z, c->k, c->twY};
+    RowBwdArgs a{gin, tape, c->probe, gout, c->grot, c->obj, B, c->NX, z, c->k, carrier_at(c, z), c->twY};
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
@@ -156,9 +176,9 @@ static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* t
 
 // Real-space detector on L1 rows.  Returns the grid (= number of partial sums when meas != null).
 static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool tstore, cf* out_wave, const float* meas,
-                            float in_scale, float out_scale, float seed_scale) {
+                            float in_scale, float out_scale, float seed_scale, cf carrier) {
     ProfScope ps(c, BDOF_K_LOSS);
-    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NX, in_scale, out_scale, seed_scale, c->twY};
+    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NX, in_scale, out_scale, seed_scale, carrier, c->twY};
     int grid = 0;
     DISPATCH_N(c->NY, {
         grid = rows_grid<N_>(c, B, c->NX);
@@ -172,7 +192,7 @@ static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool 
 static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* out_wave, const float* meas, float in_scale,
                            float out_scale, float seed_scale) {
     ProfScope ps(c, BDOF_K_LOSS);
-    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NY, in_scale, out_scale, seed_scale, c->twX};
+    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NY, in_scale, out_scale, seed_scale, carrier_det(c), c->twX};
     int grid = 0;
     DISPATCH_N(c->NX, {
         grid = rows_grid<N_>(c, B, c->NY);
@@ -319,8 +339,9 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     return 0;
 }
 
-int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det, int det_mode, int variant) {
-    if (!c || !hs) return BDOF_ERR_ARG;
+int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det, const double* h00, const double* hdet00,
+                     int det_mode, int variant) {
+    if (!c || !hs || !h00) return BDOF_ERR_ARG;
     if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
     if (det_mode < 0 || det_mode > 2 || variant < 0 || variant > 1) return fail(c, BDOF_ERR_ARG, "bad det_mode / variant");
     if (det_mode == BDOF_DET_NEAR && !hs_det) return fail(c, BDOF_ERR_ARG, "hs_det required for BDOF_DET_NEAR");
@@ -341,17 +362,20 @@ int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det
     }
     HIPC(c, hipStreamSynchronize(c->stream));
     c->k = (float)k;
+    c->h00 = std::complex<double>(h00[0], h00[1]);
+    c->hdet00 = hdet00 ? std::complex<double>(hdet00[0], hdet00[1]) : std::complex<double>(1.0, 0.0);
     c->det_mode = det_mode;
     c->variant = variant;
     c->have_physics = true;
     return 0;
 }
 
-int bdof_set_probe(bdof_ctx* c, const float* probe) {
+int bdof_set_probe(bdof_ctx* c, const float* probe, double a0_re, double a0_im) {
     if (!c || !probe) return BDOF_ERR_ARG;
     if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
     HIPC(c, hipMemcpyAsync(c->probe, probe, sizeof(cf) * c->NX * c->NY, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
+    c->a0 = std::complex<double>(a0_re, a0_im);
     c->have_probe = true;
     return 0;
 }
@@ -398,9 +422,9 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
         if (c->det_mode == BDOF_DET_FAR)
             launch_loss_far(c, B, c->bufA, nullptr, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f);
         else if (c->det_mode == BDOF_DET_NONE && !tf_all)
-            launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out_wave, nullptr, 1.f / c->NY, 1.f, 0.f);
+            launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out_wave, nullptr, 1.f / c->NY, 1.f, 0.f, carrier_det(c));
         else
-            launch_loss_real(c, B, c->bufB, nullptr, false, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f);
+            launch_loss_real(c, B, c->bufB, nullptr, false, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f, carrier_det(c));
     }
     if (keep_tape && !tf_all) {
         // probe_array[S-1] = phi_{S-1} (np_funcs.py:41-43): keep R phi_{S-1} in L1 order in bufA
@@ -423,11 +447,11 @@ int bdof_tape_to_real(bdof_ctx* c, int i, int B, void* out) {
     if (i < 0 || i >= c->S) return fail(c, BDOF_ERR_ARG, "slice index outside [0, S)");
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     if (i < c->S - 1) {
-        launch_loss_real(c, B, c->tape + (size_t)i * fld, nullptr, false, (cf*)out, nullptr, 1.f, 1.f, 0.f);
+        launch_loss_real(c, B, c->tape + (size_t)i * fld, nullptr, false, (cf*)out, nullptr, 1.f, 1.f, 0.f, carrier_at(c, i + 1));
     } else {
         if (!c->last_valid)
             return fail(c, BDOF_ERR_STATE, "the last slice's wave is only kept after bdof_forward(keep_tape=1) with the numpy_skip_last variant");
-        launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out, nullptr, 1.f / c->NY, 1.f, 0.f);
+        launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out, nullptr, 1.f / c->NY, 1.f, 0.f, carrier_at(c, c->S - 1));
     }
     HIPC(c, hipGetLastError());
     return 0;
@@ -453,11 +477,11 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     if (c->det_mode == BDOF_DET_FAR) {
         npart = launch_loss_far(c, B, c->bufA, c->bufB, (cf*)out_wave, meas, 1.f, 1.f, seed_scale);
     } else if (c->det_mode == BDOF_DET_NONE && !tf_all) {
-        npart = launch_loss_real(c, B, c->bufA, c->bufB, false, (cf*)out_wave, meas, 1.f / NYf, 1.f / NYf, seed_scale);
+        npart = launch_loss_real(c, B, c->bufA, c->bufB, false, (cf*)out_wave, meas, 1.f / NYf, 1.f / NYf, seed_scale, carrier_det(c));
     } else {
         // the detector wave came out of a transfer-function step: seed -> R (transposed) -> adjoint step
         const cf* h = c->det_mode == BDOF_DET_NONE ? c->hs : (tf_all ? c->hcomb : c->hdet);
-        npart = launch_loss_real(c, B, c->bufB, c->bufA, true, (cf*)out_wave, meas, 1.f, 1.f, seed_scale);
+        npart = launch_loss_real(c, B, c->bufB, c->bufA, true, (cf*)out_wave, meas, 1.f, 1.f, seed_scale, carrier_det(c));
         launch_row_prop(c, B, c->bufA, c->bufB, h, 1.f, 1);
     }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, npart,
@@ -513,6 +537,16 @@ int bdof_adam_step(bdof_ctx* c, const void* x_old, void* x_new, const void* g, v
     size_t need = (n + 255) / 256;
     int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
     hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_mask_shrink(bdof_ctx* c, const void* x, float* mask, size_t n, float thresh) {
+    if (!c || !x || !mask) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    size_t need = (n + 255) / 256;
+    int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
+    hipLaunchKernelGGL(k_mask_shrink, dim3(grid), dim3(256), 0, c->stream, (const float2*)x, mask, n, thresh);
     HIPC(c, hipGetLastError());
     return 0;
 }

@@ -65,28 +65,35 @@ template <> struct FftPlan<256>  { static constexpr int NS = 3, R0 = 8, R1 = 4, 
 template <> struct FftPlan<512>  { static constexpr int NS = 3, R0 = 8, R1 = 8, R2 = 8, R3 = 1; };
 template <> struct FftPlan<1024> { static constexpr int NS = 4, R0 = 8, R1 = 2, R2 = 8, R3 = 8; };
 
+// Twiddles.  The LAST stage's factors exp(-2 pi i m tid / N) depend on the lane and stay in registers (7 values);
+// the middle stages' factors depend only on k = butterfly % p (8 or 16 distinct lanes' worth) and live in a small
+// LDS table [k][m-1] (row length R-1 is odd -> the distinct k of a wave hit distinct banks, equal k broadcast).
 template <int N> struct FftTw {
     typedef FftPlan<N> P;
-    static constexpr int n1 = (8 / P::R1) * (P::R1 - 1);
-    static constexpr int n2 = P::NS > 2 ? (8 / P::R2) * (P::R2 - 1) : 0;
-    static constexpr int n3 = P::NS > 3 ? (8 / P::R3) * (P::R3 - 1) : 0;
-    static constexpr int OFF1 = 0, OFF2 = n1, OFF3 = n1 + n2, COUNT = n1 + n2 + n3;
-    cf w[COUNT];   // forward (exp(-i..)) twiddles, thread-private, loaded once per kernel
+    static constexpr int RL = P::NS == 2 ? P::R1 : (P::NS == 3 ? P::R2 : P::R3);      // last radix (8)
+    static constexpr int PL = N / RL;                                                  // its p
+    // middle stages: (R1, p = R0) when NS > 2; (R2, p = R0*R1) when NS > 3
+    static constexpr int M1_R = P::NS > 2 ? P::R1 : 1, M1_P = P::R0;
+    static constexpr int M2_R = P::NS > 3 ? P::R2 : 1, M2_P = P::R0 * P::R1;
+    static constexpr int M1_OFF = 0, M1_CNT = P::NS > 2 ? M1_P * (M1_R - 1) : 0;
+    static constexpr int M2_OFF = M1_CNT, M2_CNT = P::NS > 3 ? M2_P * (M2_R - 1) : 0;
+    static constexpr int LDS_CNT = M1_CNT + M2_CNT > 0 ? M1_CNT + M2_CNT : 1;
+    static constexpr int D1 = M1_R > 1 ? M1_R - 1 : 1, D2 = M2_R > 1 ? M2_R - 1 : 1;   // row lengths (never 0 as divisors)
+    cf w[7];            // last stage, forward sign
+    const cf* mid;      // LDS table of the middle stages
 
-    template <int R, int PP, int OFF> __device__ __forceinline__ void load_stage(const cf* __restrict__ table, int tid) {
-        constexpr int T = N / 8, NB = 8 / R;
+    // table[j] = exp(-2 pi i j / N), j in [0, N).  Must be called by every thread of the workgroup.
+    __device__ __forceinline__ void load(const cf* __restrict__ table, int tid, cf* lds_mid) {
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            int k = (tid + j * T) % PP;
-#pragma unroll
-            for (int m = 1; m < R; ++m) w[OFF + j * (R - 1) + m - 1] = table[m * k * (N / (PP * R))];
+        for (int m = 1; m < 8; ++m) w[m - 1] = table[m * tid];
+        for (int e = threadIdx.x; e < M1_CNT + M2_CNT; e += blockDim.x) {
+            int k, m, step;
+            if (e < M1_CNT) { k = e / D1; m = e % D1 + 1; step = N / (M1_P * M1_R); }
+            else { const int f = e - M1_CNT; k = f / D2; m = f % D2 + 1; step = N / (M2_P * M2_R); }
+            lds_mid[e] = table[m * k * step];
         }
-    }
-    // table[j] = exp(-2 pi i j / N), j in [0, N)
-    __device__ __forceinline__ void load(const cf* __restrict__ table, int tid) {
-        load_stage<P::R1, P::R0, OFF1>(table, tid);
-        if constexpr (P::NS > 2) load_stage<P::R2, P::R0 * P::R1, OFF2>(table, tid);
-        if constexpr (P::NS > 3) load_stage<P::R3, P::R0 * P::R1 * P::R2, OFF3>(table, tid);
+        mid = lds_mid;
+        __syncthreads();
     }
 };
 
@@ -114,15 +121,26 @@ template <int N, int R, class L> __device__ __forceinline__ void stage_read(cf (
     }
 }
 
-template <int N, int SIGN, int R, int PP, int TWOFF>
-__device__ __forceinline__ void stage_compute(cf (&u)[8], const FftTw<N>& tw) {
-    constexpr int NB = 8 / R;
+// WHICH: 0 = first stage (no twiddles), 1 / 2 = middle stage (LDS table), 3 = last stage (registers)
+template <int N, int SIGN, int R, int PP, int WHICH>
+__device__ __forceinline__ void stage_compute(cf (&u)[8], const FftTw<N>& tw, int tid) {
+    constexpr int T = N / 8, NB = 8 / R;
+    typedef FftTw<N> TW;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        if constexpr (PP > 1) {
+        if constexpr (WHICH == 3) {
 #pragma unroll
             for (int m = 1; m < R; ++m) {
-                cf w = tw.w[TWOFF + j * (R - 1) + m - 1];
+                cf w = tw.w[m - 1];
+                if (SIGN > 0) w.y = -w.y;
+                u[j * R + m] = cmul(u[j * R + m], w);
+            }
+        } else if constexpr (WHICH == 1 || WHICH == 2) {
+            const int k = (tid + j * T) % PP;
+            const cf* row = tw.mid + (WHICH == 1 ? TW::M1_OFF : TW::M2_OFF) + k * (R - 1);
+#pragma unroll
+            for (int m = 1; m < R; ++m) {
+                cf w = row[m - 1];
                 if (SIGN > 0) w.y = -w.y;
                 u[j * R + m] = cmul(u[j * R + m], w);
             }
@@ -149,26 +167,25 @@ template <int N, int R, int PP, class L> __device__ __forceinline__ void stage_w
 template <int N, int SIGN, class L>
 __device__ __forceinline__ void line_fft(cf (&u)[8], const FftTw<N>& tw, int tid, L& lds) {
     typedef FftPlan<N> P;
-    typedef FftTw<N> TW;
-    stage_compute<N, SIGN, P::R0, 1, 0>(u, tw);
+    stage_compute<N, SIGN, P::R0, 1, 0>(u, tw, tid);
     lds.sync_r2w();
     stage_write<N, P::R0, 1>(u, tid, lds);
     lds.sync_w2r();
     stage_read<N, P::R1>(u, tid, lds);
-    stage_compute<N, SIGN, P::R1, P::R0, TW::OFF1>(u, tw);
+    stage_compute<N, SIGN, P::R1, P::R0, (P::NS == 2 ? 3 : 1)>(u, tw, tid);
     if constexpr (P::NS > 2) {
         lds.sync_r2w();
         stage_write<N, P::R1, P::R0>(u, tid, lds);
         lds.sync_w2r();
         stage_read<N, P::R2>(u, tid, lds);
-        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, TW::OFF2>(u, tw);
+        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, (P::NS == 3 ? 3 : 2)>(u, tw, tid);
     }
     if constexpr (P::NS > 3) {
         lds.sync_r2w();
         stage_write<N, P::R2, P::R0 * P::R1>(u, tid, lds);
         lds.sync_w2r();
         stage_read<N, P::R3>(u, tid, lds);
-        stage_compute<N, SIGN, P::R3, P::R0 * P::R1 * P::R2, TW::OFF3>(u, tw);
+        stage_compute<N, SIGN, P::R3, P::R0 * P::R1 * P::R2, 3>(u, tw, tid);
     }
 }
 
@@ -177,21 +194,20 @@ __device__ __forceinline__ void line_fft(cf (&u)[8], const FftTw<N>& tw, int tid
 template <int N, int SIGN, class L>
 __device__ __forceinline__ void line_fft_partial(cf (&u)[8], const FftTw<N>& tw, int tid, L& lds) {
     typedef FftPlan<N> P;
-    typedef FftTw<N> TW;
-    stage_compute<N, SIGN, P::R0, 1, 0>(u, tw);
+    stage_compute<N, SIGN, P::R0, 1, 0>(u, tw, tid);
     lds.sync_r2w();
     stage_write<N, P::R0, 1>(u, tid, lds);
     if constexpr (P::NS > 2) {
         lds.sync_w2r();
         stage_read<N, P::R1>(u, tid, lds);
-        stage_compute<N, SIGN, P::R1, P::R0, TW::OFF1>(u, tw);
+        stage_compute<N, SIGN, P::R1, P::R0, 1>(u, tw, tid);
         lds.sync_r2w();
         stage_write<N, P::R1, P::R0>(u, tid, lds);
     }
     if constexpr (P::NS > 3) {
         lds.sync_w2r();
         stage_read<N, P::R2>(u, tid, lds);
-        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, TW::OFF2>(u, tw);
+        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, 2>(u, tw, tid);
         lds.sync_r2w();
         stage_write<N, P::R2, P::R0 * P::R1>(u, tid, lds);
     }

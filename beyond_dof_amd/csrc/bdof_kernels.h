@@ -91,31 +91,49 @@ __device__ __forceinline__ long long obj_src_row(const ObjView& o, int b, int x,
     return ((long long)b * o.S + z) * NX + x;
 }
 
-// sin/cos with a 3-term Cody-Waite reduction by pi/2 and the cephes minimax polynomials: ~1 ulp for
-// |x| < 1e5 (k*delta is the phase picked up in ONE slice), a handful of registers instead of the
-// general-purpose sincosf's large-argument path.
-__device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
+// sin x and cos x - 1 with a 3-term Cody-Waite reduction by pi/2 and the cephes minimax polynomials: ~1 ulp for
+// |x| < 1e5 (k*delta is the phase picked up in ONE slice).  cos - 1 comes straight out of the polynomial in the
+// first quadrant (no cancellation for small arguments); in the other quadrants it is not small anyway.
+__device__ __forceinline__ void sin_cosm1(float x, float& s, float& cm1) {
     const float n = rintf(x * 0.636619772367581343f);
     float r = fmaf(-n, 1.5703125f, x);
     r = fmaf(-n, 4.837512969970703125e-4f, r);
     r = fmaf(-n, 7.54978995489188216e-8f, r);
     const float r2 = r * r;
     const float sp = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
-    const float cp = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
-                          fmaf(-0.5f, r2, 1.0f));
-    const int q = (int)n;
-    const float ss = (q & 1) ? cp : sp;
-    const float cc = (q & 1) ? sp : cp;
-    s = (q & 2) ? -ss : ss;
-    c = ((q + 1) & 2) ? -cc : cc;
+    const float cpm1 = fmaf(r2 * r2, fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f),
+                            -0.5f * r2);                      // cos r - 1
+    const int q = (int)n & 3;
+    const float cp = 1.0f + cpm1;
+    s = q == 0 ? sp : (q == 1 ? cp : (q == 2 ? -sp : -cp));
+    cm1 = q == 0 ? cpm1 : (q == 1 ? -sp - 1.0f : (q == 2 ? -2.0f - cpm1 : sp - 1.0f));
 }
 
 // c = exp(i k delta) * exp(-k beta)                      cnn_propagator/np_funcs.py:39
 __device__ __forceinline__ cf slice_modulation(float2 db, float k) {
-    float s, c;
-    sincos_cw(k * db.x, s, c);
+    float s, cm1;
+    sin_cosm1(k * db.x, s, cm1);
     const float e = __expf(-k * db.y);
-    return make_float2(e * c, e * s);
+    return make_float2(fmaf(e, cm1, e), e * s);
+}
+
+// cm1 = exp(i k delta) * exp(-k beta) - 1, free of cancellation for small arguments   (c: cnn_propagator/np_funcs.py:39)
+//   Re = expm1(-k beta) cos(k delta) + (cos(k delta) - 1) ;  Im = exp(-k beta) sin(k delta)
+__device__ __forceinline__ cf slice_modulation_m1(float2 db, float k) {
+    float s, cm1;
+    sin_cosm1(k * db.x, s, cm1);
+    const float y = -k * db.y;
+    const float e = __expf(y);
+    const float poly = y * fmaf(y * 0.5f, fmaf(y * (1.f / 3.f), fmaf(y * 0.25f, fmaf(y, 0.2f, 1.f), 1.f), 1.f), 1.f);
+    const float em1 = fabsf(y) < 0.1f ? poly : e - 1.f;
+    return make_float2(fmaf(em1, 1.0f + cm1, cm1), e * s);
+}
+
+// Carrier splitting: the wave is held as psi = a + eps with a known complex scalar a per slice (the plane-wave part,
+// propagated exactly on the host in float64) and only eps goes through the float32 FFTs, so round-off scales with the
+// scattered field instead of the full wave.  c (a + eps) = a + [eps + (c-1)(a + eps)].
+__device__ __forceinline__ cf modulate_eps(cf eps, cf carrier, cf cm1) {
+    return cadd(eps, cmul(cm1, cadd(carrier, eps)));
 }
 
 __device__ __forceinline__ void load_obj_row(const ObjView& o, long long srow, int y0, int tid, int T, float2 (&db)[8]) {
@@ -137,6 +155,7 @@ struct RowFwdArgs {
     ObjView obj;
     int B, NX, z;
     float k;
+    cf carrier;        // a_z: constant part of the wave entering slice z
     const cf* twiddle;
 };
 
@@ -145,8 +164,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
     FftTw<NY> tw;
-    tw.load(a.twiddle, tid);
+    tw.load(a.twiddle, tid, smem_tw);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -165,7 +185,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
             load_obj_row(a.obj, obj_src_row(a.obj, b, x, a.z, a.NX), y0, tid, C::T, db);
             if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) u[m] = cmul(u[m], slice_modulation(db[m], a.k));
+            for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], a.carrier, slice_modulation_m1(db[m], a.k));
             if constexpr (TSTORE) {
                 line_fft_partial<NY, -1>(u, tw, tid, lds);
             } else {
@@ -201,8 +221,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_pro
     typedef RowCfg<NX> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
+    __shared__ cf smem_tw[FftTw<NX>::LDS_CNT];
     FftTw<NX> tw;
-    tw.load(a.twiddle, tid);
+    tw.load(a.twiddle, tid, smem_tw);
     const int ntiles = a.B * a.NY / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -270,6 +291,7 @@ struct LossArgs {
     double* partial;     // [gridDim.x] per-workgroup sums of (|d|-|m|)^2
     int B, R;            // R rows per batch element
     float in_scale, out_scale, seed_scale;
+    cf carrier;          // constant part of the detector wave (far field: its DC bin value a*NX*NY)
     const cf* twiddle;
 };
 
@@ -288,8 +310,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
     constexpr int S1 = FAR ? -1 : +1;     // direction of the first transform; the second is the opposite
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
+    __shared__ cf smem_tw[FftTw<N>::LDS_CNT];
     FftTw<N> tw;
-    tw.load(a.twiddle, tid);
+    tw.load(a.twiddle, tid, smem_tw);
     const int ntiles = a.B * a.R / C::TILE;
     double acc = 0.0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -311,6 +334,12 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
             line_fft<N, S1>(u, tw, tid, lds);
 #pragma unroll
             for (int m = 0; m < 8; ++m) u[m] = cscale(u[m], a.in_scale);
+            if constexpr (FAR) {
+                if (r0 + r == 0 && tid == 0) u[0] = cadd(u[0], a.carrier);       // DC bin of the un-shifted fft2
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) u[m] = cadd(u[m], a.carrier);
+            }
             if (a.out_wave) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) a.out_wave[off + tid + m * C::T] = u[m];
@@ -364,6 +393,7 @@ struct RowBwdArgs {
     ObjView obj;
     int B, NX, z;
     float k;
+    cf carrier;        // a_z
     const cf* twiddle;
 };
 
@@ -372,8 +402,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
     FftTw<NY> tw;
-    tw.load(a.twiddle, tid);
+    tw.load(a.twiddle, tid, smem_tw);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -398,11 +429,13 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
             float2* gdst = a.grot + (((size_t)b * a.obj.S + a.z) * a.NX + x) * NY;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
+                // here c multiplies full-size fields, so the plain form is accurate enough (the cancellation-free
+                // c - 1 only matters where it generates the scattered field, in the forward kernel)
                 const cf c = slice_modulation(db[m], a.k);
-                const cf phi = cmul(p[m], c);
-                const cf t = cmulc(g[m], phi);          // G * conj(phi)
+                const cf phi = cmul(cadd(p[m], a.carrier), c);       // c psi,  psi = a_z + eps
+                const cf t = cmulc(g[m], phi);                       // G * conj(phi)
                 gdst[tid + m * C::T] = make_float2(a.k * t.y, -a.k * t.x);
-                g[m] = cmulc(g[m], c);                  // conj(c) G
+                g[m] = cmulc(g[m], c);                               // conj(c) G
             }
             if (a.gout) line_fft_partial<NY, -1>(g, tw, tid, lds);
         }
@@ -569,4 +602,10 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
         if (a.clip) { nd = fmaxf(nd, 0.f); nb = fmaxf(nb, 0.f); }
         a.x_new[idx] = make_float2(nd, nb);
     }
+}
+
+// shrink-wrap of the finite-support mask: mask *= (delta > thresh)      cnn_propagator/fullfield.py:365-368
+__global__ __launch_bounds__(256) void k_mask_shrink(const float2* x, float* mask, size_t n, float thresh) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)
+        mask[idx] = x[idx].x > thresh ? mask[idx] : 0.f;
 }

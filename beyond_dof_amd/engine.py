@@ -39,7 +39,8 @@ class MultisliceEngine(object):
         delta_nm = voxel_nm[-1]
         k = 2. * pi * delta_nm / lmbda_nm
         hs = util.device_transfer_function(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi)
-        hdet = None
+        h00 = np.array(util.transfer_function_dc(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi))
+        hdet = hdet00 = None
         if free_prop_cm is None:
             det = _lib.DET_NONE
         elif isinstance(free_prop_cm, str):
@@ -49,6 +50,7 @@ class MultisliceEngine(object):
         else:
             det = _lib.DET_NEAR
             hdet = util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi)
+            hdet00 = np.array(util.transfer_function_dc(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi))
         self.det_mode = det
         self.variant = variant
         self.k = k
@@ -58,12 +60,17 @@ class MultisliceEngine(object):
         if det == _lib.DET_FAR and variant == 'tf_all':
             self._far_phase = (hs.astype(np.complex128) * (self.nx * self.ny)).astype(np.complex64)
         self.ctx.check(self.lib.bdof_set_physics(self.h, k, hs.ctypes.data, hdet.ctypes.data if hdet is not None else None,
+                                                 h00.ctypes.data, hdet00.ctypes.data if hdet00 is not None else None,
                                                  det, _VARIANT[variant]))
 
     def set_probe(self, probe_real, probe_imag):
         probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.ny, self.nx))
-        p = np.ascontiguousarray(probe.T.astype(np.complex64))     # the reference rounds to complex64 too (np_funcs.py:20)
-        self.ctx.check(self.lib.bdof_set_probe(self.h, p.ctypes.data))
+        probe = probe.astype(np.complex64)                         # the reference rounds to complex64 too (np_funcs.py:20)
+        # carrier splitting: probe = a0 + eps.  A (nearly) uniform probe rides on its mean; a localised one has a0 = 0.
+        mean = complex(probe.astype(np.complex128).mean())
+        a0 = mean if np.abs(probe - mean).max() <= 0.25 * abs(mean) else 0j
+        eps = np.ascontiguousarray((probe.astype(np.complex128) - a0).T.astype(np.complex64))
+        self.ctx.check(self.lib.bdof_set_probe(self.h, eps.ctypes.data, a0.real, a0.imag))
 
     # ---- object --------------------------------------------------------------------------------
     def set_object_batch(self, grid_delta_batch, grid_beta_batch):

@@ -111,6 +111,11 @@ class FullfieldSolver(object):
         self.adam_update(i_batch, learning_rate, alpha_d, alpha_b, gamma)
         return loss
 
+    def shrink_wrap(self, thresh=1e-15):
+        """mask = mask * (obj_delta > 1e-15)   (cnn_propagator/fullfield.py:365-368, intended behaviour, quirk Q8)."""
+        if self.mask is not None:
+            self.ctx.check(self.ctx.lib.bdof_mask_shrink(self.ctx.handle, self.x[self.cur].ptr, self.mask.ptr, self.nvox, thresh))
+
     def gradient_to_host(self):
         self.ctx.sync()
         return util.rows_to_volume(self.g.download())

@@ -30,6 +30,13 @@ def device_transfer_function(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI):
     return np.ascontiguousarray(hs.astype(np.complex64))
 
 
+def transfer_function_dc(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI):
+    """(re, im) of ifftshift(H)[0][0]: the factor a constant wave picks up in one transfer-function step."""
+    h = get_kernel(dist_nm, lmbda_nm, voxel_nm, (ny, nx), pi=pi)
+    v = complex(np.fft.ifftshift(h)[0, 0])
+    return v.real, v.imag
+
+
 def rotation_lookup(array_size, n_theta):
     """Nearest-neighbour rotation source coordinates for every angle, as save_rotation_lookup builds
     them (cnn_propagator/util.py:294-332) but kept in memory: list of (X*Z, 2) int arrays.  Angles are

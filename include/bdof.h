@@ -47,11 +47,16 @@ int bdof_configure(bdof_ctx* ctx, int NY, int NX, int S, int Bmax, int with_grad
 /* Physics.  k = 2*PI*delta_nm/lambda_nm (np_funcs.py:32).  hs / hs_det: HOST arrays [NX][NY] complex,
  * hs[kx][ky] = ifftshift(get_kernel(...))[ky][kx] / (NX*NY)   (cnn_propagator/util.py:82-102, np_funcs.py:42);
  * the host computes them in float64 exactly as the reference does and rounds once to float32.
- * hs_det may be NULL unless det_mode == BDOF_DET_NEAR. */
-int bdof_set_physics(bdof_ctx* ctx, double k, const float* hs, const float* hs_det, int det_mode, int variant);
+ * hs_det may be NULL unless det_mode == BDOF_DET_NEAR.  h00 / hdet00: (re, im) of the un-scaled DC values
+ * ifftshift(H)[0][0] in float64 — the factor a constant wave picks up in one step (carrier splitting, below). */
+int bdof_set_physics(bdof_ctx* ctx, double k, const float* hs, const float* hs_det, const double* h00, const double* hdet00,
+                     int det_mode, int variant);
 
-/* Probe wavefront, HOST [NX][NY] complex (np_funcs.py:20-21; cnn_propagator/fullfield.py:276-314). */
-int bdof_set_probe(bdof_ctx* ctx, const float* probe);
+/* Probe wavefront (np_funcs.py:20-21; cnn_propagator/fullfield.py:276-314), split as probe = a0 + eps: `probe_eps` is
+ * the HOST array [NX][NY] complex of eps, a0 any complex constant (0 for a general probe, the plane-wave amplitude for a
+ * plane probe).  The library carries a0 through the slices exactly (a_{z+1} = a_z * h00, float64 on the host) and runs
+ * only eps through the float32 FFTs, so round-off scales with the scattered field, not with the full wave. */
+int bdof_set_probe(bdof_ctx* ctx, const float* probe_eps, double a0_re, double a0_im);
 
 /* Object.  vol: device rows of volNY pairs.  tab == NULL: row(b,z,x) = (b*S+z)*NX+x, i.e. the caller
  * supplies already rotated objects (the grid_delta_batch/grid_beta_batch arguments of
@@ -93,6 +98,9 @@ int bdof_rotation_adjoint(bdof_ctx* ctx, int B, const int* angle_of_b, void* gvo
 int bdof_adam_step(bdof_ctx* ctx, const void* x_old, void* x_new, const void* g, void* m, void* v, const float* mask,
                    int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
                    float lr, float b1, float b2, float eps, int i_batch, int clip);
+
+/* Shrink-wrap (cnn_propagator/fullfield.py:365-368): mask[i] *= (delta[i] > thresh) over n voxels. */
+int bdof_mask_shrink(bdof_ctx* ctx, const void* x, float* mask, size_t n, float thresh);
 
 /* Per-kernel-class timing with HIP events on the ctx stream (bench.py roofline leg). */
 int bdof_profile_enable(bdof_ctx* ctx, int enable);

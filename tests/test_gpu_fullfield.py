@@ -1,0 +1,89 @@
+"""End-to-end: reconstruct_fullfield (HDF5 in, TIFF out, Adam loop on the GPU) against an oracle-driven loop with
+the same schedule.  Adam's update is sign-like in its first steps (m_hat/sqrt(v_hat) = +-1), so voxels whose
+gradient lies within float32 noise of zero may move by up to 2*lr differently; the comparison therefore bounds the
+fraction of such voxels and the L2 distance, and checks the loss, instead of asking for 1e-5 per voxel."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bdof_oracle as orc
+
+
+def _phantom(n, rng):
+    z, y, x = np.mgrid[:n, :n, :n]
+    d = np.zeros((n, n, n))
+    for _ in range(6):
+        c = rng.uniform(n * 0.3, n * 0.7, size=3)
+        r = rng.uniform(n * 0.08, n * 0.2)
+        d += 1e-6 * np.exp(-((z - c[0]) ** 2 + (y - c[1]) ** 2 + (x - c[2]) ** 2) / (2 * r ** 2))
+    return d, 0.1 * d
+
+
+def test_reconstruct_fullfield_end_to_end(tmp_path, monkeypatch):
+    import __graft_entry__ as entry
+    entry.build()
+    from beyond_dof_amd import h5io, tiffio
+    from beyond_dof_amd.comm import minibatch_schedule
+    from beyond_dof_amd.fullfield import reconstruct_fullfield
+    monkeypatch.chdir(tmp_path)                                  # rotation tables are written to the CWD like the reference
+    rng = np.random.default_rng(0)
+    n, n_theta, mb, fp = 64, 8, 4, 1e-4
+    true_d, true_b = _phantom(n, rng)
+    coords = orc.rotation_lookup([n, n, n], n_theta)
+    one, zero = np.ones((n, n)), np.zeros((n, n))
+    rot = np.stack([orc.apply_rotation(np.stack([true_d, true_b], axis=3), c) for c in coords])
+    prj, _ = orc.multislice_propagate_batch_numpy(rot[..., 0], rot[..., 1], one, zero, 5000., 1e-7, fp, rot[..., 0].shape,
+                                                  return_probe_array=False)
+    prj = prj.astype(np.complex64)
+    os.makedirs('case')
+    h5io.write_dataset('case/data.h5', 'exchange/data', prj)
+    mask = np.ones((n, n, n), dtype=np.float32)
+    mask[:4] = 0
+    tiffio.write_tiff_stack(mask, 'case/fin_sup_mask/mask', dtype='float32', overwrite=True)
+    init_d = np.clip(rng.normal(8.7e-7, 1e-7, size=(n, n, n)), 0, None)
+    init_b = np.clip(rng.normal(5.1e-8, 1e-8, size=(n, n, n)), 0, None)
+    kw = dict(alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)
+    lr = 1e-7
+    d, b = reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, n_epochs=1, learning_rate=lr, minibatch_size=mb,
+                                 energy_ev=5000, psize_cm=1e-7, free_prop_cm=fp, save_path='case', output_folder='out',
+                                 initial_guess=[init_d, init_b], shrink_cycle=None, seed=7, center=32, unknown_key=1, **kw)
+    out = os.path.join('case', 'out')
+    assert os.path.exists(os.path.join(out, 'summary.txt'))
+    assert np.array_equal(tiffio.read_tiff(os.path.join(out, 'delta_ds_1.tiff')), d.astype(np.float32))
+    assert tiffio.read_tiff(os.path.join(out, 'beta_ds_1.tiff')).shape == (n, n, n)
+    assert np.all(d[:4] == 0) and np.all(d >= 0)                 # finite support + non-negativity
+
+    # oracle loop, same schedule (cnn_propagator/fullfield.py:337-362)
+    x = np.array([init_d * mask, init_b * mask])
+    sched = minibatch_schedule(n_theta, 1, mb, rng=np.random.RandomState(7))
+    m = v = None
+    losses = []
+    for i_batch, idx in enumerate(sched):
+        loss, g1, g2 = orc.fullfield_loss_and_grad(x[0], x[1], coords, idx, prj[idx], one, zero, 5000., 1e-7, free_prop_cm=fp,
+                                                   with_reg=True, **kw)
+        losses.append(loss)
+        x, m, v = orc.apply_gradient_adam(x, np.array([g1, g2]), i_batch, m, v, step_size=lr)
+        x = np.clip(x * mask, 0, None)
+    diff = np.abs(d - x[0])
+    assert np.mean(diff > 0.05 * lr) < 2e-3                      # almost every voxel took the same (sign-like) step
+    assert diff.max() <= 2.5 * lr * len(sched)
+    assert np.linalg.norm(d - x[0]) <= 2e-3 * np.linalg.norm(x[0])
+    assert np.linalg.norm(b - x[1]) <= 2e-2 * np.linalg.norm(x[1])
+
+    # a second run with more epochs lowers the data-term loss (and exercises 'auto' stop + shrink-wrap + no mask files)
+    from beyond_dof_amd.solver import FullfieldSolver
+    s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=fp, coord_ls=coords)
+    s.set_measurements(np.abs(prj))
+    s.set_volume(init_d * mask, init_b * mask)
+    l0 = s.loss_and_grad(sched[0])
+    d2, b2 = reconstruct_fullfield('data.h5', n_epochs='auto', max_nepochs=3, crit_conv_rate=1e-9, learning_rate=lr,
+                                   minibatch_size=mb, energy_ev=5000, psize_cm=1e-7, free_prop_cm=fp, save_path='case',
+                                   output_folder='out2', initial_guess=[init_d, init_b], shrink_cycle=1, seed=7,
+                                   save_intermediate=True, **kw)
+    s.set_volume(d2, b2)
+    l1 = s.loss_and_grad(sched[0])
+    assert l1 < l0
+    assert os.path.exists(os.path.join('case', 'out2', 'intermediate', 'current.tiff'))

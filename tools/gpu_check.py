@@ -14,12 +14,14 @@ def rel(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
 
 
-def case(B, Y, X, S, fp, variant, seed=0, dmax=2e-5, grad=True):
+def case(B, Y, X, S, fp, variant, seed=0, dmax=2e-5, grad=True, plane=False, noise=0.05):
     rng = np.random.default_rng(seed)
     delta = rng.uniform(0, dmax, size=(B, Y, X, S))
     beta = 0.1 * delta
     pr = 1 + 0.1 * rng.normal(size=(Y, X))
     pi = 0.1 * rng.normal(size=(Y, X))
+    if plane:
+        pr, pi = np.ones((Y, X)), np.zeros((Y, X))
     eng = MultisliceEngine(Y, X, S, B, with_grad=True)
     eng.set_physics(5000., 1e-7, fp, variant=variant)
     eng.set_probe(pr, pi)
@@ -31,9 +33,9 @@ def case(B, Y, X, S, fp, variant, seed=0, dmax=2e-5, grad=True):
                                                   return_probe_array=False)
     ew = rel(wave, ref)
     ei = rel(np.abs(wave) ** 2, np.abs(ref) ** 2)
-    msg = 'B{} {}x{}x{} det={} {}: wave {:.2e} intensity {:.2e}'.format(B, Y, X, S, fp, variant, ew, ei)
+    msg = ('PLANE ' if plane else '') + 'B{} {}x{}x{} det={} {}: wave {:.2e} intensity {:.2e}'.format(B, Y, X, S, fp, variant, ew, ei)
     if grad:
-        meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
+        meas = np.abs(ref) * (1 + noise * rng.normal(size=ref.shape))
         loss = eng.loss_grad(B, meas)
         gd, gb = eng.grad_batch_to_host(B)
         rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, fp, variant)
@@ -42,6 +44,11 @@ def case(B, Y, X, S, fp, variant, seed=0, dmax=2e-5, grad=True):
 
 
 if __name__ == '__main__':
+    for fp in [None, 1e-4, 'inf']:
+        for variant in ['numpy_skip_last', 'tf_all']:
+            case(2, 128, 128, 64, fp, variant, dmax=2e-6, plane=True, noise=0.0 if fp != 'inf' else 0.05)
+    case(2, 512, 512, 128, 1e-4, 'numpy_skip_last', dmax=2e-6, plane=True, noise=0.0)
+    case(2, 512, 512, 128, 1e-4, 'numpy_skip_last', dmax=2e-6, plane=False, noise=0.0)
     for (Y, X) in [(64, 64), (128, 128), (64, 256), (256, 128)]:
         for fp in [None, 1e-4, 'inf']:
             for variant in ['numpy_skip_last', 'tf_all']:
