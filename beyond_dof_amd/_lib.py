@@ -35,6 +35,7 @@ _SIGNATURES = {
     'bdof_get_loss': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double)]),
     'bdof_grot': (_vp, [_vp]),
     'bdof_rotation_adjoint': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float]),
+    'bdof_window_rotation_adjoint': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float]),
     'bdof_adam_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
                        + [ctypes.c_float] * 8 + [ctypes.c_int, ctypes.c_int]),
     'bdof_mask_shrink': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_float]),

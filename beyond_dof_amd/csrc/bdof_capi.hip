@@ -521,6 +521,24 @@ int bdof_rotation_adjoint(bdof_ctx* c, int B, const int* angle_of_b, void* gvol,
     return 0;
 }
 
+int bdof_window_rotation_adjoint(bdof_ctx* c, int B, int angle, const int* xoff, const int* yoff, void* gvol,
+                                 int accumulate, float scale) {
+    if (!c || !gvol || !xoff || !yoff) return BDOF_ERR_ARG;
+    if (!c->grot) return fail(c, BDOF_ERR_STATE, "no gradient workspace (configure with_grad=1)");
+    if (!c->adj_off || !c->obj.tab) return fail(c, BDOF_ERR_STATE, "rotation tables have not been set");
+    if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
+    if (angle < 0 || angle >= c->n_angles) return fail(c, BDOF_ERR_ARG, "angle index outside the rotation tables");
+    HIPC(c, hipSetDevice(c->device));
+    ProfScope ps(c, BDOF_K_ROT_ADJ);
+    const int n_src = c->S * c->obj.volNX;
+    WinAdjArgs a{c->grot, (float2*)gvol, c->adj_off + (size_t)angle * (c->adj_ndest + 1), c->adj_order + (size_t)angle * n_src,
+                 xoff, yoff, B, c->S, c->NX, c->NY, c->obj.volNX, c->obj.volNY, c->adj_ndest, accumulate, scale};
+    int grid = c->adj_ndest < c->ncu * 16 ? c->adj_ndest : c->ncu * 16;
+    hipLaunchKernelGGL(k_window_rot_adjoint, dim3(grid), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
 int bdof_adam_step(bdof_ctx* c, const void* x_old, void* x_new, const void* g, void* m, void* v, const float* mask,
                    int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
                    float lr, float b1, float b2, float eps, int i_batch, int clip) {

@@ -609,3 +609,46 @@ __global__ __launch_bounds__(256) void k_mask_shrink(const float2* x, float* mas
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)
         mask[idx] = x[idx].x > thresh ? mask[idx] : 0.f;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Ptychography: adjoint of "rotate, zero-pad, cut a window per probe position" (K1^T . K11^T).
+//   cnn_propagator/ptychography.py:32-34,42-73.  Destination row d of the volume gradient collects, for every rotated
+// row (z, xg) gathered from it and every window b that covers xg, the window-frame gradient row shifted by yoff[b].
+// All batch elements share one rotation angle.  Deterministic (no atomics).
+// ---------------------------------------------------------------------------------------------
+struct WinAdjArgs {
+    const float2* grot;       // [B][S][NX][NY]  window-frame gradient
+    float2* gvol;             // [n_dest][volNY]
+    const int* off;           // [n_dest + 1] of the batch's angle
+    const int* order;         // [S*volNX] source rows (z*volNX + xg) sorted by destination
+    const int* xoff;          // [B] window origin in x (may be negative / beyond the volume: zero padding)
+    const int* yoff;          // [B]
+    int B, S, NX, NY, volNX, volNY, n_dest, accumulate;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void k_window_rot_adjoint(WinAdjArgs a) {
+    for (int d = blockIdx.x; d < a.n_dest; d += gridDim.x) {
+        const int e0 = a.off[d], e1 = a.off[d + 1];
+        for (int y = threadIdx.x; y < a.volNY; y += blockDim.x) {
+            float2 acc = make_float2(0.f, 0.f);
+            for (int e = e0; e < e1; ++e) {
+                const int src = a.order[e];
+                const int z = src / a.volNX, xg = src - z * a.volNX;
+                for (int b = 0; b < a.B; ++b) {
+                    const int xw = xg - a.xoff[b];
+                    if (xw < 0 || xw >= a.NX) continue;
+                    const int yw = y - a.yoff[b];
+                    if (yw < 0 || yw >= a.NY) continue;
+                    const float2 g = a.grot[(((size_t)b * a.S + z) * a.NX + xw) * a.NY + yw];
+                    acc.x += g.x;
+                    acc.y += g.y;
+                }
+            }
+            float2* dst = a.gvol + (size_t)d * a.volNY + y;
+            float2 o = make_float2(acc.x * a.scale, acc.y * a.scale);
+            if (a.accumulate) { o.x += dst->x; o.y += dst->y; }
+            *dst = o;
+        }
+    }
+}

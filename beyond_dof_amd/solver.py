@@ -128,3 +128,92 @@ class FullfieldSolver(object):
             chunk = idx[i:i + self.mb]
             out.append(self.eng.forward(len(chunk), angle_idx=chunk))
         return np.concatenate(out, axis=0)
+
+
+class PtychoSolver(object):
+    """Device-resident state of a ptychographic reconstruction (cnn_propagator/ptychography.py:285-310): volume,
+    Adam moments, rotation tables, all diffraction amplitudes; windows are cut by index math inside the kernels."""
+
+    def __init__(self, obj_size, probe_size, probe_pos, n_theta, minibatch_size, energy_ev, psize_cm, probe_real, probe_imag,
+                 variant='numpy_skip_last', comm=None, device=0, stream=None, coord_ls=None):
+        self.dim_y, self.dim_x, self.dim_z = [int(s) for s in obj_size]
+        self.py, self.px = int(probe_size[0]), int(probe_size[1])
+        self.n_theta, self.mb = int(n_theta), int(minibatch_size)
+        self.comm = comm or PseudoComm()
+        self.probe_pos = np.asarray(probe_pos).astype(int)
+        self.half = (np.array(probe_size) / 2).astype('int')            # ptychography.py:138
+        self.eng = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream)
+        self.ctx = self.eng.ctx
+        self.eng.set_physics(energy_ev, psize_cm, 'inf', variant=variant)   # free_prop_cm='inf', ptychography.py:76
+        self.eng.set_probe(probe_real, probe_imag)
+        if coord_ls is None:
+            coord_ls = util.rotation_lookup([self.dim_y, self.dim_x, self.dim_z], n_theta)
+        tab, off, order = util.device_rotation_tables(coord_ls, self.dim_x, self.dim_z)
+        self.tab = DeviceBuffer.from_host(self.ctx, tab)
+        self.off = DeviceBuffer.from_host(self.ctx, off)
+        self.order = DeviceBuffer.from_host(self.ctx, order)
+        shape = (self.dim_x, self.dim_z, self.dim_y, 2)
+        self.x = [DeviceBuffer.zeros(self.ctx, shape, np.float32), DeviceBuffer.zeros(self.ctx, shape, np.float32)]
+        self.cur = 0
+        self.g = DeviceBuffer.zeros(self.ctx, shape, np.float32)
+        self.m = DeviceBuffer.zeros(self.ctx, shape, np.float32)
+        self.v = DeviceBuffer.zeros(self.ctx, shape, np.float32)
+        self.meas_stage = DeviceBuffer(self.ctx, self.mb * self.py * self.px * 4, np.float32, (self.mb, self.py, self.px))
+        self.idx_buf = DeviceBuffer(self.ctx, 3 * self.mb * 4, np.int32, (3, self.mb))
+        self._bind_volume()
+        self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
+
+    def _bind_volume(self):
+        self.eng.set_volume(self.x[self.cur], self.dim_y, self.tab, self.dim_x, self.n_theta)
+
+    def set_volume(self, obj_delta, obj_beta):
+        self.x[self.cur].upload(util.volume_to_rows(obj_delta, obj_beta))
+
+    def get_volume(self):
+        self.ctx.sync()
+        return util.rows_to_volume(self.x[self.cur].download())
+
+    def reset_moments(self):
+        lib, h = self.ctx.lib, self.ctx.handle
+        self.ctx.check(lib.bdof_memset(h, self.m.ptr, 0, self.m.nbytes))
+        self.ctx.check(lib.bdof_memset(h, self.v.ptr, 0, self.v.nbytes))
+
+    def _stage(self, i_theta, pos_idx, prj_abs_batch):
+        pos = self.probe_pos[np.asarray(pos_idx)]
+        idx = np.empty((3, self.mb), dtype=np.int32)
+        idx[0] = i_theta
+        idx[1] = pos[:, 1] - self.half[1]            # window origin in x (axis 1), ptychography.py:68-70
+        idx[2] = pos[:, 0] - self.half[0]            # window origin in y (axis 0)
+        self.idx_buf.upload(idx)
+        self.meas_stage.upload(self.eng.meas_layout(prj_abs_batch))
+        p = self.idx_buf.ptr
+        return p, p + 4 * self.mb, p + 8 * self.mb
+
+    def loss_and_grad(self, i_theta, pos_idx, prj_abs_batch, want_loss=True):
+        """prj_abs_batch: |this_prj_batch| (mb, py, px) for probe positions pos_idx at angle i_theta."""
+        import ctypes
+        lib, h = self.ctx.lib, self.ctx.handle
+        a, xo, yo = self._stage(i_theta, pos_idx, prj_abs_batch)
+        self.ctx.check(lib.bdof_loss_grad(h, self.mb, a, xo, yo, self.meas_stage.ptr, None))
+        self.ctx.check(lib.bdof_window_rotation_adjoint(h, self.mb, int(i_theta), xo, yo, self.g.ptr, 0, 1.0))
+        if want_loss:
+            loss = ctypes.c_double(0)
+            self.ctx.check(lib.bdof_get_loss(h, ctypes.byref(loss)))
+            return loss.value
+        return None
+
+    def forward(self, i_theta, pos_idx):
+        pos = self.probe_pos[np.asarray(pos_idx)]
+        return self.eng.forward(len(pos), angle_idx=[i_theta] * len(pos), xoff=pos[:, 1] - self.half[1],
+                                yoff=pos[:, 0] - self.half[0])
+
+    def adam_update(self, i_batch, learning_rate, clip=True):
+        new = 1 - self.cur
+        self.eng.adam_step(self.x[self.cur], self.x[new], self.g, self.m, self.v, None, (self.dim_x, self.dim_z, self.dim_y),
+                           i_batch, learning_rate, g_scale=1.0 / self.comm.size, clip=clip)
+        self.cur = new
+        self._bind_volume()
+
+    def gradient_to_host(self):
+        self.ctx.sync()
+        return util.rows_to_volume(self.g.download())

@@ -91,6 +91,11 @@ void* bdof_grot(bdof_ctx* ctx);      /* device [B][S][NX][NY] pairs */
  * from dest.  gvol: device [n_dest][NY] pairs. */
 int bdof_rotation_adjoint(bdof_ctx* ctx, int B, const int* angle_of_b, void* gvol, int accumulate, float scale);
 
+/* Ptychography: adjoint of rotate + zero-pad + per-position window (cnn_propagator/ptychography.py:32-34,42-73) for a
+ * batch whose elements all use rotation angle `angle` and windows at (xoff[b], yoff[b]); gvol: device [n_dest][volNY] pairs. */
+int bdof_window_rotation_adjoint(bdof_ctx* ctx, int B, int angle, const int* xoff, const int* yoff, void* gvol,
+                                 int accumulate, float scale);
+
 /* Fused regulariser gradient + Adam + mask + clip on a volume [NXv][NZv][NYv] of pairs.
  * Replaces cnn_propagator/fullfield.py:109-118 (gradient of the L1 + TV terms), apply_gradient_adam
  * (cnn_propagator/util.py:280-291) and the constraints of fullfield.py:359-362.  g is the data-term
