@@ -27,6 +27,9 @@ class PseudoComm(object):
     def bcast_host(self, arr, root=0):
         return arr
 
+    def close(self):
+        pass
+
 
 class TorchComm(object):
     """torch.distributed group.  Device buffers are all-reduced in place through RCCL."""
@@ -40,14 +43,24 @@ class TorchComm(object):
             if backend is None:
                 backend = 'nccl' if torch.cuda.is_available() else 'gloo'
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            dist.init_process_group(backend=backend)
+            if backend == 'nccl':
+                dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+                torch.cuda.set_device(dev)
+                dist.init_process_group(backend=backend, device_id=dev)
+            else:
+                dist.init_process_group(backend=backend)
         self.size = dist.get_world_size()
         self.rank = dist.get_rank()
         self.local_rank = int(os.environ.get('LOCAL_RANK', self.rank))
         self.backend = dist.get_backend()
+        self.always_reduce = bool(os.environ.get('BDOF_FORCE_TORCH_COMM'))   # run the collective even with one rank (tests)
 
     def Barrier(self):
         self.dist.barrier()
+
+    def close(self):
+        if self.dist.is_initialized():
+            self.dist.destroy_process_group()
 
     def as_tensor(self, buf):
         """Zero-copy torch view of a DeviceBuffer (or pass a tensor through)."""

@@ -37,6 +37,8 @@ struct bdof_ctx {
     int adj_ndest = 0;
     // profiling
     bool prof = false;
+    int prof_stride = 1;                        // time every prof_stride-th launch of a class
+    unsigned prof_seen[BDOF_K_COUNT] = {0};
     std::vector<hipEvent_t> ev_pool;
     std::vector<std::pair<int, int>> ev_used;   // (class, index of start event)
     size_t ev_next = 0;
@@ -85,6 +87,7 @@ struct ProfScope {
     bool on;
     size_t idx = 0;
     ProfScope(bdof_ctx* c_, int cls_) : c(c_), cls(cls_), on(c_->prof) {
+        if (on && c->prof_stride > 1 && cls <= BDOF_K_ROW_BWD) on = (c->prof_seen[cls]++ % (unsigned)c->prof_stride) == 0;
         if (!on) return;
         if (c->ev_next + 2 > c->ev_pool.size()) {
             size_t old = c->ev_pool.size();
@@ -573,8 +576,9 @@ int bdof_profile_enable(bdof_ctx* c, int enable) {
     if (!c) return BDOF_ERR_ARG;
     HIPC(c, hipStreamSynchronize(c->stream));
     prof_collect(c);
-    if (enable) { for (int i = 0; i < BDOF_K_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; } }
+    if (enable) { for (int i = 0; i < BDOF_K_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; c->prof_seen[i] = 0; } }
     c->prof = enable != 0;
+    c->prof_stride = enable > 1 ? enable : 1;
     return 0;
 }
 

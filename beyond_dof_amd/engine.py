@@ -162,8 +162,8 @@ class MultisliceEngine(object):
                                                lr, b1, b2, eps, int(i_batch), int(clip)))
 
     # ---- profiling -----------------------------------------------------------------------------
-    def profile_enable(self, on=True):
-        self.ctx.check(self.lib.bdof_profile_enable(self.h, int(on)))
+    def profile_enable(self, on=True, stride=1):
+        self.ctx.check(self.lib.bdof_profile_enable(self.h, int(stride) if on else 0))
 
     def profile_read(self):
         res = {}

@@ -106,7 +106,7 @@ class FullfieldSolver(object):
     def step(self, i_batch, angle_idx, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, want_loss=False):
         """grads = loss_grad(...); Allreduce; /size; Adam; mask; clip   (fullfield.py:345-362)."""
         loss = self.loss_and_grad(angle_idx, want_loss=want_loss)
-        if self.comm.size > 1:
+        if self.comm.size > 1 or getattr(self.comm, 'always_reduce', False):
             self.comm.allreduce_sum_device(self.g, stream_sync=self.ctx.sync)
         self.adam_update(i_batch, learning_rate, alpha_d, alpha_b, gamma)
         return loss

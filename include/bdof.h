@@ -107,7 +107,8 @@ int bdof_adam_step(bdof_ctx* ctx, const void* x_old, void* x_new, const void* g,
 /* Shrink-wrap (cnn_propagator/fullfield.py:365-368): mask[i] *= (delta[i] > thresh) over n voxels. */
 int bdof_mask_shrink(bdof_ctx* ctx, const void* x, float* mask, size_t n, float thresh);
 
-/* Per-kernel-class timing with HIP events on the ctx stream (bench.py roofline leg). */
+/* Per-kernel-class timing with HIP events on the ctx stream (bench.py roofline leg).  enable = 0 off, 1 every launch,
+ * n > 1 every n-th launch of the per-slice kernel classes (two event records per launch cost ~9 us of stream time). */
 int bdof_profile_enable(bdof_ctx* ctx, int enable);
 int bdof_profile_read(bdof_ctx* ctx, int kernel_class, int* n_launches, double* total_ms);
 

@@ -7,6 +7,7 @@
 #include <vector>
 #include <algorithm>
 #include "../beyond_dof_amd/csrc/bdof_kernels.h"
+#include "kvariants.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -73,6 +74,14 @@ int main(int argc, char** argv) {
             RowPropArgs a{in, out, h, B, N, 1.f, 0, tw};
             float ms = time_it([&] { hipLaunchKernelGGL((k_row_prop<N>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters);
             printf("row_prop  %8.2f us  %7.1f GB/s (16 B/px)\n", ms * 1e3, 16 * px / ms / 1e6);
+        }
+        {
+            RowPropArgs a{in, out, h, B, N, 1.f, 0, tw};
+            float ms;
+            ms = time_it([&] { hipLaunchKernelGGL((kv_prop<N, 0>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters); printf("  prop full        %8.2f us\n", ms * 1e3);
+            ms = time_it([&] { hipLaunchKernelGGL((kv_prop<N, 1>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters); printf("  prop memory-only %8.2f us\n", ms * 1e3);
+            ms = time_it([&] { hipLaunchKernelGGL((kv_prop<N, 2>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters); printf("  prop compute-only%8.2f us\n", ms * 1e3);
+            ms = time_it([&] { hipLaunchKernelGGL((kv_prop<N, 3>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters); printf("  prop plain-store %8.2f us\n", ms * 1e3);
         }
         {
             RowBwdArgs a{in, tape, probe, out, grot, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};
