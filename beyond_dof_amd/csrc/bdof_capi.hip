@@ -35,6 +35,7 @@ struct bdof_ctx {
     int n_angles = 0;
     const int *adj_off = nullptr, *adj_order = nullptr;
     int adj_ndest = 0;
+    int* heavy = nullptr;                       // [1 + n_dest]: counter + deferred rows of the rotation adjoint
     // profiling
     bool prof = false;
     int prof_stride = 1;                        // time every prof_stride-th launch of a class
@@ -286,6 +287,7 @@ void bdof_ctx_destroy(bdof_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_workspace(c);
+    if (c->heavy) (void)hipFree(c->heavy);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -401,6 +403,10 @@ int bdof_set_object(bdof_ctx* c, const void* vol, int volNY, const int* tab, int
 int bdof_set_rotation_adjoint(bdof_ctx* c, const int* off, const int* order, int n_dest) {
     if (!c || !off || !order || n_dest < 1) return BDOF_ERR_ARG;
     c->adj_off = off; c->adj_order = order; c->adj_ndest = n_dest;
+    HIPC(c, hipSetDevice(c->device));
+    if (c->heavy) (void)hipFree(c->heavy);
+    c->heavy = nullptr;
+    HIPC(c, hipMalloc((void**)&c->heavy, sizeof(int) * ((size_t)n_dest + 1)));
     return 0;
 }
 
@@ -516,10 +522,13 @@ int bdof_rotation_adjoint(bdof_ctx* c, int B, const int* angle_of_b, void* gvol,
     if (c->NY % 2) return fail(c, BDOF_ERR_SIZE, "NY must be even");
     HIPC(c, hipSetDevice(c->device));
     ProfScope ps(c, BDOF_K_ROT_ADJ);
-    RotAdjArgs a{c->grot, (float2*)gvol, c->adj_off, c->adj_order, angle_of_b, B, c->S * c->NX, c->adj_ndest, c->NY, accumulate, scale};
-    int grid = c->adj_ndest < c->ncu * 16 ? c->adj_ndest : c->ncu * 16;
-    if (B > 256) return fail(c, BDOF_ERR_ARG, "rotation adjoint handles at most 256 batch elements per call");
+    RotAdjArgs a{c->grot, (float2*)gvol, c->adj_off, c->adj_order, angle_of_b, B, c->S * c->NX, c->adj_ndest, c->NY, accumulate, scale,
+                 c->heavy, c->heavy + 1};
+    HIPC(c, hipMemsetAsync(c->heavy, 0, sizeof(int), c->stream));
+    int need = (c->adj_ndest + 3) / 4;
+    int grid = need < c->ncu * 8 ? need : c->ncu * 8;
     hipLaunchKernelGGL(k_rot_adjoint, dim3(grid), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_rot_adjoint_heavy, dim3(c->ncu * 8), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;
 }

@@ -462,87 +462,134 @@ struct RotAdjArgs {
     const int* angle_of_b;    // [B]
     int B, n_src, n_dest, NY, accumulate;
     float scale;
+    int* heavy_count;         // device counter (zeroed before the launch)
+    int* heavy_rows;          // [n_dest] destination rows whose source list does not fit a wave's LDS list
 };
 
-#define BDOF_ROTADJ_MAXLIST 1024
+#define BDOF_ROTADJ_MAXLIST 256      // per wave; longer lists (clamped border rows) take the direct path
 
+__device__ __forceinline__ void f4acc(float4& a, const float4 s) { a.x += s.x; a.y += s.y; a.z += s.z; a.w += s.w; }
+
+// One WAVE per destination row (4 rows per workgroup, no workgroup barrier): lane b looks up batch element b's CSR
+// range, a wave scan places the (batch, source-row) pairs into the wave's LDS list in a fixed order, then the 64 lanes
+// stream the listed 4-KB rows with 16-byte loads, several rows in flight.
 __global__ __launch_bounds__(256) void k_rot_adjoint(RotAdjArgs a) {
-    __shared__ int list[BDOF_ROTADJ_MAXLIST];   // global row index into grot (b*n_src + src)
-    __shared__ int count;
+    __shared__ int lists[4][BDOF_ROTADJ_MAXLIST];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int* list = lists[wave];
     const int nv = a.NY / 2;                    // float4 = two (delta,beta) pairs
-    for (int d = blockIdx.x; d < a.n_dest; d += gridDim.x) {
-        if (threadIdx.x == 0) count = 0;
-        __syncthreads();
-        // deterministic list order: batch-major, then CSR order -> prefix positions via a serial scan
-        // over the (few) batch elements by thread 0 would serialise; instead every b writes into its
-        // own slot range computed from per-b counts.
-        __shared__ int cnt[256];
-        int e0 = 0, e1 = 0;
-        if (threadIdx.x < a.B) {
-            const int ang = a.angle_of_b[threadIdx.x];
-            const int* off = a.off + (size_t)ang * (a.n_dest + 1);
-            e0 = off[d];
-            e1 = off[d + 1];
-        }
-        cnt[threadIdx.x] = e1 - e0;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int run = 0;
-            for (int b = 0; b < a.B; ++b) { const int c = cnt[b]; cnt[b] = run; run += c; }
-            count = run;
-        }
-        __syncthreads();
-        const int total = count;
-        if (total <= BDOF_ROTADJ_MAXLIST) {
-            if (threadIdx.x < a.B) {
-                const int ang = a.angle_of_b[threadIdx.x];
-                const int* order = a.order + (size_t)ang * a.n_src;
-                int pos = cnt[threadIdx.x];
-                for (int e = e0; e < e1; ++e) list[pos++] = threadIdx.x * a.n_src + order[e];
+    for (int d = blockIdx.x * 4 + wave; d < a.n_dest; d += gridDim.x * 4) {
+        int total = 0;
+        for (int b0 = 0; b0 < a.B; b0 += 64) {
+            const int b = b0 + lane;
+            int e0 = 0, cnt = 0;
+            const int* order = a.order;
+            if (b < a.B) {
+                const int ang = a.angle_of_b[b];
+                const int* off = a.off + (size_t)ang * (a.n_dest + 1);
+                e0 = off[d];
+                cnt = off[d + 1] - e0;
+                order = a.order + (size_t)ang * a.n_src;
             }
-            __syncthreads();
-            for (int v = threadIdx.x; v < nv; v += blockDim.x) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                int e = 0;
-                for (; e + 4 <= total; e += 4) {
-                    const float4 s0 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e] * a.NY)[v];
-                    const float4 s1 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e + 1] * a.NY)[v];
-                    const float4 s2 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e + 2] * a.NY)[v];
-                    const float4 s3 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e + 3] * a.NY)[v];
-                    acc.x += s0.x; acc.y += s0.y; acc.z += s0.z; acc.w += s0.w;
-                    acc.x += s1.x; acc.y += s1.y; acc.z += s1.z; acc.w += s1.w;
-                    acc.x += s2.x; acc.y += s2.y; acc.z += s2.z; acc.w += s2.w;
-                    acc.x += s3.x; acc.y += s3.y; acc.z += s3.z; acc.w += s3.w;
-                }
-                for (; e < total; ++e) {
-                    const float4 s = reinterpret_cast<const float4*>(a.grot + (size_t)list[e] * a.NY)[v];
-                    acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
-                }
-                float4* dst = reinterpret_cast<float4*>(a.gvol + (size_t)d * a.NY) + v;
-                float4 o = make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
-                if (a.accumulate) { const float4 q = *dst; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            const int chunk_total = __shfl(incl, 63, 64);
+            if (total + chunk_total <= BDOF_ROTADJ_MAXLIST) {
+                int pos = total + incl - cnt;
+                for (int e = 0; e < cnt; ++e) list[pos++] = b * a.n_src + order[e0 + e];
+            }
+            total += chunk_total;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (total > BDOF_ROTADJ_MAXLIST) {
+            // clamped border rows collect thousands of sources: one wave would become the kernel's tail.  Defer them to
+            // k_rot_adjoint_heavy, which gives each such row a whole workgroup.
+            if (lane == 0) a.heavy_rows[atomicAdd(a.heavy_count, 1)] = d;
+            continue;
+        }
+        float4* drow = reinterpret_cast<float4*>(a.gvol + (size_t)d * a.NY);
+        for (int v0 = 0; v0 < nv; v0 += 256) {
+            float4 acc[4];
+            bool ok[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { acc[c] = make_float4(0.f, 0.f, 0.f, 0.f); ok[c] = v0 + c * 64 + lane < nv; }
+            int e = 0;
+            for (; e + 2 <= total; e += 2) {
+                const float4* r0 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e] * a.NY) + v0 + lane;
+                const float4* r1 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e + 1] * a.NY) + v0 + lane;
+                float4 s0[4], s1[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (ok[c]) { s0[c] = r0[c * 64]; s1[c] = r1[c * 64]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (ok[c]) { f4acc(acc[c], s0[c]); f4acc(acc[c], s1[c]); }
+            }
+            for (; e < total; ++e) {
+                const float4* r0 = reinterpret_cast<const float4*>(a.grot + (size_t)list[e] * a.NY) + v0 + lane;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (ok[c]) f4acc(acc[c], r0[c * 64]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (!ok[c]) continue;
+                float4 o = make_float4(acc[c].x * a.scale, acc[c].y * a.scale, acc[c].z * a.scale, acc[c].w * a.scale);
+                float4* dst = drow + v0 + c * 64 + lane;
+                if (a.accumulate) f4acc(o, *dst);
                 *dst = o;
             }
-        } else {
-            // clamped border rows of large volumes can collect more sources than the LDS list holds
-            for (int v = threadIdx.x; v < nv; v += blockDim.x) {
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int b = 0; b < a.B; ++b) {
-                    const int ang = a.angle_of_b[b];
-                    const int* off = a.off + (size_t)ang * (a.n_dest + 1);
-                    const int* order = a.order + (size_t)ang * a.n_src;
-                    for (int e = off[d]; e < off[d + 1]; ++e) {
-                        const float4 s = reinterpret_cast<const float4*>(a.grot + ((size_t)b * a.n_src + order[e]) * a.NY)[v];
-                        acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// Heavy destination rows: one workgroup per row; the source indices are staged through LDS 256 at a time and all
+// threads stream the rows (16 B per lane, 4 rows in flight).  Fixed summation order -> deterministic.
+__global__ __launch_bounds__(256) void k_rot_adjoint_heavy(RotAdjArgs a) {
+    __shared__ int stage[256];
+    const int nheavy = *a.heavy_count;
+    const int nv = a.NY / 2;
+    for (int i = blockIdx.x; i < nheavy; i += gridDim.x) {
+        const int d = a.heavy_rows[i];
+        for (int v0 = 0; v0 < nv; v0 += 256) {
+            const int v = v0 + threadIdx.x;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int b = 0; b < a.B; ++b) {
+                const int ang = a.angle_of_b[b];
+                const int* off = a.off + (size_t)ang * (a.n_dest + 1);
+                const int* order = a.order + (size_t)ang * a.n_src;
+                const int e0 = off[d], e1 = off[d + 1];
+                for (int c0 = e0; c0 < e1; c0 += 256) {
+                    const int n = min(256, e1 - c0);
+                    __syncthreads();
+                    if ((int)threadIdx.x < n) stage[threadIdx.x] = b * a.n_src + order[c0 + threadIdx.x];
+                    __syncthreads();
+                    if (v < nv) {
+                        int e = 0;
+                        for (; e + 4 <= n; e += 4) {
+                            const float4 s0 = reinterpret_cast<const float4*>(a.grot + (size_t)stage[e] * a.NY)[v];
+                            const float4 s1 = reinterpret_cast<const float4*>(a.grot + (size_t)stage[e + 1] * a.NY)[v];
+                            const float4 s2 = reinterpret_cast<const float4*>(a.grot + (size_t)stage[e + 2] * a.NY)[v];
+                            const float4 s3 = reinterpret_cast<const float4*>(a.grot + (size_t)stage[e + 3] * a.NY)[v];
+                            f4acc(acc, s0); f4acc(acc, s1); f4acc(acc, s2); f4acc(acc, s3);
+                        }
+                        for (; e < n; ++e) f4acc(acc, reinterpret_cast<const float4*>(a.grot + (size_t)stage[e] * a.NY)[v]);
                     }
                 }
+            }
+            if (v < nv) {
                 float4* dst = reinterpret_cast<float4*>(a.gvol + (size_t)d * a.NY) + v;
                 float4 o = make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
-                if (a.accumulate) { const float4 q = *dst; o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w; }
+                if (a.accumulate) f4acc(o, *dst);
                 *dst = o;
             }
         }
-        __syncthreads();
     }
 }
 

@@ -186,6 +186,35 @@ def test_fullfield_fused_rotation_and_adjoint(engine_mod):
     assert rel(gd, acc_d) <= 1e-6            # summation order only
 
 
+def test_rotation_adjoint_heavy_border_rows(engine_mod):
+    """48 angles in one batch: the clamped border rows of the volume collect far more than 256 rotated rows each and
+    take the workgroup-per-row path (k_rot_adjoint_heavy); the rest take the wave-per-row path."""
+    from beyond_dof_amd.solver import FullfieldSolver
+    from beyond_dof_amd import util
+    n, n_theta = 64, 48
+    rng = np.random.default_rng(11)
+    od = rng.uniform(0, 2e-6, size=(n, n, n))
+    ob = 0.1 * od
+    coords = orc.rotation_lookup([n, n, n], n_theta)
+    _, off, _ = util.device_rotation_tables(coords, n, n)
+    assert (off[:, 1:] - off[:, :-1]).sum(axis=0).max() > 256          # the heavy path is really exercised
+    idx = np.arange(n_theta)
+    s = FullfieldSolver(n, n, n, n_theta, n_theta, 5000., 1e-7, free_prop_cm=None, coord_ls=coords)
+    s.set_volume(od, ob)
+    prj = 1 + 0.05 * rng.normal(size=(n_theta, n, n))
+    s.set_measurements(prj)
+    s.loss_and_grad(idx)
+    gd, gb = s.gradient_to_host()
+    g_dev_d, g_dev_b = s.eng.grad_batch_to_host(n_theta)               # rotated-frame gradient the adjoint consumed
+    acc_d = sum(orc.apply_rotation_adjoint(g_dev_d[b].astype(np.float64), coords[j]) for b, j in enumerate(idx))
+    acc_b = sum(orc.apply_rotation_adjoint(g_dev_b[b].astype(np.float64), coords[j]) for b, j in enumerate(idx))
+    assert rel(gd, acc_d) <= 1e-6 and rel(gb, acc_b) <= 1e-6           # index work: only the summation order differs
+    # deterministic: a second evaluation gives bit-identical results
+    s.loss_and_grad(idx)
+    gd2, gb2 = s.gradient_to_host()
+    assert np.array_equal(gd, gd2) and np.array_equal(gb, gb2)
+
+
 def test_adam_kernel_vs_oracle(engine_mod):
     """bdof_adam_step alone (identical gradients in): regulariser gradient + Adam + mask + clip."""
     from beyond_dof_amd import util
