@@ -141,9 +141,9 @@ template <int N> static int rows_grid(const bdof_ctx* c, int B, int R) {
     }
 
 // A_z: L1 (or the probe) -> L2 (tstore) or L1 (plain)
-static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore) {
+static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore, cf* phi_out = nullptr) {
     ProfScope ps(c, BDOF_K_ROW_FWD);
-    RowFwdArgs a{in, c->probe, out, c->obj, B, c->NX, z, c->k, carrier_at(c, z), c->twY};
+    RowFwdArgs a{in, c->probe, out, phi_out, c->obj, B, c->NX, z, c->k, carrier_at(c, z), c->twY};
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
@@ -166,15 +166,12 @@ static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf*
     });
 }
 
-// A'_z: L1 (g) + L1 (tape) -> L2 (g)
+// A'_z: L1 (g) + phi tape -> L2 (g)
 static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout) {
     ProfScope ps(c, BDOF_K_ROW_BWD);
-    RowBwdArgs a{gin, tape, c->probe, gout, c->grot, c->obj, B, c->NX, z, c->k, carrier_at(c, z), c->twY};
+    RowBwdArgs a{gin, tape, gout, c->grot, c->obj, B, c->NX, z, c->k, carrier_at(c, z), c->twY};
     DISPATCH_N(c->NY, {
-        const dim3 grid(rows_grid<N_>(c, B, c->NX));
-        const dim3 blk(BDOF_THREADS);
-        if (z == 0) hipLaunchKernelGGL((k_row_bwd<N_, true>), grid, blk, 0, c->stream, a);
-        else hipLaunchKernelGGL((k_row_bwd<N_, false>), grid, blk, 0, c->stream, a);
+        hipLaunchKernelGGL((k_row_bwd<N_>), dim3(rows_grid<N_>(c, B, c->NX)), dim3(BDOF_THREADS), 0, c->stream, a);
     });
 }
 
@@ -213,20 +210,24 @@ static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* ou
 //   DET_NEAR                  : bufB = d_hat (L1)    (tf_all: one step with the combined transfer function)
 //   DET_FAR                   : bufA = R phi_{S-1} in L2 order, un-normalised (|fft2| is unchanged by the
 //                               unit-modulus transfer function, so tf_all needs no extra step here)
-static void forward_sweep(bdof_ctx* c, int B, bool use_tape) {
+enum { TAPE_NONE = 0, TAPE_HISTORY = 1, TAPE_PHI = 2 };
+// TAPE_HISTORY keeps psi_hat_{z+1} (the transfer-function step's output) per slice: probe_array of np_funcs.py:43.
+// TAPE_PHI keeps the real-space phi_z written by A_z: what the adjoint needs, without a third transform in A'_z.
+static void forward_sweep(bdof_ctx* c, int B, int tape_mode) {
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
     for (int z = 0; z < c->S; ++z) {
         const cf* in = nullptr;
-        if (z > 0) in = use_tape ? c->tape + (size_t)(z - 1) * fld : c->bufB;
+        if (z > 0) in = tape_mode == TAPE_HISTORY ? c->tape + (size_t)(z - 1) * fld : c->bufB;
+        cf* phi = tape_mode == TAPE_PHI ? c->tape + (size_t)z * fld : nullptr;
         const bool last = z == c->S - 1;
         if (!last) {
-            launch_row_fwd(c, B, z, in, c->bufA, true);
-            launch_row_prop(c, B, c->bufA, use_tape ? c->tape + (size_t)z * fld : c->bufB, c->hs, 1.f, 0);
+            launch_row_fwd(c, B, z, in, c->bufA, true, phi);
+            launch_row_prop(c, B, c->bufA, tape_mode == TAPE_HISTORY ? c->tape + (size_t)z * fld : c->bufB, c->hs, 1.f, 0);
         } else if (c->det_mode == BDOF_DET_NONE && !tf_all) {
-            launch_row_fwd(c, B, z, in, c->bufA, false);
+            launch_row_fwd(c, B, z, in, c->bufA, false, phi);
         } else {
-            launch_row_fwd(c, B, z, in, c->bufA, true);
+            launch_row_fwd(c, B, z, in, c->bufA, true, phi);
             if (c->det_mode == BDOF_DET_NONE) launch_row_prop(c, B, c->bufA, c->bufB, c->hs, 1.f, 0);
             else if (c->det_mode == BDOF_DET_NEAR) launch_row_prop(c, B, c->bufA, c->bufB, tf_all ? c->hcomb : c->hdet, 1.f, 0);
         }
@@ -334,7 +335,7 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     HIPC(c, hipMalloc((void**)&c->bufA, sizeof(cf) * fld));
     HIPC(c, hipMalloc((void**)&c->bufB, sizeof(cf) * fld));
     if (c->with_grad) {
-        if (S > 1) HIPC(c, hipMalloc((void**)&c->tape, sizeof(cf) * fld * (size_t)(S - 1)));
+        HIPC(c, hipMalloc((void**)&c->tape, sizeof(cf) * fld * (size_t)S));
         HIPC(c, hipMalloc((void**)&c->grot, sizeof(float2) * fld * (size_t)S));
     }
     c->npartial = c->ncu * 2 + 64;
@@ -424,7 +425,7 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
-    forward_sweep(c, B, keep_tape != 0 && c->S > 1);
+    forward_sweep(c, B, keep_tape ? TAPE_HISTORY : TAPE_NONE);
     c->tape_valid = keep_tape != 0;
     c->last_valid = false;
     if (out_wave) {
@@ -439,7 +440,7 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
         // probe_array[S-1] = phi_{S-1} (np_funcs.py:41-43): keep R phi_{S-1} in L1 order in bufA
         if (!(c->det_mode == BDOF_DET_NONE)) {
             const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
-            const cf* in = c->S > 1 ? c->tape + (size_t)(c->S - 2) * fld : nullptr;
+            const cf* in = c->S > 1 ? c->tape + (size_t)(c->S - 2) * fld : nullptr;   // psi_hat_{S-1}
             launch_row_fwd(c, B, c->S - 1, in, c->bufA, false);
         }
         c->last_valid = true;
@@ -452,7 +453,7 @@ int bdof_tape_to_real(bdof_ctx* c, int i, int B, void* out) {
     int r = check_ready(c, B);
     if (r) return r;
     if (!out) return BDOF_ERR_ARG;
-    if (!c->tape_valid) return fail(c, BDOF_ERR_STATE, "no tape: run bdof_forward(keep_tape=1) or bdof_loss_grad first");
+    if (!c->tape_valid) return fail(c, BDOF_ERR_STATE, "no history: run bdof_forward(keep_tape=1) first");
     if (i < 0 || i >= c->S) return fail(c, BDOF_ERR_ARG, "slice index outside [0, S)");
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     if (i < c->S - 1) {
@@ -477,8 +478,8 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     const float NYf = (float)c->NY;
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
-    forward_sweep(c, B, c->S > 1);
-    c->tape_valid = true;
+    forward_sweep(c, B, TAPE_PHI);
+    c->tape_valid = false;      // the tape now holds phi_z, not the per-slice history
     c->last_valid = false;
     const float seed_scale = 2.f / ((float)B * (float)c->NX * (float)c->NY);
     int npart = 0;
@@ -497,8 +498,7 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
                        1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
     // backward sweep: A'_z (L1 -> L2), then the adjoint transfer-function step (L2 -> L1)
     for (int z = c->S - 1; z >= 0; --z) {
-        const cf* tape = z > 0 ? c->tape + (size_t)(z - 1) * fld : nullptr;
-        launch_row_bwd(c, B, z, c->bufB, tape, z > 0 ? c->bufA : nullptr);
+        launch_row_bwd(c, B, z, c->bufB, c->tape + (size_t)z * fld, z > 0 ? c->bufA : nullptr);
         if (z > 0) launch_row_prop(c, B, c->bufA, c->bufB, c->hs, 1.f, 1);
     }
     HIPC(c, hipGetLastError());

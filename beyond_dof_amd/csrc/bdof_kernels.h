@@ -152,6 +152,7 @@ struct RowFwdArgs {
     const cf* in;      // L1 psi_hat_i [B][NX][NY]; ignored when FIRST (probe used)
     const cf* probe;   // [NX][NY] real-space probe
     cf* out;           // TSTORE: L2 [B][NY][NX] = R phi_i ; else L1 [B][NX][NY]
+    cf* phi_out;       // nullable: tape of the real-space scattered part of phi_i, [B][NX][NY] (read back by A'_i)
     ObjView obj;
     int B, NX, z;
     float k;
@@ -186,6 +187,11 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
             if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
 #pragma unroll
             for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], a.carrier, slice_modulation_m1(db[m], a.k));
+            if (a.phi_out) {
+                cf* pdst = a.phi_out + (size_t)(row0 + r) * NY;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) pdst[tid + m * C::T] = u[m];
+            }
             if constexpr (TSTORE) {
                 line_fft_partial<NY, -1>(u, tw, tid, lds);
             } else {
@@ -381,23 +387,22 @@ __global__ void k_sum_partials(const double* partial, int n, double scale, doubl
 
 // ---------------------------------------------------------------------------------------------
 // A': backward row kernel (hand-derived adjoint of A):
-//   G(phi) = R^-1' g_hat ; psi = R^-1' tape ; phi = c psi ; t = conj(phi) G(phi)
+//   G(phi) = R^-1' g_hat ; phi = a_z + tape (written by A_z) ; t = conj(phi) G(phi)
 //   g_delta = k Im t ; g_beta = -k Re t ; G(psi) = conj(c) G(phi) ; out = R G(psi)
 // ---------------------------------------------------------------------------------------------
 struct RowBwdArgs {
     const cf* gin;     // L1 g_hat(phi_i) [B][NX][NY]
-    const cf* tape;    // L1 psi_hat_i; ignored when FIRST (probe)
-    const cf* probe;
+    const cf* tape;    // real-space scattered part of phi_i, [B][NX][NY]
     cf* gout;          // nullable: L2 R G(psi_i)
     float2* grot;      // [B][S][NX][NY] (g_delta, g_beta) in the rotated / windowed frame
     ObjView obj;
     int B, NX, z;
     float k;
-    cf carrier;        // a_z
+    cf carrier;        // constant part of phi_z (= a_z: the modulation moves no weight into it)
     const cf* twiddle;
 };
 
-template <int NY, bool FIRST>
+template <int NY>
 __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd(RowBwdArgs a) {
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
@@ -418,24 +423,19 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
             const size_t off = (size_t)(row0 + r) * NY;
             cf g[8], p[8];
             float2 db[8];
-            const cf* psrc = FIRST ? a.probe + (size_t)x * NY : a.tape + off;
 #pragma unroll
             for (int m = 0; m < 8; ++m) g[m] = a.gin[off + tid + m * C::T];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) p[m] = psrc[tid + m * C::T];
+            for (int m = 0; m < 8; ++m) p[m] = a.tape[off + tid + m * C::T];
             load_obj_row(a.obj, obj_src_row(a.obj, b, x, a.z, a.NX), y0, tid, C::T, db);
             line_fft<NY, +1>(g, tw, tid, lds);
-            if constexpr (!FIRST) line_fft<NY, +1>(p, tw, tid, lds);
             float2* gdst = a.grot + (((size_t)b * a.obj.S + a.z) * a.NX + x) * NY;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                // here c multiplies full-size fields, so the plain form is accurate enough (the cancellation-free
-                // c - 1 only matters where it generates the scattered field, in the forward kernel)
-                const cf c = slice_modulation(db[m], a.k);
-                const cf phi = cmul(cadd(p[m], a.carrier), c);       // c psi,  psi = a_z + eps
+                const cf phi = cadd(p[m], a.carrier);
                 const cf t = cmulc(g[m], phi);                       // G * conj(phi)
                 gdst[tid + m * C::T] = make_float2(a.k * t.y, -a.k * t.x);
-                g[m] = cmulc(g[m], c);                               // conj(c) G
+                g[m] = cmulc(g[m], slice_modulation(db[m], a.k));    // conj(c) G
             }
             if (a.gout) line_fft_partial<NY, -1>(g, tw, tid, lds);
         }

@@ -39,7 +39,7 @@ int bdof_sync(bdof_ctx* ctx);
 int bdof_device_count(void);
 
 /* Workspace for wavefields of NY x NX (powers of two, 64..1024), S slices, up to Bmax wavefields per
- * launch.  with_grad != 0 also allocates the tape (S-1 hybrid fields per wavefield) and the
+ * launch.  with_grad != 0 also allocates the tape (S fields per wavefield) and the
  * rotated-frame gradient.  Replaces the per-call allocations of multislice_propagate_batch_numpy
  * (cnn_propagator/np_funcs.py:20,43) and of autograd's tape (cnn_propagator/fullfield.py:329). */
 int bdof_configure(bdof_ctx* ctx, int NY, int NX, int S, int Bmax, int with_grad);
@@ -75,7 +75,7 @@ int bdof_set_rotation_adjoint(bdof_ctx* ctx, const int* off, const int* order, i
 int bdof_forward(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave, int keep_tape);
 
 /* probe_array[i] of np_funcs.py:43 (wave after slice i), device out [B][NX][NY]; valid after a
- * bdof_forward(keep_tape=1) or bdof_loss_grad. */
+ * bdof_forward(keep_tape=1) (bdof_loss_grad reuses the tape for its own purposes and invalidates it). */
 int bdof_tape_to_real(bdof_ctx* ctx, int i, int B, void* out);
 
 /* Loss + gradient: replaces loss_grad = autograd.grad(calculate_loss,[0,1]) for the multislice part

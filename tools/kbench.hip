@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
         const int grid = balanced(tiles, ncu * per_cu);
         printf("-- %d WG/CU cap, grid %d (tiles %d)\n", per_cu, grid, tiles);
         {
-            RowFwdArgs a{in, probe, out, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};
+            RowFwdArgs a{in, probe, out, tape, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};
             float ms = time_it([&] { hipLaunchKernelGGL((k_row_fwd<N, false, true>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters);
             printf("row_fwd   %8.2f us  %7.1f GB/s (24 B/px)\n", ms * 1e3, 24 * px / ms / 1e6);
         }
@@ -84,8 +84,8 @@ int main(int argc, char** argv) {
             ms = time_it([&] { hipLaunchKernelGGL((kv_prop<N, 3>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters); printf("  prop plain-store %8.2f us\n", ms * 1e3);
         }
         {
-            RowBwdArgs a{in, tape, probe, out, grot, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};
-            float ms = time_it([&] { hipLaunchKernelGGL((k_row_bwd<N, false>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters);
+            RowBwdArgs a{in, tape, out, grot, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};
+            float ms = time_it([&] { hipLaunchKernelGGL((k_row_bwd<N>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters);
             printf("row_bwd   %8.2f us  %7.1f GB/s (40 B/px)\n", ms * 1e3, 40 * px / ms / 1e6);
         }
     }
