@@ -23,6 +23,19 @@ sys.path.insert(0, ROOT)
 # algorithmic bytes per pixel per launch (they sum to SURVEY §8(d)'s 104 B per slice-step)
 BYTES_PER_PX = {'row_fwd': 24.0, 'col_prop': 16.0, 'row_bwd': 40.0, 'rot_adjoint': 8.0}
 HBM_PEAK = 8.0e12
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_summary.py applies the gfx950
+# corrections); a process cannot collect them on itself, so the committed summary is read back here
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_bench.json')
+PMC_KERNEL = {'row_fwd': 'k_row_fwd<512, false, true>', 'col_prop': 'k_row_prop<512>', 'row_bwd': 'k_row_bwd<512>',
+              'rot_adjoint': 'k_rot_adjoint'}
+
+
+def pmc_traffic(kernel_class, n, mb):
+    """Measured L2<->fabric bytes per launch of the class's kernel (512^3, 25 angles only), or None."""
+    if (n, mb) != (512, 25) or not os.path.exists(PMC_SUMMARY):
+        return None
+    k = json.load(open(PMC_SUMMARY))['kernels'].get(PMC_KERNEL[kernel_class])
+    return k['total_bytes_per_launch'] if k else None
 
 
 def make_phantom(n, seed=3):
@@ -137,8 +150,13 @@ def main():
             launches_per_step = {'row_fwd': S, 'col_prop': 2 * S, 'row_bwd': S, 'rot_adjoint': 1}
             dom = max(per_class, key=lambda k: per_class[k]['avg_ms'] * launches_per_step[k])
             ach = per_class[dom]['GBps']
+            tb = pmc_traffic(dom, n, mb)
             roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                    'frac': ach * 1e9 / HBM_PEAK, 'traffic': None, 'per_kernel': per_class,
+                    'frac': ach * 1e9 / HBM_PEAK,
+                    'traffic': None if tb is None else tb / (per_class[dom]['avg_ms'] * 1e-3) / 1e9,
+                    'traffic_bytes_per_launch': tb, 'algorithmic_bytes_per_launch': BYTES_PER_PX[dom] * px * (S if dom == 'rot_adjoint' else 1),
+                    'traffic_source': 'profiles/r01_pmc_traffic_bench.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE x1)' if tb else None,
+                    'per_kernel': per_class,
                     'whole_step_frac': 104.0 * n * n * (slice_steps / world) / elapsed / HBM_PEAK}
         out = {'metric': 'multislice fwd+adjoint slice-steps/s (full Adam iteration: rotation, forward, loss, adjoint, '
                          'gradient all-reduce, regulariser+Adam)',

@@ -25,6 +25,14 @@ template <class F> static float time_it(F f, int iters) {
     return ms / iters;
 }
 
+// calibration kernels for the PMC byte counters: known traffic with this library's access widths
+__global__ void k_calib_copy8(const float2* in, float2* out, size_t n) {       // 8 B per lane, like the row loads/stores
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+__global__ void k_calib_copy16(const float4* in, float4* out, size_t n) {      // 16 B per lane
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
 static int balanced(int tiles, int cap) { if (tiles <= cap) return tiles; int r = (tiles + cap - 1) / cap; return (tiles + r - 1) / r; }
 
 int main(int argc, char** argv) {
@@ -61,6 +69,17 @@ int main(int argc, char** argv) {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int ncu = prop.multiProcessorCount;
     const double px = (double)B * N * N;
+    {   // 2 x 1 GiB buffers: far beyond the 256 MiB Infinity Cache
+        const size_t nb = (size_t)1 << 30;
+        float2 *ca, *cb;
+        CK(hipMalloc(&ca, nb)); CK(hipMalloc(&cb, nb));
+        CK(hipMemset(ca, 1, nb));
+        float ms = time_it([&] { hipLaunchKernelGGL(k_calib_copy8, dim3(ncu * 8), dim3(256), 0, 0, ca, cb, nb / 8); }, 3);
+        printf("calib copy8  1 GiB read + 1 GiB write: %8.2f us  %7.1f GB/s\n", ms * 1e3, 2.0 * nb / ms / 1e6);
+        ms = time_it([&] { hipLaunchKernelGGL(k_calib_copy16, dim3(ncu * 8), dim3(256), 0, 0, (const float4*)ca, (float4*)cb, nb / 16); }, 3);
+        printf("calib copy16 1 GiB read + 1 GiB write: %8.2f us  %7.1f GB/s\n", ms * 1e3, 2.0 * nb / ms / 1e6);
+        CK(hipFree(ca)); CK(hipFree(cb));
+    }
     const int tiles = B * N / RowCfg<N>::TILE;
     for (int per_cu : {1, 2}) {
         const int grid = balanced(tiles, ncu * per_cu);

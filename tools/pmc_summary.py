@@ -1,0 +1,37 @@
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into bytes per launch per kernel, applying the gfx950
+corrections of MI355X_MICROARCH.md §HBM: FETCH_SIZE (KB) counts half of the bytes of coalesced streaming reads ->
+x2 (re-checked here on known-size copy kernels, tools/kbench.hip k_calib_copy8/16: 1 GiB read reports 512 MiB);
+WRITE_SIZE (KB) is exact.   usage: pmc_summary.py FETCH.csv WRITE.csv out.json"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        acc[r['Kernel_Name']].append(float(r['Counter_Value']))
+    return acc
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+    out = {}
+    for name in fetch:
+        if 'rocclr' in name:
+            continue
+        f, w = fetch[name], write.get(name, [0.0])
+        short = name.split('(')[0].replace('void ', '')
+        out[short] = {'dispatches': len(f), 'read_bytes_per_launch': 2.0 * 1024 * sum(f) / len(f),
+                      'write_bytes_per_launch': 1024 * sum(w) / len(w)}
+        out[short]['total_bytes_per_launch'] = out[short]['read_bytes_per_launch'] + out[short]['write_bytes_per_launch']
+    json.dump({'corrections': {'FETCH_SIZE': 'KB x 1024 x 2', 'WRITE_SIZE': 'KB x 1024'}, 'kernels': out},
+              open(sys.argv[3], 'w'), indent=1, sort_keys=True)
+    for k, v in sorted(out.items()):
+        print('{:<45} n={:<5} read {:8.1f} MB  write {:8.1f} MB'.format(k, v['dispatches'], v['read_bytes_per_launch'] / 1e6,
+                                                                     v['write_bytes_per_launch'] / 1e6))
+
+
+if __name__ == '__main__':
+    main()
