@@ -32,6 +32,11 @@ struct bdof_ctx {
     int det_mode = BDOF_DET_NONE, variant = BDOF_VARIANT_NUMPY_SKIP_LAST;
     bool have_physics = false, have_probe = false, tape_valid = false, last_valid = false;
     ObjView obj{};
+    const float2* obj_src = nullptr;            // caller's (delta, beta) rows
+    size_t obj_rows = 0;
+    float2* mod = nullptr;                      // c - 1 table of those rows (k_modulation_table)
+    size_t mod_cap = 0;
+    bool mod_dirty = true;
     int n_angles = 0;
     const int *adj_off = nullptr, *adj_order = nullptr;
     int adj_ndest = 0;
@@ -234,12 +239,31 @@ static void forward_sweep(bdof_ctx* c, int B, int tape_mode) {
     }
 }
 
+// (Re)build the modulation table c - 1 = exp(i k delta - k beta) - 1 of the object rows when the object or k changed.
+static int ensure_modulation(bdof_ctx* c) {
+    if (!c->mod_dirty) return 0;
+    const size_t n = c->obj_rows * (size_t)c->obj.volNY;
+    if (n > c->mod_cap) {
+        if (c->mod) (void)hipFree(c->mod);
+        c->mod = nullptr; c->mod_cap = 0;
+        HIPC(c, hipMalloc((void**)&c->mod, sizeof(float2) * n));
+        c->mod_cap = n;
+    }
+    size_t need = (n + 255) / 256;
+    int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
+    hipLaunchKernelGGL(k_modulation_table, dim3(grid), dim3(256), 0, c->stream, c->obj_src, c->mod, n, c->k);
+    HIPC(c, hipGetLastError());
+    c->obj.vol = c->mod;
+    c->mod_dirty = false;
+    return 0;
+}
+
 static int check_ready(bdof_ctx* c, int B) {
     if (!c) return BDOF_ERR_ARG;
     if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
     if (!c->have_physics) return fail(c, BDOF_ERR_STATE, "bdof_set_physics has not been called");
     if (!c->have_probe) return fail(c, BDOF_ERR_STATE, "bdof_set_probe has not been called");
-    if (!c->obj.vol) return fail(c, BDOF_ERR_STATE, "bdof_set_object has not been called");
+    if (!c->obj_src) return fail(c, BDOF_ERR_STATE, "bdof_set_object has not been called");
     if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
     return 0;
 }
@@ -289,6 +313,7 @@ void bdof_ctx_destroy(bdof_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     free_workspace(c);
     if (c->heavy) (void)hipFree(c->heavy);
+    if (c->mod) (void)hipFree(c->mod);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -373,6 +398,7 @@ int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det
     c->det_mode = det_mode;
     c->variant = variant;
     c->have_physics = true;
+    c->mod_dirty = true;
     return 0;
 }
 
@@ -386,13 +412,16 @@ int bdof_set_probe(bdof_ctx* c, const float* probe, double a0_re, double a0_im) 
     return 0;
 }
 
-int bdof_set_object(bdof_ctx* c, const void* vol, int volNY, const int* tab, int volNX, int n_angles) {
-    if (!c || !vol) return BDOF_ERR_ARG;
+int bdof_set_object(bdof_ctx* c, const void* vol, long long n_rows, int volNY, const int* tab, int volNX, int n_angles) {
+    if (!c || !vol || n_rows < 1) return BDOF_ERR_ARG;
     if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
     if (volNY < 1) return fail(c, BDOF_ERR_ARG, "volNY must be >= 1");
     if (tab && (volNX < 1 || n_angles < 1)) return fail(c, BDOF_ERR_ARG, "volNX and n_angles must be >= 1 with a table");
     if (!tab && volNY != c->NY) return fail(c, BDOF_ERR_ARG, "without a rotation table volNY must equal NY");
-    c->obj.vol = (const float2*)vol;
+    c->obj_src = (const float2*)vol;
+    c->obj_rows = (size_t)n_rows;
+    c->mod_dirty = true;
+    c->obj.vol = nullptr;
     c->obj.volNY = volNY;
     c->obj.tab = tab;
     c->obj.volNX = tab ? volNX : c->NX;
@@ -424,6 +453,7 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
     if (keep_tape && !c->with_grad) return fail(c, BDOF_ERR_STATE, "keep_tape needs bdof_configure(with_grad=1)");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
+    if ((r = ensure_modulation(c))) return r;
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
     forward_sweep(c, B, keep_tape ? TAPE_HISTORY : TAPE_NONE);
     c->tape_valid = keep_tape != 0;
@@ -475,6 +505,7 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
+    if ((r = ensure_modulation(c))) return r;
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     const float NYf = (float)c->NY;
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;

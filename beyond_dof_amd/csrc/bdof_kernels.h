@@ -74,7 +74,7 @@ __device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, 
 // Object access: which (delta,beta) row feeds wavefield row (b, x) at slice z
 // ---------------------------------------------------------------------------------------------
 struct ObjView {
-    const float2* vol;       // rows of volNY (delta, beta) pairs
+    const float2* vol;       // rows of volNY modulation factors c - 1 (k_modulation_table of the (delta, beta) rows)
     const int* tab;          // nullable: [n_angles][S][volNX] -> source row (rotation lookup, K1)
     const int* angle_of_b;   // [B] angle index per batch element (with tab)
     const int* xoff;         // nullable [B]: window origin in x (ptychography, K11)
@@ -136,12 +136,24 @@ __device__ __forceinline__ cf modulate_eps(cf eps, cf carrier, cf cm1) {
     return cadd(eps, cmul(cm1, cadd(carrier, eps)));
 }
 
+// The modulation factors of the whole object, once per object update (one pass, 16 B/voxel): every voxel row is used by
+// ~25 angles per Adam step, so evaluating sincos/exp here instead of in A and A' removes a third of their arithmetic.
+__global__ __launch_bounds__(256) void k_modulation_table(const float2* __restrict__ db, float2* __restrict__ cm1, size_t n, float k) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        cm1[i] = slice_modulation_m1(db[i], k);
+}
+
+// Loads are unconditional (clamped address) and zeroed afterwards: a branch around each load makes hipcc wait
+// vmcnt(0) per element, i.e. eight dependent memory round trips per row.
 __device__ __forceinline__ void load_obj_row(const ObjView& o, long long srow, int y0, int tid, int T, float2 (&db)[8]) {
+    const float2* row = o.vol + (size_t)(srow >= 0 ? srow : 0) * o.volNY;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
         const int yg = tid + m * T + y0;
-        db[m] = make_float2(0.f, 0.f);
-        if (srow >= 0 && yg >= 0 && yg < o.volNY) db[m] = o.vol[(size_t)srow * o.volNY + yg];
+        const int yc = min(max(yg, 0), o.volNY - 1);
+        const float2 v = row[yc];
+        const bool in = srow >= 0 && yg == yc;
+        db[m] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
     }
 }
 
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
             load_obj_row(a.obj, obj_src_row(a.obj, b, x, a.z, a.NX), y0, tid, C::T, db);
             if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], a.carrier, slice_modulation_m1(db[m], a.k));
+            for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], a.carrier, db[m]);
             if (a.phi_out) {
                 cf* pdst = a.phi_out + (size_t)(row0 + r) * NY;
 #pragma unroll
@@ -435,7 +447,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
                 const cf phi = cadd(p[m], a.carrier);
                 const cf t = cmulc(g[m], phi);                       // G * conj(phi)
                 gdst[tid + m * C::T] = make_float2(a.k * t.y, -a.k * t.x);
-                g[m] = cmulc(g[m], slice_modulation(db[m], a.k));    // conj(c) G
+                g[m] = cmulc(g[m], make_float2(1.f + db[m].x, db[m].y));    // conj(c) G,  c = 1 + (c - 1)
             }
             if (a.gout) line_fft_partial<NY, -1>(g, tw, tid, lds);
         }

@@ -78,14 +78,15 @@ class MultisliceEngine(object):
         rows = util.batch_to_rows(grid_delta_batch, grid_beta_batch)
         buf = DeviceBuffer.from_host(self.ctx, rows)
         self._keep['obj'] = buf
-        self.ctx.check(self.lib.bdof_set_object(self.h, buf.ptr, self.ny, None, 0, 0))
+        self.ctx.check(self.lib.bdof_set_object(self.h, buf.ptr, rows.shape[0] * rows.shape[1] * rows.shape[2], self.ny, None, 0, 0))
         return buf
 
-    def set_volume(self, vol_buf, vol_ny, tab_buf, vol_nx, n_angles):
-        """Un-rotated volume rows [X*Z][vol_ny] pairs + rotation table [n_angles][S][vol_nx] (device)."""
+    def set_volume(self, vol_buf, n_rows, vol_ny, tab_buf, vol_nx, n_angles):
+        """Un-rotated volume rows [n_rows = X*Z][vol_ny] pairs + rotation table [n_angles][S][vol_nx] (device).
+        Must be called again after the volume memory changed (the modulation table is rebuilt)."""
         self._keep['obj'] = vol_buf
         self._keep['tab'] = tab_buf
-        self.ctx.check(self.lib.bdof_set_object(self.h, _lib._ptr(vol_buf), int(vol_ny), _lib._ptr(tab_buf), int(vol_nx), int(n_angles)))
+        self.ctx.check(self.lib.bdof_set_object(self.h, _lib._ptr(vol_buf), int(n_rows), int(vol_ny), _lib._ptr(tab_buf), int(vol_nx), int(n_angles)))
 
     def set_rotation_adjoint(self, off_buf, order_buf, n_dest):
         self._keep['off'] = off_buf

@@ -47,11 +47,12 @@ class FullfieldSolver(object):
         self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
 
     def _bind_volume(self):
-        self.eng.set_volume(self.x[self.cur], self.dim_y, self.tab, self.dim_x, self.n_theta)
+        self.eng.set_volume(self.x[self.cur], self.dim_x * self.dim_z, self.dim_y, self.tab, self.dim_x, self.n_theta)
 
     # ---- state -------------------------------------------------------------------------------
     def set_volume(self, obj_delta, obj_beta):
         self.x[self.cur].upload(util.volume_to_rows(obj_delta, obj_beta))
+        self._bind_volume()
 
     def get_volume(self):
         self.ctx.sync()
@@ -164,10 +165,11 @@ class PtychoSolver(object):
         self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
 
     def _bind_volume(self):
-        self.eng.set_volume(self.x[self.cur], self.dim_y, self.tab, self.dim_x, self.n_theta)
+        self.eng.set_volume(self.x[self.cur], self.dim_x * self.dim_z, self.dim_y, self.tab, self.dim_x, self.n_theta)
 
     def set_volume(self, obj_delta, obj_beta):
         self.x[self.cur].upload(util.volume_to_rows(obj_delta, obj_beta))
+        self._bind_volume()
 
     def get_volume(self):
         self.ctx.sync()

@@ -58,12 +58,14 @@ int bdof_set_physics(bdof_ctx* ctx, double k, const float* hs, const float* hs_d
  * only eps through the float32 FFTs, so round-off scales with the scattered field, not with the full wave. */
 int bdof_set_probe(bdof_ctx* ctx, const float* probe_eps, double a0_re, double a0_im);
 
-/* Object.  vol: device rows of volNY pairs.  tab == NULL: row(b,z,x) = (b*S+z)*NX+x, i.e. the caller
+/* Object.  vol: n_rows device rows of volNY (delta, beta) pairs.  Call again whenever that memory has been modified: the
+ * library keeps a table of the modulation factors exp(i k delta - k beta) - 1 of these rows and rebuilds it lazily.
+ *  tab == NULL: row(b,z,x) = (b*S+z)*NX+x, i.e. the caller
  * supplies already rotated objects (the grid_delta_batch/grid_beta_batch arguments of
  * multislice_propagate_batch_numpy).  tab != NULL (device, [n_angles][S][volNX] int32): fused
  * nearest-neighbour rotation gather, row = tab[angle][z][x]  (apply_rotation, cnn_propagator/util.py:377-402
  * with the tables of save_rotation_lookup, util.py:294-347). */
-int bdof_set_object(bdof_ctx* ctx, const void* vol, int volNY, const int* tab, int volNX, int n_angles);
+int bdof_set_object(bdof_ctx* ctx, const void* vol, long long n_rows, int volNY, const int* tab, int volNX, int n_angles);
 
 /* Inverse rotation tables for the gradient (device): off [n_angles][n_dest+1], order [n_angles][S*volNX]. */
 int bdof_set_rotation_adjoint(bdof_ctx* ctx, const int* off, const int* order, int n_dest);
