@@ -73,6 +73,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-slices', type=int, default=96)
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--propagator', default='fft', choices=['fft', 'conv'],
+                    help="'conv': the reference entry points' truncated real-space kernel (17 taps), for comparison")
     ap.add_argument('--profile-stride', type=int, default=16,
                     help='HIP-event time every n-th launch of the per-slice kernels (each timed launch costs ~9 us of stream time)')
     args = ap.parse_args()
@@ -98,7 +100,8 @@ def main():
     my_angles = np.unique(np.concatenate(my_batches[:min(len(my_batches), args.steps + args.warmup)]))
 
     t_setup = time.time()
-    solver = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, comm=comm, device=local_rank)
+    solver = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, comm=comm, device=local_rank,
+                             propagator=args.propagator)
     true_d, true_b = make_phantom(n)
     solver.set_volume(true_d, true_b)
     meas = np.zeros((n_theta, n, n), dtype=np.float32)
@@ -166,7 +169,8 @@ def main():
                'adam_iters_per_s': args.steps / elapsed, 'final_loss': loss,
                'config': {'workload': 'cfg3: {0}^3 charcoal-like random (delta,beta) volume, {1} of {2} angles per GPU per '
                                       'Adam step, {0} slices, 5 keV, 1 nm, free_prop_cm=1e-4, plane probe'.format(n, mb, n_theta),
-                          'global_batch_angles': world * mb, 'parallelism': 'angle-sharded dp{}'.format(world)},
+                          'global_batch_angles': world * mb, 'parallelism': 'angle-sharded dp{}'.format(world),
+                          'propagator': args.propagator},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n, args.cpu_slices)

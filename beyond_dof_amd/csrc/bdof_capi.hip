@@ -1,6 +1,7 @@
 // libbdof.so — host side of the C ABI declared in include/bdof.h.
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <algorithm>
 #include <complex>
 #include <cstdio>
 #include <cstring>
@@ -29,6 +30,12 @@ struct bdof_ctx {
     int npartial = 0;
     float k = 0.f;
     std::complex<double> h00{1.0, 0.0}, hdet00{1.0, 0.0}, a0{0.0, 0.0};   // carrier splitting (bdof_kernels.h)
+    // real-space truncated-kernel propagator (bdof_set_conv)
+    bool have_conv = false;
+    ConvTaps taps{};
+    std::complex<double> ksum{1.0, 0.0};
+    float k_conv = 0.f;
+    cf *bufC = nullptr, *conv_scal = nullptr;
     int det_mode = BDOF_DET_NONE, variant = BDOF_VARIANT_NUMPY_SKIP_LAST;
     bool have_physics = false, have_probe = false, tape_valid = false, last_valid = false;
     ObjView obj{};
@@ -300,8 +307,10 @@ int bdof_ctx_create(bdof_ctx** out, int device, void* stream) {
 }
 
 static void free_workspace(bdof_ctx* c) {
-    void* ptrs[] = {c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
+    void* ptrs[] = {c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    c->bufC = c->conv_scal = nullptr;
+    c->have_conv = false;
     c->twY = c->twX = c->hs = c->hdet = c->hcomb = c->probe = c->bufA = c->bufB = c->tape = nullptr;
     c->grot = nullptr;
     c->partial = c->loss_dev = nullptr;
@@ -363,8 +372,8 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
         HIPC(c, hipMalloc((void**)&c->tape, sizeof(cf) * fld * (size_t)S));
         HIPC(c, hipMalloc((void**)&c->grot, sizeof(float2) * fld * (size_t)S));
     }
-    c->npartial = c->ncu * 2 + 64;
-    HIPC(c, hipMalloc((void**)&c->partial, sizeof(double) * c->npartial));
+    c->npartial = c->ncu * 16 + 64;
+    HIPC(c, hipMalloc((void**)&c->partial, sizeof(double) * 2 * c->npartial));
     HIPC(c, hipMalloc((void**)&c->loss_dev, sizeof(double)));
     HIPC(c, hipMemsetAsync(c->loss_dev, 0, sizeof(double), c->stream));
     return 0;
@@ -531,6 +540,193 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     for (int z = c->S - 1; z >= 0; --z) {
         launch_row_bwd(c, B, z, c->bufB, c->tape + (size_t)z * fld, z > 0 ? c->bufA : nullptr);
         if (z > 0) launch_row_prop(c, B, c->bufA, c->bufB, c->hs, 1.f, 1);
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+
+// =================================================================================================
+// Real-space truncated-kernel propagator (cnn_propagator/propagation.py:18-133)
+// =================================================================================================
+int bdof_set_conv(bdof_ctx* c, const float* ky, const float* kx, int ks, double e_re, double e_im, double ksum_re,
+                  double ksum_im, double k) {
+    if (!c || !ky || !kx) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    if (ks < 1 || ks > BDOF_CONV_MAXK || ks % 2 == 0) return fail(c, BDOF_ERR_ARG, "kernel_size must be odd and <= 33");
+    if (c->NX % BDOF_CONV_TX || c->NY % BDOF_CONV_TY) return fail(c, BDOF_ERR_SIZE, "conv propagator tiles are 32 x 64");
+    HIPC(c, hipSetDevice(c->device));
+    for (int i = 0; i < ks; ++i) {
+        c->taps.ky[i] = make_float2(ky[2 * i], ky[2 * i + 1]);
+        c->taps.kx[i] = make_float2(kx[2 * i], kx[2 * i + 1]);
+    }
+    c->taps.e = make_float2((float)e_re, (float)e_im);
+    c->taps.ks = ks;
+    c->ksum = std::complex<double>(ksum_re, ksum_im);
+    c->k_conv = (float)k;
+    const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+    if (!c->bufC) HIPC(c, hipMalloc((void**)&c->bufC, sizeof(cf) * fld));
+    if (!c->conv_scal) HIPC(c, hipMalloc((void**)&c->conv_scal, sizeof(cf) * 4));
+    c->have_conv = true;
+    c->mod_dirty = true;
+    return 0;
+}
+
+}  // extern "C"  (helpers below have C++ linkage)
+
+static cf conv_carrier(const bdof_ctx* c, int z) {        // a_z = a_0 sum(K)^z
+    const std::complex<double> a = c->a0 * std::pow(c->ksum, z);
+    return make_float2((float)a.real(), (float)a.imag());
+}
+static cf conv_pad(const bdof_ctx* c, int z) {            // padding constant of eps: edge_val_z - a_z = (1 - a_0) sum(K)^z
+    const std::complex<double> a = (1.0 - c->a0) * std::pow(c->ksum, z);
+    return make_float2((float)a.real(), (float)a.imag());
+}
+
+static int conv_lds_bytes(const bdof_ctx* c) {
+    const int h = (c->taps.ks - 1) / 2;
+    const int TXH = BDOF_CONV_TX + 2 * h, TYH = BDOF_CONV_TY + 2 * h;
+    return (TXH * TYH + TXH * BDOF_CONV_TY) * (int)sizeof(cf);
+}
+
+template <bool BWD> static int launch_conv(bdof_ctx* c, ConvArgs& a) {
+    ProfScope ps(c, BWD ? BDOF_K_ROW_BWD : BDOF_K_ROW_FWD);
+    const int lds = conv_lds_bytes(c);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[BWD]) {
+        HIPC(c, hipFuncSetAttribute((const void*)k_conv<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr_set[BWD] = true;
+    }
+    const int tiles = a.B * (a.NX / BDOF_CONV_TX) * (a.NY / BDOF_CONV_TY);
+    const int grid = balanced_grid(c, tiles, 2);
+    hipLaunchKernelGGL((k_conv<BWD>), dim3(grid), dim3(256), lds, c->stream, a);
+    return 0;
+}
+
+// forward sweep of the conv propagator; leaves psi_S (eps part) in bufB and the scalars in conv_scal
+static int conv_forward_sweep(bdof_ctx* c, int B, bool tape) {
+    const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+    const size_t n = (size_t)B * c->NX * c->NY;
+    const int egrid = (int)std::min<size_t>((n + 255) / 256, (size_t)c->ncu * 16);
+    ObjView obj = c->obj;
+    cf* cur = tape ? c->tape : c->bufA;
+    ConvInitArgs ia{c->probe, cur, obj, B, c->NX, c->NY, conv_carrier(c, 0)};
+    hipLaunchKernelGGL(k_conv_init, dim3(egrid), dim3(256), 0, c->stream, ia);
+    int r;
+    for (int z = 0; z < c->S; ++z) {
+        const bool last = z == c->S - 1;
+        cf* out = last ? c->bufB : (tape ? c->tape + (size_t)(z + 1) * fld : (cur == c->bufA ? c->bufC : c->bufA));
+        ConvArgs a{cur, out, nullptr, nullptr, obj, B, c->NX, c->NY, last ? -1 : z + 1, conv_pad(c, z), conv_carrier(c, z + 1),
+                   c->k_conv, c->taps};
+        if ((r = launch_conv<false>(c, a))) return r;
+        cur = out;
+    }
+    hipLaunchKernelGGL(k_conv_scalars, dim3(1), dim3(64), 0, c->stream, c->bufB, conv_carrier(c, c->S), c->probe,
+                       conv_carrier(c, 0), c->conv_scal);
+    return 0;
+}
+
+static int conv_check(bdof_ctx* c, int B, const int* angle_of_b) {
+    int r = check_ready(c, B);
+    if (r) return r;
+    if (!c->have_conv) return fail(c, BDOF_ERR_STATE, "bdof_set_conv has not been called");
+    if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
+    return 0;
+}
+
+static int ensure_modulation_k(bdof_ctx* c, float k) {
+    // the conv propagator's k uses numpy's pi, the FFT path's the reference's literal (quirk Q1): one table per k
+    if (c->k != k) { c->k = k; c->mod_dirty = true; }
+    return ensure_modulation(c);
+}
+
+extern "C" {
+
+int bdof_forward_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave) {
+    int r = conv_check(c, B, angle_of_b);
+    if (r) return r;
+    if (!out_wave) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    set_batch_views(c, angle_of_b, xoff, yoff);
+    if ((r = ensure_modulation_k(c, c->k_conv))) return r;
+    if ((r = conv_forward_sweep(c, B, false))) return r;
+    c->tape_valid = c->last_valid = false;
+    const size_t n = (size_t)B * c->NX * c->NY;
+    const int egrid = (int)std::min<size_t>((n + 255) / 256, (size_t)c->ncu * 16);
+    const cf zero = make_float2(0.f, 0.f);
+    if (c->det_mode == BDOF_DET_NONE) {
+        ConvFinalArgs fa{c->bufB, (cf*)out_wave, nullptr, nullptr, nullptr, c->conv_scal, conv_carrier(c, c->S), n, 0.f};
+        hipLaunchKernelGGL((k_conv_final<0>), dim3(egrid), dim3(256), 0, c->stream, fa);
+    } else {
+        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, conv_carrier(c, c->S), n, 0.f};
+        hipLaunchKernelGGL((k_conv_final<0>), dim3(egrid), dim3(256), 0, c->stream, fa);
+        RealToHybArgs ra{c->bufA, c->bufC, B, c->NX, c->twY};
+        DISPATCH_N(c->NY, { hipLaunchKernelGGL((k_row_real_to_hyb<N_>), dim3(rows_grid<N_>(c, B, c->NX)), dim3(BDOF_THREADS), 0, c->stream, ra); });
+        if (c->det_mode == BDOF_DET_NEAR) {
+            launch_row_prop(c, B, c->bufC, c->bufA, c->hdet, 1.f, 0);
+            launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f, zero);
+        } else {
+            const std::complex<double> keep = c->a0;      // the far-field kernel adds the carrier's DC bin: none here
+            c->a0 = 0.0;
+            launch_loss_far(c, B, c->bufC, nullptr, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f);
+            c->a0 = keep;
+        }
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, void* out_wave) {
+    int r = conv_check(c, B, angle_of_b);
+    if (r) return r;
+    if (!meas) return BDOF_ERR_ARG;
+    if (!c->with_grad) return fail(c, BDOF_ERR_STATE, "bdof_loss_grad_conv needs bdof_configure(with_grad=1)");
+    HIPC(c, hipSetDevice(c->device));
+    set_batch_views(c, angle_of_b, xoff, yoff);
+    if ((r = ensure_modulation_k(c, c->k_conv))) return r;
+    if ((r = conv_forward_sweep(c, B, true))) return r;
+    c->tape_valid = c->last_valid = false;
+    const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+    const size_t n = (size_t)B * c->NX * c->NY;
+    const int egrid = (int)std::min<size_t>((n + 255) / 256, (size_t)c->ncu * 16);
+    const double seed_scale = 2.0 / ((double)B * c->NX * c->NY);
+    const cf zero = make_float2(0.f, 0.f);
+    cf* gp;
+    int npart;
+    if (c->det_mode == BDOF_DET_NONE) {
+        ConvFinalArgs fa{c->bufB, (cf*)out_wave, c->bufA, meas, c->partial, c->conv_scal, conv_carrier(c, c->S), n, (float)seed_scale};
+        hipLaunchKernelGGL((k_conv_final<1>), dim3(egrid), dim3(256), 0, c->stream, fa);
+        npart = egrid;
+        gp = c->bufA;
+    } else {
+        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, conv_carrier(c, c->S), n, 0.f};
+        hipLaunchKernelGGL((k_conv_final<0>), dim3(egrid), dim3(256), 0, c->stream, fa);
+        RealToHybArgs ra{c->bufA, c->bufC, B, c->NX, c->twY};
+        DISPATCH_N(c->NY, { hipLaunchKernelGGL((k_row_real_to_hyb<N_>), dim3(rows_grid<N_>(c, B, c->NX)), dim3(BDOF_THREADS), 0, c->stream, ra); });
+        if (c->det_mode == BDOF_DET_NEAR) {
+            launch_row_prop(c, B, c->bufC, c->bufA, c->hdet, 1.f, 0);                                     // d_hat (L1)
+            npart = launch_loss_real(c, B, c->bufA, c->bufC, true, (cf*)out_wave, meas, 1.f, 1.f, (float)seed_scale, zero);
+            launch_row_prop(c, B, c->bufC, c->bufA, c->hdet, 1.f, 1);                                     // g_hat(q) (L1)
+        } else {
+            const std::complex<double> keep = c->a0;
+            c->a0 = 0.0;
+            npart = launch_loss_far(c, B, c->bufC, c->bufA, (cf*)out_wave, meas, 1.f, 1.f, (float)seed_scale);   // g_hat(q) (L1)
+            c->a0 = keep;
+        }
+        launch_loss_real(c, B, c->bufA, nullptr, false, c->bufC, nullptr, 1.f, 1.f, 0.f, zero);            // G(q), real space
+        hipLaunchKernelGGL(k_conv_scale_seed, dim3(egrid), dim3(256), 0, c->stream, c->bufC, c->conv_scal, n);
+        gp = c->bufC;
+    }
+    hipLaunchKernelGGL(k_conv_finish, dim3(1), dim3(256), 0, c->stream, c->partial, npart, 2, 1.0 / ((double)B * c->NX * c->NY),
+                       seed_scale, c->loss_dev, gp, c->conv_scal);
+    // backward sweep
+    ObjView obj = c->obj;
+    cf* gcur = gp;
+    for (int z = c->S - 1; z >= 0; --z) {
+        cf* gout = gcur == c->bufB ? c->bufA : c->bufB;
+        ConvArgs a{gcur, gout, c->tape + (size_t)z * fld, c->grot, obj, B, c->NX, c->NY, z, zero, conv_carrier(c, z), c->k_conv, c->taps};
+        if ((r = launch_conv<true>(c, a))) return r;
+        gcur = gout;
     }
     HIPC(c, hipGetLastError());
     return 0;

@@ -281,16 +281,19 @@ __device__ __forceinline__ double wave_reduce_sum(double v) {
     return v;
 }
 
-__device__ __forceinline__ void block_store_sum(double v, double* dst) {
-    __shared__ double wsum[BDOF_THREADS / 64];
+// two sums at once: dst[0] = sum v, dst[1] = sum v2
+__device__ __forceinline__ void block_store_sum2(double v, double v2, double* dst) {
+    __shared__ double wsum[2][BDOF_THREADS / 64];
     v = wave_reduce_sum(v);
+    v2 = wave_reduce_sum(v2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) wsum[wid] = v;
+    if (lane == 0) { wsum[0][wid] = v; wsum[1][wid] = v2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double s = 0;
-        for (int j = 0; j < BDOF_THREADS / 64; ++j) s += wsum[j];
-        *dst = s;
+        double s = 0, s2 = 0;
+        for (int j = 0; j < BDOF_THREADS / 64; ++j) { s += wsum[0][j]; s2 += wsum[1][j]; }
+        dst[0] = s;
+        dst[1] = s2;
     }
 }
 
@@ -306,17 +309,18 @@ struct LossArgs {
     cf* out_hyb;         // nullable: seed transformed back (* out_scale); layout by TSTORE
     cf* out_wave;        // nullable: detector wave, same row layout as `in`
     const float* meas;   // nullable: |measured|, same row layout as `in`
-    double* partial;     // [gridDim.x] per-workgroup sums of (|d|-|m|)^2
+    double* partial;     // [2 * gridDim.x] per-workgroup sums of (|d|-|m|)^2 and of (|d|-|m|) |d|
     int B, R;            // R rows per batch element
     float in_scale, out_scale, seed_scale;
     cf carrier;          // constant part of the detector wave (far field: its DC bin value a*NX*NY)
     const cf* twiddle;
 };
 
-__device__ __forceinline__ cf loss_seed(cf d, float m, float seed_scale, double& acc) {
+__device__ __forceinline__ cf loss_seed(cf d, float m, float seed_scale, double& acc, double& acc2) {
     const float a = sqrtf(d.x * d.x + d.y * d.y);
     const float r = a - m;
     acc += (double)r * (double)r;
+    acc2 += (double)r * (double)a;
     const float f = a > 0.f ? seed_scale * r / a : 0.f;
     return make_float2(d.x * f, d.y * f);
 }
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
     FftTw<N> tw;
     tw.load(a.twiddle, tid, smem_tw);
     const int ntiles = a.B * a.R / C::TILE;
-    double acc = 0.0;
+    double acc = 0.0, acc2 = 0.0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
         const int b = row0 / a.R, r0 = row0 - b * a.R;
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
             }
             if (a.meas) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) u[m] = loss_seed(u[m], mm[m], a.seed_scale, acc);
+                for (int m = 0; m < 8; ++m) u[m] = loss_seed(u[m], mm[m], a.seed_scale, acc, acc2);
             }
             if (a.out_hyb) {
                 if constexpr (TSTORE) {
@@ -384,12 +388,12 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
             }
         }
     }
-    if (a.meas) block_store_sum(acc, a.partial + blockIdx.x);
+    if (a.meas) block_store_sum2(acc, acc2, a.partial + 2 * blockIdx.x);
 }
 
 __global__ void k_sum_partials(const double* partial, int n, double scale, double* out) {
     double v = 0.0;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) v += partial[j];
+    for (int j = threadIdx.x; j < n; j += blockDim.x) v += partial[2 * j];
     __shared__ double wsum[4];
     v = wave_reduce_sum(v);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
@@ -709,5 +713,244 @@ __global__ __launch_bounds__(256) void k_window_rot_adjoint(WinAdjArgs a) {
             if (a.accumulate) { o.x += dst->x; o.y += dst->y; }
             *dst = o;
         }
+    }
+}
+
+// =============================================================================================
+// Real-space truncated-kernel propagator (cnn_propagator/propagation.py:18-133):
+//   per slice  phi = c psi ; psi' = K * pad(phi, edge_val)   (true 2-D convolution, K = E ky (x) kx separable,
+//   ks x ks taps, the padding constant follows edge_val' = sum(K) edge_val), after the last slice the wave is
+//   renormalised by the corner pixel of batch element 0 (propagation.py:79,109-110).
+// Fields are real-space [b][x][y] with the same carrier splitting as the FFT path: psi = a_z + eps, a_{z+1} = a_z sum(K),
+// so the padding constant of eps is (1 - a_0) sum(K)^z — zero for a unit plane wave.
+// One launch per slice: 2-D LDS tile with halo, y pass then x pass, then the next slice's modulation is applied to
+// the tile's outputs (no halo overhead) — 24 B/px forward; the stored phi_z double as the tape.
+// =============================================================================================
+#define BDOF_CONV_MAXK 33
+#define BDOF_CONV_TX 32
+#define BDOF_CONV_TY 64
+
+struct ConvTaps {
+    float2 ky[BDOF_CONV_MAXK];
+    float2 kx[BDOF_CONV_MAXK];
+    float2 e;          // global factor of the kernel
+    int ks;
+};
+
+struct ConvArgs {
+    const cf* in;        // [B][NX][NY]  forward: phi_z (eps part) ; backward: G(psi_{z+1})
+    cf* out;             // forward: phi_{z+1} (or psi_S after the last slice) ; backward: G(psi_z)
+    const cf* tape;      // backward: phi_z
+    float2* grot;        // backward: gradient rows [B][S][NX][NY]
+    ObjView obj;         // modulation table rows (c - 1) of slice `zmod`
+    int B, NX, NY, zmod; // forward: zmod = z + 1 (or -1: no modulation) ; backward: zmod = z
+    cf pad;              // forward: padding constant of the eps field (0 in backward)
+    cf carrier;          // forward: a_{z+1} ; backward: a_z
+    float k;
+    ConvTaps taps;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+    constexpr int TX = BDOF_CONV_TX, TY = BDOF_CONV_TY;
+    const int h = (a.taps.ks - 1) / 2;
+    const int TXH = TX + 2 * h, TYH = TY + 2 * h;
+    extern __shared__ cf lds[];
+    cf* A = lds;                       // [TXH][TYH]
+    cf* M = lds + TXH * TYH;           // [TXH][TY]
+    const int tiles_x = a.NX / TX, tiles_y = a.NY / TY;
+    const int ntiles = a.B * tiles_x * tiles_y;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / (tiles_x * tiles_y);
+        const int t2 = tile - b * tiles_x * tiles_y;
+        const int x0 = (t2 / tiles_y) * TX, y0 = (t2 % tiles_y) * TY;
+        const cf* src = a.in + (size_t)b * a.NX * a.NY;
+        for (int e = threadIdx.x; e < TXH * TYH; e += blockDim.x) {
+            const int i = e / TYH, j = e - i * TYH;
+            const int x = x0 - h + i, y = y0 - h + j;
+            const bool in = x >= 0 && x < a.NX && y >= 0 && y < a.NY;
+            const cf v = src[(size_t)min(max(x, 0), a.NX - 1) * a.NY + min(max(y, 0), a.NY - 1)];
+            A[e] = in ? v : a.pad;
+        }
+        __syncthreads();
+        // pass along y.  forward: o[y] = sum_d K[h+d] f[y-d] ; backward: o[y] = sum_d conj(K[h+d]) g[y+d]
+        for (int e = threadIdx.x; e < TXH * TY; e += blockDim.x) {
+            const int i = e / TY, j = e - i * TY;
+            cf acc = make_float2(0.f, 0.f);
+            for (int d = -h; d <= h; ++d) {
+                const cf w = a.taps.ky[h + d];
+                const cf f = A[i * TYH + j + h + (BWD ? d : -d)];
+                acc = cadd(acc, BWD ? cmulc(f, w) : cmul(f, w));
+            }
+            M[e] = acc;
+        }
+        __syncthreads();
+        // pass along x, then the pointwise physics
+        for (int e = threadIdx.x; e < TX * TY; e += blockDim.x) {
+            const int i = e / TY, j = e - i * TY;
+            cf acc = make_float2(0.f, 0.f);
+            for (int d = -h; d <= h; ++d) {
+                const cf w = a.taps.kx[h + d];
+                const cf f = M[(i + h + (BWD ? d : -d)) * TY + j];
+                acc = cadd(acc, BWD ? cmulc(f, w) : cmul(f, w));
+            }
+            acc = BWD ? cmulc(acc, a.taps.e) : cmul(acc, a.taps.e);
+            const int x = x0 + i, y = y0 + j;
+            const size_t off = ((size_t)b * a.NX + x) * a.NY + y;
+            float2 m1 = make_float2(0.f, 0.f);
+            if (a.zmod >= 0) {
+                const long long srow = obj_src_row(a.obj, b, x, a.zmod, a.NX);
+                const int yg = y + (a.obj.yoff ? a.obj.yoff[b] : 0);
+                if (srow >= 0 && yg >= 0 && yg < a.obj.volNY) m1 = a.obj.vol[(size_t)srow * a.obj.volNY + yg];
+            }
+            if constexpr (!BWD) {
+                a.out[off] = modulate_eps(acc, a.carrier, m1);          // phi_{z+1} = c_{z+1} psi_{z+1}  (eps part)
+            } else {
+                const cf phi = cadd(a.tape[off], a.carrier);
+                const cf t = cmulc(acc, phi);                               // G(phi) conj(phi)
+                a.grot[(((size_t)b * a.obj.S + a.zmod) * a.NX + x) * a.NY + y] = make_float2(a.k * t.y, -a.k * t.x);
+                a.out[off] = cmulc(acc, make_float2(1.f + m1.x, m1.y));     // G(psi_z) = conj(c_z) G(phi_z)
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// phi_0 = c_0 (a_0 + eps_probe): the first modulation, before any convolution
+struct ConvInitArgs {
+    const cf* probe;     // [NX][NY] eps part
+    cf* out;             // [B][NX][NY]
+    ObjView obj;
+    int B, NX, NY;
+    cf carrier;          // a_0
+};
+__global__ __launch_bounds__(256) void k_conv_init(ConvInitArgs a) {
+    const size_t n = (size_t)a.B * a.NX * a.NY;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = idx % a.NY;
+        const size_t r = idx / a.NY;
+        const int x = r % a.NX, b = r / a.NX;
+        float2 m1 = make_float2(0.f, 0.f);
+        const long long srow = obj_src_row(a.obj, b, x, 0, a.NX);
+        const int yg = y + (a.obj.yoff ? a.obj.yoff[b] : 0);
+        if (srow >= 0 && yg >= 0 && yg < a.obj.volNY) m1 = a.obj.vol[(size_t)srow * a.obj.volNY + yg];
+        a.out[idx] = modulate_eps(a.probe[(size_t)x * a.NY + y], a.carrier, m1);
+    }
+}
+
+// s = probe[0,0] / psi_S[0,0,0]   (propagation.py:79,109-110).  scal[0] = s, scal[1] = psi_S[0,0,0]
+__global__ void k_conv_scalars(const cf* psi_eps, cf carrier_end, const cf* probe_eps, cf carrier0, cf* scal) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const cf p000 = cadd(psi_eps[0], carrier_end);
+        const cf init = cadd(probe_eps[0], carrier0);
+        const float den = p000.x * p000.x + p000.y * p000.y;
+        scal[0] = cscale(cmulc(init, p000), 1.f / den);
+        scal[1] = p000;
+    }
+}
+
+// Renormalised wave q = s (a_S + eps) and, for the real-space detector without free propagation, loss + seed.
+//   MODE 0: q only (out) ; MODE 1: q, loss partials, Gp = conj(s) G(d) (out2)
+struct ConvFinalArgs {
+    const cf* psi_eps;
+    cf* out;             // q  [B][NX][NY] (nullable in MODE 1)
+    cf* out2;            // MODE 1: conj(s) G(d)
+    const float* meas;   // MODE 1
+    double* partial;     // MODE 1: [2 * gridDim.x]: sum r^2, sum r |d|
+    const cf* scal;
+    cf carrier_end;
+    size_t n;
+    float seed_scale;
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv_final(ConvFinalArgs a) {
+    const cf s = a.scal[0];
+    double acc = 0.0, acc2 = 0.0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.n; idx += (size_t)gridDim.x * blockDim.x) {
+        const cf q = cmul(cadd(a.psi_eps[idx], a.carrier_end), s);
+        if (a.out) a.out[idx] = q;
+        if constexpr (MODE == 1) {
+            const float ab = sqrtf(q.x * q.x + q.y * q.y);
+            const float r = ab - a.meas[idx];
+            acc += (double)r * r;
+            acc2 += (double)r * ab;
+            const float f = ab > 0.f ? a.seed_scale * r / ab : 0.f;
+            a.out2[idx] = cmulc(cscale(q, f), s);                         // conj(s) G(d)
+        }
+    }
+    if constexpr (MODE == 1) {
+        __shared__ double w1[4], w2[4];
+        acc = wave_reduce_sum(acc);
+        acc2 = wave_reduce_sum(acc2);
+        if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = acc; w2[threadIdx.x >> 6] = acc2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.partial[2 * blockIdx.x] = w1[0] + w1[1] + w1[2] + w1[3];
+            a.partial[2 * blockIdx.x + 1] = w2[0] + w2[1] + w2[2] + w2[3];
+        }
+    }
+}
+
+// Gp = conj(s) G(q) for detectors that went through the FFT machinery (G(q) arrives in real space)
+__global__ __launch_bounds__(256) void k_conv_scale_seed(cf* g, const cf* scal, size_t n) {
+    const cf s = scal[0];
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)
+        g[idx] = cmulc(g[idx], s);
+}
+
+// loss = sum r^2 / n ; corner fix  Gp[0] -= (sum_j G(q)_j conj(q_j)) / conj(psi_S[0,0,0]),  the sum being
+// seed_scale * sum r |d| (G(d) is parallel to d and the detector step is unitary / an exact adjoint pair)
+__global__ void k_conv_finish(const double* partial, int nblocks, int stride, double inv_n, double seed_scale, double* loss,
+                              cf* gp, const cf* scal) {
+    double v = 0.0, v2 = 0.0;
+    for (int j = threadIdx.x; j < nblocks; j += blockDim.x) { v += partial[stride * j]; v2 += partial[stride * j + 1]; }
+    __shared__ double w1[4], w2[4];
+    v = wave_reduce_sum(v);
+    v2 = wave_reduce_sum(v2);
+    if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = v; w2[threadIdx.x >> 6] = v2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        loss[0] = (w1[0] + w1[1] + w1[2] + w1[3]) * inv_n;
+        const double rsum = (w2[0] + w2[1] + w2[2] + w2[3]) * seed_scale;
+        const cf p = scal[1];
+        const double den = (double)p.x * p.x + (double)p.y * p.y;
+        // rsum / conj(p) = rsum * p / |p|^2
+        gp[0].x -= (float)(rsum * p.x / den);
+        gp[0].y -= (float)(rsum * p.y / den);
+    }
+}
+
+// real-space rows -> hybrid (FFT along y), transposed into L2: feeds the detector steps of the FFT machinery
+struct RealToHybArgs {
+    const cf* in;      // [B][NX][NY] real space
+    cf* out;           // L2
+    int B, NX;
+    const cf* twiddle;
+};
+template <int NY>
+__global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_real_to_hyb(RealToHybArgs a) {
+    typedef RowCfg<NY> C;
+    __shared__ cf smem[C::LDS_CF];
+    const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
+    FftTw<NY> tw;
+    tw.load(a.twiddle, tid, smem_tw);
+    const int ntiles = a.B * a.NX / C::TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * C::TILE;
+        const int b = row0 / a.NX, x0 = row0 - b * a.NX;
+#pragma nounroll
+        for (int pass = 0; pass < C::PASSES; ++pass) {
+            const int r = pass * C::RPP + rl;
+            RowLds<C::T> lds{smem + r * C::RS};
+            cf u[8];
+            const cf* src = a.in + (size_t)(row0 + r) * NY;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) u[m] = src[tid + m * C::T];
+            line_fft_partial<NY, -1>(u, tw, tid, lds);
+        }
+        __syncthreads();
+        transposed_tail<NY, -1>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, a.twiddle);
+        __syncthreads();
     }
 }

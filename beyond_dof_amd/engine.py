@@ -72,6 +72,20 @@ class MultisliceEngine(object):
         eps = np.ascontiguousarray((probe.astype(np.complex128) - a0).T.astype(np.complex64))
         self.ctx.check(self.lib.bdof_set_probe(self.h, eps.ctypes.data, a0.real, a0.imag))
 
+    def set_conv(self, energy_ev, psize_cm, kernel_size=17):
+        """Switch the slice-to-slice step to the truncated real-space kernel of multislice_propagate_cnn
+        (cnn_propagator/propagation.py:18-44): k uses numpy's pi there (:25), the kernel the reference's PI literal."""
+        voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
+        lmbda_nm = 1240. / energy_ev
+        delta_nm = voxel_nm[-1]
+        ky, kx, e = util.conv_kernel_separable(delta_nm, lmbda_nm, voxel_nm, (self.ny, self.nx), kernel_size)
+        ksum = e * ky.sum() * kx.sum()
+        k = 2. * np.pi * delta_nm / lmbda_nm
+        kyf = np.ascontiguousarray(ky.astype(np.complex64))
+        kxf = np.ascontiguousarray(kx.astype(np.complex64))
+        self.ctx.check(self.lib.bdof_set_conv(self.h, kyf.ctypes.data, kxf.ctypes.data, int(kernel_size), e.real, e.imag,
+                                              ksum.real, ksum.imag, k))
+
     # ---- object --------------------------------------------------------------------------------
     def set_object_batch(self, grid_delta_batch, grid_beta_batch):
         """Already rotated objects, (B, Y, X, S) each (the np_funcs.py:15 argument convention)."""
@@ -112,12 +126,15 @@ class MultisliceEngine(object):
     def _meas_to_device(self, meas_abs):
         return DeviceBuffer.from_host(self.ctx, self.meas_layout(meas_abs))
 
-    def forward(self, B, angle_idx=None, xoff=None, yoff=None, keep_tape=False, to_host=True):
+    def forward(self, B, angle_idx=None, xoff=None, yoff=None, keep_tape=False, to_host=True, conv=False):
         out = DeviceBuffer(self.ctx, B * self.nx * self.ny * 8, np.complex64, (B, self.nx, self.ny))
         a = _idx_buf(self.ctx, angle_idx) if angle_idx is not None else None
         xo = _idx_buf(self.ctx, xoff) if xoff is not None else None
         yo = _idx_buf(self.ctx, yoff) if yoff is not None else None
-        self.ctx.check(self.lib.bdof_forward(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), out.ptr, int(keep_tape)))
+        if conv:
+            self.ctx.check(self.lib.bdof_forward_conv(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), out.ptr))
+        else:
+            self.ctx.check(self.lib.bdof_forward(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), out.ptr, int(keep_tape)))
         self.ctx.sync()
         return self._wave_to_host(out, B) if to_host else out
 
@@ -131,13 +148,14 @@ class MultisliceEngine(object):
         return res
 
     # ---- loss + gradient -----------------------------------------------------------------------
-    def loss_grad(self, B, meas_abs, angle_idx=None, xoff=None, yoff=None, meas_on_device=False):
+    def loss_grad(self, B, meas_abs, angle_idx=None, xoff=None, yoff=None, meas_on_device=False, conv=False):
         """Runs forward + loss + adjoint; returns the loss.  The gradient stays on the device."""
         m = meas_abs if meas_on_device else self._meas_to_device(meas_abs)
         a = _idx_buf(self.ctx, angle_idx) if angle_idx is not None else None
         xo = _idx_buf(self.ctx, xoff) if xoff is not None else None
         yo = _idx_buf(self.ctx, yoff) if yoff is not None else None
-        self.ctx.check(self.lib.bdof_loss_grad(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), _lib._ptr(m), None))
+        fn = self.lib.bdof_loss_grad_conv if conv else self.lib.bdof_loss_grad
+        self.ctx.check(fn(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), _lib._ptr(m), None))
         loss = ctypes.c_double(0)
         self.ctx.check(self.lib.bdof_get_loss(self.h, ctypes.byref(loss)))
         self._keep['last_idx'] = (a, xo, yo, m)

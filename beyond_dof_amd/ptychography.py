@@ -53,6 +53,9 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
     size, rank = comm.size, comm.rank
     seed = kwargs.get('seed', int(time.time() / 60))
     variant = kwargs.get('variant', 'numpy_skip_last')
+    # 'fft' (default): transfer-function propagator of np_funcs.py; 'conv': truncated real-space kernel of propagation.py,
+    # the reference's own choice in this entry point, with `kernel_size` taps per axis
+    propagator = kwargs.get('propagator', 'fft')
 
     print_flush('Reading data...', 0, rank)
     f = h5io.File(os.path.join(save_path, fname))
@@ -134,7 +137,7 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
 
         solver = PtychoSolver(this_obj_size, this_probe_size, this_probe_pos, n_theta, minibatch_size, energy_ev,
                               psize_cm * ds_level, probe_real, probe_imag, variant=variant, comm=comm, device=comm.local_rank,
-                              coord_ls=coord_ls)
+                              coord_ls=coord_ls, propagator=propagator, kernel_size=kwargs.get('kernel_size', 17))
         solver.set_volume(obj_delta, obj_beta)
         print_flush('Optimizer started.', 0, rank)
         if rank == 0:

@@ -13,13 +13,18 @@ from .engine import MultisliceEngine
 class FullfieldSolver(object):
     def __init__(self, dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm, free_prop_cm=None,
                  probe_real=None, probe_imag=None, variant='numpy_skip_last', comm=None, device=0, stream=None,
-                 coord_ls=None):
+                 coord_ls=None, propagator='fft', kernel_size=17):
+        """propagator='fft': the transfer-function step of np_funcs.py (north-star path); 'conv': the truncated real-space
+        kernel of propagation.py, what cnn_propagator/fullfield.py:87,102 calls (kernel_size taps per axis)."""
+        self.conv = propagator == 'conv'
         self.dim_y, self.dim_x, self.dim_z = int(dim_y), int(dim_x), int(dim_z)
         self.n_theta, self.mb = int(n_theta), int(minibatch_size)
         self.comm = comm or PseudoComm()
         self.eng = MultisliceEngine(self.dim_y, self.dim_x, self.dim_z, self.mb, with_grad=True, device=device, stream=stream)
         self.ctx = self.eng.ctx
         self.eng.set_physics(energy_ev, psize_cm, free_prop_cm, variant=variant)
+        if self.conv:
+            self.eng.set_conv(energy_ev, psize_cm, kernel_size)
         if probe_real is None:
             probe_real, probe_imag = np.ones((dim_y, dim_x)), np.zeros((dim_y, dim_x))   # 'plane', fullfield.py:276-278
         self.eng.set_probe(probe_real, probe_imag)
@@ -86,7 +91,8 @@ class FullfieldSolver(object):
         """Data-term loss and its gradient w.r.t. the volume for this rank's angles (left in self.g)."""
         lib, h = self.ctx.lib, self.ctx.handle
         self._stage_batch(angle_idx)
-        self.ctx.check(lib.bdof_loss_grad(h, self.mb, self.angle_buf.ptr, None, None, self.meas_stage.ptr, None))
+        fn = lib.bdof_loss_grad_conv if self.conv else lib.bdof_loss_grad
+        self.ctx.check(fn(h, self.mb, self.angle_buf.ptr, None, None, self.meas_stage.ptr, None))
         self.ctx.check(lib.bdof_rotation_adjoint(h, self.mb, self.angle_buf.ptr, self.g.ptr, 0, 1.0))
         if want_loss:
             import ctypes
@@ -127,7 +133,7 @@ class FullfieldSolver(object):
         out = []
         for i in range(0, len(idx), self.mb):
             chunk = idx[i:i + self.mb]
-            out.append(self.eng.forward(len(chunk), angle_idx=chunk))
+            out.append(self.eng.forward(len(chunk), angle_idx=chunk, conv=self.conv))
         return np.concatenate(out, axis=0)
 
 
@@ -136,7 +142,8 @@ class PtychoSolver(object):
     Adam moments, rotation tables, all diffraction amplitudes; windows are cut by index math inside the kernels."""
 
     def __init__(self, obj_size, probe_size, probe_pos, n_theta, minibatch_size, energy_ev, psize_cm, probe_real, probe_imag,
-                 variant='numpy_skip_last', comm=None, device=0, stream=None, coord_ls=None):
+                 variant='numpy_skip_last', comm=None, device=0, stream=None, coord_ls=None, propagator='fft', kernel_size=17):
+        self.conv = propagator == 'conv'
         self.dim_y, self.dim_x, self.dim_z = [int(s) for s in obj_size]
         self.py, self.px = int(probe_size[0]), int(probe_size[1])
         self.n_theta, self.mb = int(n_theta), int(minibatch_size)
@@ -146,6 +153,8 @@ class PtychoSolver(object):
         self.eng = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream)
         self.ctx = self.eng.ctx
         self.eng.set_physics(energy_ev, psize_cm, 'inf', variant=variant)   # free_prop_cm='inf', ptychography.py:76
+        if self.conv:
+            self.eng.set_conv(energy_ev, psize_cm, kernel_size)
         self.eng.set_probe(probe_real, probe_imag)
         if coord_ls is None:
             coord_ls = util.rotation_lookup([self.dim_y, self.dim_x, self.dim_z], n_theta)
@@ -196,7 +205,8 @@ class PtychoSolver(object):
         import ctypes
         lib, h = self.ctx.lib, self.ctx.handle
         a, xo, yo = self._stage(i_theta, pos_idx, prj_abs_batch)
-        self.ctx.check(lib.bdof_loss_grad(h, self.mb, a, xo, yo, self.meas_stage.ptr, None))
+        fn = lib.bdof_loss_grad_conv if self.conv else lib.bdof_loss_grad
+        self.ctx.check(fn(h, self.mb, a, xo, yo, self.meas_stage.ptr, None))
         self.ctx.check(lib.bdof_window_rotation_adjoint(h, self.mb, int(i_theta), xo, yo, self.g.ptr, 0, 1.0))
         if want_loss:
             loss = ctypes.c_double(0)
@@ -207,7 +217,7 @@ class PtychoSolver(object):
     def forward(self, i_theta, pos_idx):
         pos = self.probe_pos[np.asarray(pos_idx)]
         return self.eng.forward(len(pos), angle_idx=[i_theta] * len(pos), xoff=pos[:, 1] - self.half[1],
-                                yoff=pos[:, 0] - self.half[0])
+                                yoff=pos[:, 0] - self.half[0], conv=self.conv)
 
     def adam_update(self, i_batch, learning_rate, clip=True):
         new = 1 - self.cur

@@ -37,6 +37,25 @@ def transfer_function_dc(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI):
     return v.real, v.imag
 
 
+def conv_kernel_separable(delta_nm, lmbda_nm, voxel_nm, grid_shape, kernel_size, pi=PI):
+    """The truncated real-space Fresnel kernel of cnn_propagator/propagation.py:35-44 in separable form:
+    K[p][q] = e * ky[p] * kx[q].  H on the (Y-1, X-1) mesh is e * outer(fv, fu), so its inverse FFT, fftshift and centre
+    crop factorise exactly.  Returns (ky, kx, e) in complex128."""
+    ny, nx = int(grid_shape[0]) - 1, int(grid_shape[1]) - 1
+    half = int((kernel_size - 1) / 2)
+
+    def one(n, vox):
+        f = np.exp(-1j * pi * lmbda_nm * delta_nm * np.linspace(-1. / (2. * vox), 1. / (2. * vox), n) ** 2)
+        k1 = np.fft.fftshift(np.fft.ifft(np.fft.ifftshift(f)))
+        mid = int((n - 1) / 2)
+        return k1[mid - half:mid + half + 1]
+
+    ky = one(ny, voxel_nm[1])       # rows of H follow v_max = 1/(2 voxel[1])  (get_kernel)
+    kx = one(nx, voxel_nm[0])
+    e = np.exp(1j * (2 * pi / lmbda_nm) * delta_nm)
+    return ky, kx, e
+
+
 def rotation_lookup(array_size, n_theta):
     """Nearest-neighbour rotation source coordinates for every angle, as save_rotation_lookup builds
     them (cnn_propagator/util.py:294-332) but kept in memory: list of (X*Z, 2) int arrays.  Angles are

@@ -87,6 +87,17 @@ int bdof_tape_to_real(bdof_ctx* ctx, int i, int B, void* out);
  * windowed (delta,beta) is left in the ctx (bdof_grot). out_wave may be NULL. */
 int bdof_loss_grad(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, void* out_wave);
 int bdof_get_loss(bdof_ctx* ctx, double* loss);
+
+/* Real-space truncated-kernel propagator: replaces multislice_propagate_cnn (cnn_propagator/propagation.py:18-133), the
+ * forward model cnn_propagator/fullfield.py:87,102 and ptychography.py:74 literally call.  The cropped kernel is separable,
+ * K[p][q] = e * ky[p] * kx[q] (ky, kx: HOST complex arrays of ks taps, ks odd <= 33); ksum = sum of K (the factor of the
+ * padding constant per slice, propagation.py:104); k = 2*np.pi*delta_nm/lambda_nm (propagation.py:25).  The detector step
+ * and the probe are those of bdof_set_physics / bdof_set_probe.  bdof_forward_conv / bdof_loss_grad_conv mirror
+ * bdof_forward / bdof_loss_grad (same arguments, gradient left in bdof_grot). */
+int bdof_set_conv(bdof_ctx* ctx, const float* ky, const float* kx, int ks, double e_re, double e_im, double ksum_re,
+                  double ksum_im, double k);
+int bdof_forward_conv(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave);
+int bdof_loss_grad_conv(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, void* out_wave);
 void* bdof_grot(bdof_ctx* ctx);      /* device [B][S][NX][NY] pairs */
 
 /* Adjoint of the rotation gather: gvol[dest][y] (+)= scale * sum over the batch of the rows gathered

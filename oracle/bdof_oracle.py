@@ -362,3 +362,105 @@ def gaussian_probe(shape, mag_sigma, phase_sigma, phase_max):
     phase = phase_max * np.exp(-(pxx ** 2 + pyy ** 2) / (2 * phase_sigma ** 2))
     a = mag * np.exp(1j * phase)            # util.py:265-268 mag_phase_to_real_imag
     return a.real, a.imag
+
+
+# ---------------------------------------------------------------------------
+# Real-space truncated-kernel propagator            cnn_propagator/propagation.py:18-133   
+# RESTATEMENT ONLY: the reference function needs autograd.scipy.signal.convolve, which is not installed, so it
+# cannot be executed here; get_kernel (the only numerical ingredient besides FFT/convolution) is golden-pinned.
+# ---------------------------------------------------------------------------
+def conv_kernel_2d(delta_nm, lmbda_nm, voxel_nm, grid_shape, kernel_size):
+    """propagation.py:35-44: H on the (Y-1, X-1) mesh -> real space -> centre crop of kernel_size^2."""
+    kernel = get_kernel(delta_nm, lmbda_nm, voxel_nm, np.array(grid_shape) - 1)
+    kernel = np.fft.fftshift(np.fft.ifft2(np.fft.ifftshift(kernel)))
+    kernel_mid = ((np.array(kernel.shape) - 1) / 2).astype('int')
+    half = int((kernel_size - 1) / 2)
+    return kernel[kernel_mid[0] - half:kernel_mid[0] + half + 1, kernel_mid[1] - half:kernel_mid[1] + half + 1]
+
+
+def _conv_valid(field, kernel):
+    """True 2-D convolution, mode='valid', per batch element (autograd.scipy.signal.convolve with
+    axes=([1, 2], [0, 1]), propagation.py:93)."""
+    from scipy.signal import convolve2d
+    return np.stack([convolve2d(f, kernel, mode='valid') for f in field])
+
+
+def multislice_propagate_cnn(grid_delta, grid_beta, probe_real, probe_imag, energy_ev, psize_cm, kernel_size=17,
+                             free_prop_cm=None, return_tape=False):
+    """Restates cnn_propagator/propagation.py:18-133.  psize_cm is a 3-vector there (fullfield.py:89); k uses np.pi
+    (propagation.py:25, quirk Q1) while the kernel uses PI = 3.1415927 through get_kernel."""
+    assert kernel_size % 2 == 1
+    n_batch, shape_y, shape_x, n_slice = grid_delta.shape
+    lmbda_nm = 1240. / energy_ev
+    voxel_nm = np.array(psize_cm) * 1.e7 if np.ndim(psize_cm) else np.array([psize_cm] * 3) * 1.e7
+    delta_nm = voxel_nm[-1]
+    k = 2. * np.pi * delta_nm / lmbda_nm
+    grid_shape = np.array(grid_delta.shape[1:])
+    kernel = conv_kernel_2d(delta_nm, lmbda_nm, voxel_nm, grid_shape, kernel_size)
+    pad_len = (kernel_size - 1) // 2
+    probe = np.tile(probe_real + 1j * probe_imag, [n_batch, 1, 1]).astype(np.complex128)
+    edge_val = 1.0
+    initial_int = probe[0, 0, 0]
+    tape = []
+    for i_slice in range(n_slice):
+        c = np.exp(1j * k * grid_delta[:, :, :, i_slice] - k * grid_beta[:, :, :, i_slice])
+        probe = probe * c
+        tape.append((probe, c))
+        padded = np.pad(probe, [[0, 0], [pad_len, pad_len], [pad_len, pad_len]], mode='constant', constant_values=edge_val)
+        probe = _conv_valid(padded, kernel)
+        edge_val = np.sum(kernel.flatten() * edge_val)
+    final_int = probe[0, 0, 0]
+    pre_norm = probe
+    probe = probe * (initial_int / final_int)
+    if free_prop_cm is not None:
+        if free_prop_cm == 'inf':
+            probe = np.fft.fftshift(np.fft.fft2(probe), axes=[1, 2])
+        else:
+            h = get_kernel(free_prop_cm * 1e7, lmbda_nm, voxel_nm, grid_shape)
+            probe = np.fft.ifft2(np.fft.ifftshift(np.fft.fftshift(np.fft.fft2(probe), axes=[1, 2]) * h, axes=[1, 2]))
+    if return_tape:
+        return probe, tape, kernel, pre_norm, initial_int, k
+    return probe
+
+
+def cnn_loss_and_grad(grid_delta, grid_beta, probe_real, probe_imag, energy_ev, psize_cm, meas_abs, kernel_size=17,
+                      free_prop_cm=None):
+    """loss = mean((|d| - meas_abs)^2) for the conv forward and its gradient w.r.t. (delta, beta) — what
+    autograd.grad(calculate_loss) differentiates in cnn_propagator/fullfield.py:102-106,329 (hand-derived; checked
+    against finite differences in tests/test_oracle_adjoint.py)."""
+    from scipy.signal import correlate2d
+    d, tape, kernel, pre_norm, initial_int, k = multislice_propagate_cnn(
+        grid_delta, grid_beta, probe_real, probe_imag, energy_ev, psize_cm, kernel_size, free_prop_cm, return_tape=True)
+    B, Y, X, S = grid_delta.shape
+    lmbda_nm = 1240. / energy_ev
+    voxel_nm = np.array(psize_cm) * 1.e7 if np.ndim(psize_cm) else np.array([psize_cm] * 3) * 1.e7
+    absd = np.abs(d)
+    resid = absd - meas_abs
+    loss = np.mean(resid ** 2)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        unit = np.where(absd > 0, d / absd, 0)
+    G = 2.0 * resid * unit / (B * Y * X)                       # G(d)
+    if free_prop_cm is None:
+        Gq = G
+    elif free_prop_cm == 'inf':
+        Gq = (Y * X) * np.fft.ifft2(np.fft.ifftshift(G, axes=[1, 2]))
+    else:
+        h = get_kernel(free_prop_cm * 1e7, lmbda_nm, voxel_nm, (Y, X, S))
+        Gq = np.fft.ifft2(np.fft.ifftshift(np.fft.fftshift(np.fft.fft2(G), axes=[1, 2]) * np.conj(h), axes=[1, 2]))
+    # q = s * P,  s = initial_int / P[0,0,0]  (propagation.py:109-110; differentiable through the corner pixel)
+    P000 = pre_norm[0, 0, 0]
+    s = initial_int / P000
+    q = s * pre_norm
+    Gp = np.conj(s) * Gq
+    Gp[0, 0, 0] += -np.sum(Gq * np.conj(q)) / np.conj(P000)
+    g_delta = np.zeros((B, Y, X, S))
+    g_beta = np.zeros((B, Y, X, S))
+    for i in range(S - 1, -1, -1):
+        phi, c = tape[i]
+        # adjoint of (constant pad, valid convolution): full correlation with conj(kernel), cropped to the field
+        Gphi = np.stack([correlate2d(g, kernel, mode='same') for g in Gp])
+        t = np.conj(phi) * Gphi
+        g_delta[..., i] = k * t.imag
+        g_beta[..., i] = -k * t.real
+        Gp = np.conj(c) * Gphi
+    return loss, g_delta, g_beta

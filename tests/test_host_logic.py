@@ -107,3 +107,11 @@ def test_gaussian_probe_matches_oracle():
     b = orc.gaussian_probe((7, 9), 2.0, 3.0, 0.5)
     np.testing.assert_allclose(a[0], b[0])
     np.testing.assert_allclose(a[1], b[1])
+
+
+def test_conv_kernel_separable_matches_reference_recipe():
+    """The separable taps reproduce the reference's 2-D kernel (propagation.py:35-44) restated in the oracle."""
+    for shape, ks in [((64, 64, 8), 17), ((64, 128, 8), 5), ((96, 64, 4), 9)]:
+        ky, kx, e = util.conv_kernel_separable(1.0, 0.248, np.array([1., 1., 1.]), shape, ks)
+        k2 = orc.conv_kernel_2d(1.0, 0.248, np.array([1., 1., 1.]), np.array(shape), ks)
+        np.testing.assert_allclose(e * np.outer(ky, kx), k2, rtol=0, atol=1e-13 * np.abs(k2).max())

@@ -138,3 +138,40 @@ def test_fullfield_and_ptycho_grad_finite_difference():
             am = [m, ob] if arr_i == 0 else [od, m]
             fd = (orc.ptycho_loss_and_grad(*ap, *pargs)[0] - orc.ptycho_loss_and_grad(*am, *pargs)[0]) / (2 * eps)
             assert abs(fd - g[idx]) < 2e-6 * max(1.0, np.abs(g).max())
+
+
+@pytest.mark.parametrize('fp', [None, 1e-4, 'inf'])
+def test_cnn_gradient_finite_difference(fp):
+    """Real-space truncated-kernel propagator (propagation.py) incl. the corner-pixel renormalisation."""
+    rng = np.random.default_rng(5)
+    B, Y, X, S, ks = 2, 9, 11, 4, 5
+    delta = rng.uniform(0, 2e-3, size=(B, Y, X, S))
+    beta = rng.uniform(0, 2e-4, size=(B, Y, X, S))
+    pr = 1 + 0.1 * rng.normal(size=(Y, X))
+    pi = 0.1 * rng.normal(size=(Y, X))
+    meas = np.abs(1 + 0.05 * rng.normal(size=(B, Y, X))) * (np.sqrt(Y * X) if fp == 'inf' else 1.0)
+    args = (pr, pi, 5000., [1e-7] * 3, meas)
+
+    def loss_of(d, b):
+        w = orc.multislice_propagate_cnn(d, b, pr, pi, 5000., [1e-7] * 3, kernel_size=ks, free_prop_cm=fp)
+        return np.mean((np.abs(w) - meas) ** 2)
+
+    loss, gd, gb = orc.cnn_loss_and_grad(delta, beta, *args, kernel_size=ks, free_prop_cm=fp)
+    assert abs(loss - loss_of(delta, beta)) < 1e-14 * max(1, loss)
+    for arr, g, which in [(delta, gd, 0), (beta, gb, 1)]:
+        for trial in range(8):
+            idx = (0, 0, 0, int(rng.integers(0, S))) if trial == 0 else tuple(rng.integers(0, s) for s in arr.shape)
+            eps = 1e-6
+            p, m = arr.copy(), arr.copy()
+            p[idx] += eps
+            m[idx] -= eps
+            fd = ((loss_of(p, beta) - loss_of(m, beta)) if which == 0 else (loss_of(delta, p) - loss_of(delta, m))) / (2 * eps)
+            assert abs(fd - g[idx]) <= 2e-6 * max(abs(g).max(), 1e-30), (idx, fd, g[idx])
+
+
+def test_cnn_kernel_is_separable():
+    """The cropped real-space Fresnel kernel is an outer product (H is separable): basis of the GPU's two 1-D passes."""
+    k2 = orc.conv_kernel_2d(1.0, 0.248, np.array([1., 1., 1.]), np.array([64, 48, 10]), 17)
+    c = 8
+    sep = np.outer(k2[:, c], k2[c, :]) / k2[c, c]
+    assert np.abs(sep - k2).max() <= 1e-13 * np.abs(k2).max()
