@@ -586,21 +586,31 @@ static cf conv_pad(const bdof_ctx* c, int z) {            // padding constant of
 static int conv_lds_bytes(const bdof_ctx* c) {
     const int h = (c->taps.ks - 1) / 2;
     const int TXH = BDOF_CONV_TX + 2 * h, TYH = BDOF_CONV_TY + 2 * h;
-    return (TXH * TYH + TXH * BDOF_CONV_TY) * (int)sizeof(cf);
+    return (TXH * (TYH | 1) + TXH * (BDOF_CONV_TY + 1)) * (int)sizeof(cf);
+}
+
+template <bool BWD, int H> static int launch_conv_h(bdof_ctx* c, ConvArgs& a) {
+    const int lds = conv_lds_bytes(c);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPC(c, hipFuncSetAttribute((const void*)k_conv<BWD, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        attr_set = true;
+    }
+    const int tiles = a.B * (a.NX / BDOF_CONV_TX) * (a.NY / BDOF_CONV_TY);
+    const int grid = balanced_grid(c, tiles, 2);
+    hipLaunchKernelGGL((k_conv<BWD, H>), dim3(grid), dim3(256), lds, c->stream, a);
+    return 0;
 }
 
 template <bool BWD> static int launch_conv(bdof_ctx* c, ConvArgs& a) {
     ProfScope ps(c, BWD ? BDOF_K_ROW_BWD : BDOF_K_ROW_FWD);
-    const int lds = conv_lds_bytes(c);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[BWD]) {
-        HIPC(c, hipFuncSetAttribute((const void*)k_conv<BWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        attr_set[BWD] = true;
+    switch ((c->taps.ks - 1) / 2) {           // register-window fast paths for the common kernel sizes 5, 9, 17, 33
+        case 2: return launch_conv_h<BWD, 2>(c, a);
+        case 4: return launch_conv_h<BWD, 4>(c, a);
+        case 8: return launch_conv_h<BWD, 8>(c, a);
+        case 16: return launch_conv_h<BWD, 16>(c, a);
+        default: return launch_conv_h<BWD, 0>(c, a);
     }
-    const int tiles = a.B * (a.NX / BDOF_CONV_TX) * (a.NY / BDOF_CONV_TY);
-    const int grid = balanced_grid(c, tiles, 2);
-    hipLaunchKernelGGL((k_conv<BWD>), dim3(grid), dim3(256), lds, c->stream, a);
-    return 0;
 }
 
 // forward sweep of the conv propagator; leaves psi_S (eps part) in bufB and the scalars in conv_scal

@@ -750,14 +750,35 @@ struct ConvArgs {
     ConvTaps taps;
 };
 
-template <bool BWD>
+// 1-D pass over a register window: thread owns R consecutive outputs and the R + 2H inputs they need, so every LDS
+// value is read once per R outputs instead of once per tap.
+template <bool BWD, int H, int R>
+__device__ __forceinline__ void conv_window(const cf (&win)[R + 2 * H], const float2* taps, cf (&out)[R]) {
+#pragma unroll
+    for (int o = 0; o < R; ++o) out[o] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int d = -H; d <= H; ++d) {
+        const cf w = taps[H + d];
+#pragma unroll
+        for (int o = 0; o < R; ++o) {
+            const cf f = win[o + H + (BWD ? d : -d)];
+            out[o] = cadd(out[o], BWD ? cmulc(f, w) : cmul(f, w));
+        }
+    }
+}
+
+// H = (ks - 1) / 2 as a template parameter (2, 4, 8, 16 instantiated; H = 0 selects the generic runtime-ks loops)
+template <bool BWD, int H>
 __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
-    constexpr int TX = BDOF_CONV_TX, TY = BDOF_CONV_TY;
-    const int h = (a.taps.ks - 1) / 2;
+    constexpr int TX = BDOF_CONV_TX, TY = BDOF_CONV_TY, R = 8;
+    const int h = H > 0 ? H : (a.taps.ks - 1) / 2;
     const int TXH = TX + 2 * h, TYH = TY + 2 * h;
+    // odd row strides: pass 1 runs with consecutive lanes on consecutive ROWS (each lane slides its own window along y),
+    // so the row stride in 8-byte slots must be odd for those lanes to hit distinct LDS banks
+    const int SA = TYH | 1, SM = TY + 1;
     extern __shared__ cf lds[];
-    cf* A = lds;                       // [TXH][TYH]
-    cf* M = lds + TXH * TYH;           // [TXH][TY]
+    cf* A = lds;                       // [TXH][SA]
+    cf* M = lds + TXH * SA;            // [TXH][SM]
     const int tiles_x = a.NX / TX, tiles_y = a.NY / TY;
     const int ntiles = a.B * tiles_x * tiles_y;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -770,46 +791,80 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
             const int x = x0 - h + i, y = y0 - h + j;
             const bool in = x >= 0 && x < a.NX && y >= 0 && y < a.NY;
             const cf v = src[(size_t)min(max(x, 0), a.NX - 1) * a.NY + min(max(y, 0), a.NY - 1)];
-            A[e] = in ? v : a.pad;
+            A[i * SA + j] = in ? v : a.pad;
         }
         __syncthreads();
         // pass along y.  forward: o[y] = sum_d K[h+d] f[y-d] ; backward: o[y] = sum_d conj(K[h+d]) g[y+d]
-        for (int e = threadIdx.x; e < TXH * TY; e += blockDim.x) {
-            const int i = e / TY, j = e - i * TY;
-            cf acc = make_float2(0.f, 0.f);
-            for (int d = -h; d <= h; ++d) {
-                const cf w = a.taps.ky[h + d];
-                const cf f = A[i * TYH + j + h + (BWD ? d : -d)];
-                acc = cadd(acc, BWD ? cmulc(f, w) : cmul(f, w));
+        if constexpr (H > 0) {
+            for (int t = threadIdx.x; t < TXH * (TY / R); t += blockDim.x) {
+                const int i = t % TXH, j0 = (t / TXH) * R;
+                cf win[R + 2 * H], o[R];
+#pragma unroll
+                for (int q = 0; q < R + 2 * H; ++q) win[q] = A[i * SA + j0 + q];
+                conv_window<BWD, H, R>(win, a.taps.ky, o);
+#pragma unroll
+                for (int q = 0; q < R; ++q) M[i * SM + j0 + q] = o[q];
             }
-            M[e] = acc;
+        } else {
+            for (int e = threadIdx.x; e < TXH * TY; e += blockDim.x) {
+                const int i = e / TY, j = e - i * TY;
+                cf acc = make_float2(0.f, 0.f);
+                for (int d = -h; d <= h; ++d) {
+                    const cf f = A[i * SA + j + h + (BWD ? d : -d)];
+                    acc = cadd(acc, BWD ? cmulc(f, a.taps.ky[h + d]) : cmul(f, a.taps.ky[h + d]));
+                }
+                M[i * SM + j] = acc;
+            }
         }
         __syncthreads();
-        // pass along x, then the pointwise physics
-        for (int e = threadIdx.x; e < TX * TY; e += blockDim.x) {
-            const int i = e / TY, j = e - i * TY;
-            cf acc = make_float2(0.f, 0.f);
-            for (int d = -h; d <= h; ++d) {
-                const cf w = a.taps.kx[h + d];
-                const cf f = M[(i + h + (BWD ? d : -d)) * TY + j];
-                acc = cadd(acc, BWD ? cmulc(f, w) : cmul(f, w));
-            }
-            acc = BWD ? cmulc(acc, a.taps.e) : cmul(acc, a.taps.e);
-            const int x = x0 + i, y = y0 + j;
-            const size_t off = ((size_t)b * a.NX + x) * a.NY + y;
-            float2 m1 = make_float2(0.f, 0.f);
-            if (a.zmod >= 0) {
-                const long long srow = obj_src_row(a.obj, b, x, a.zmod, a.NX);
-                const int yg = y + (a.obj.yoff ? a.obj.yoff[b] : 0);
-                if (srow >= 0 && yg >= 0 && yg < a.obj.volNY) m1 = a.obj.vol[(size_t)srow * a.obj.volNY + yg];
-            }
-            if constexpr (!BWD) {
-                a.out[off] = modulate_eps(acc, a.carrier, m1);          // phi_{z+1} = c_{z+1} psi_{z+1}  (eps part)
+        // pass along x (window of R consecutive x for one y), then the pointwise physics
+        for (int t = threadIdx.x; t < (TX / R) * TY; t += blockDim.x) {
+            const int i0 = (t / TY) * R, j = t % TY;
+            cf o[R];
+            if constexpr (H > 0) {
+                cf win[R + 2 * H];
+#pragma unroll
+                for (int q = 0; q < R + 2 * H; ++q) win[q] = M[(i0 + q) * SM + j];
+                conv_window<BWD, H, R>(win, a.taps.kx, o);
             } else {
-                const cf phi = cadd(a.tape[off], a.carrier);
-                const cf t = cmulc(acc, phi);                               // G(phi) conj(phi)
-                a.grot[(((size_t)b * a.obj.S + a.zmod) * a.NX + x) * a.NY + y] = make_float2(a.k * t.y, -a.k * t.x);
-                a.out[off] = cmulc(acc, make_float2(1.f + m1.x, m1.y));     // G(psi_z) = conj(c_z) G(phi_z)
+                for (int q = 0; q < R; ++q) {
+                    cf acc = make_float2(0.f, 0.f);
+                    for (int d = -h; d <= h; ++d) {
+                        const cf f = M[(i0 + q + h + (BWD ? d : -d)) * SM + j];
+                        acc = cadd(acc, BWD ? cmulc(f, a.taps.kx[h + d]) : cmul(f, a.taps.kx[h + d]));
+                    }
+                    o[q] = acc;
+                }
+            }
+            const int y = y0 + j;
+            const int yg = y + (a.obj.yoff ? a.obj.yoff[b] : 0);
+            const int yc = min(max(yg, 0), a.obj.volNY - 1);
+            // batch the dependent loads (row table -> modulation row, tape): issued as R independent requests each
+            long long srow[R];
+            float2 m1[R];
+            cf tp[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) srow[q] = a.zmod >= 0 ? obj_src_row(a.obj, b, x0 + i0 + q, a.zmod, a.NX) : -1;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                m1[q] = a.obj.vol[(size_t)(srow[q] >= 0 ? srow[q] : 0) * a.obj.volNY + yc];
+                if constexpr (BWD) tp[q] = a.tape[((size_t)b * a.NX + x0 + i0 + q) * a.NY + y];
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const cf acc = BWD ? cmulc(o[q], a.taps.e) : cmul(o[q], a.taps.e);
+                const int x = x0 + i0 + q;
+                const size_t off = ((size_t)b * a.NX + x) * a.NY + y;
+                const bool in = srow[q] >= 0 && yg == yc;
+                const float2 mm = make_float2(in ? m1[q].x : 0.f, in ? m1[q].y : 0.f);
+                if constexpr (!BWD) {
+                    a.out[off] = modulate_eps(acc, a.carrier, mm);          // phi_{z+1} = c_{z+1} psi_{z+1}  (eps part)
+                } else {
+                    const cf phi = cadd(tp[q], a.carrier);
+                    const cf tt = cmulc(acc, phi);                              // G(phi) conj(phi)
+                    a.grot[(((size_t)b * a.obj.S + a.zmod) * a.NX + x) * a.NY + y] = make_float2(a.k * tt.y, -a.k * tt.x);
+                    a.out[off] = cmulc(acc, make_float2(1.f + mm.x, mm.y));     // G(psi_z) = conj(c_z) G(phi_z)
+                }
             }
         }
         __syncthreads();
