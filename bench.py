@@ -47,8 +47,11 @@ def make_phantom(n, seed=3):
     return d, (0.1 * d).astype(np.float32)
 
 
-def cpu_baseline(size, n_slice, seed=11):
-    """Oracle (numpy restatement of np_funcs.py + adjoint) forward+adjoint on one host core."""
+def _cpu_sample(args):
+    """One worker of the CPU baseline: oracle forward + adjoint of one angle (numpy is single-threaded here)."""
+    size, n_slice, seed = args
+    for var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ[var] = '1'
     from oracle import bdof_oracle as orc
     rng = np.random.default_rng(seed)
     delta = rng.uniform(0, 2e-6, size=(1, size, size, n_slice))
@@ -57,12 +60,39 @@ def cpu_baseline(size, n_slice, seed=11):
     meas = np.ones((1, size, size))
     t0 = time.perf_counter()
     orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, 1e-4)
-    dt = time.perf_counter() - t0
-    return {'value': n_slice / dt, 'unit': 'slice-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': '{0}x{0} wavefield, {1} slices, 1 angle, fwd+adjoint, complex128 numpy ({2:.1f} s)'.format(size, n_slice, dt)}
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(size, n_slice, seed=11):
+    """The oracle (numpy restatement of np_funcs.py + its adjoint, complex128) timed on the host: one process per core,
+    one projection angle each — the reference's one-MPI-rank-per-core model (cnn_propagator/fullfield.py:343).
+    Workers are plain subprocesses of this file (`--cpu-worker`), killed after a deadline: they never touch the GPU."""
+    import subprocess
+    cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
+    env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(size), str(n_slice), str(seed + i)],
+                              stdout=subprocess.PIPE, env=env) for i in range(cores)]
+    times = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+            times.append(float(out.decode().strip().splitlines()[-1]))
+        except Exception:                      # noqa: BLE001  (deadline or a worker that died: drop it)
+            p.kill()
+    wall = time.perf_counter() - t0
+    if not times:
+        return None
+    return {'value': len(times) * n_slice / wall, 'unit': 'slice-steps/s', 'cores': len(times), 'kind': 'port',
+            'per_core_value': n_slice / (sum(times) / len(times)),
+            'sample': '{0}x{0} wavefield, {1} slices, fwd+adjoint, complex128 numpy; {2} processes x 1 angle in {3:.1f} s wall '
+                      '(incl. interpreter start)'.format(size, n_slice, len(times), wall)}
 
 
 def main():
+    if len(sys.argv) >= 5 and sys.argv[1] == '--cpu-worker':
+        print(_cpu_sample((int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -71,7 +101,7 @@ def main():
     ap.add_argument('--angles-per-gpu', type=int, default=25)
     ap.add_argument('--n-theta', type=int, default=200)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-slices', type=int, default=96)
+    ap.add_argument('--cpu-slices', type=int, default=192)
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--propagator', default='fft', choices=['fft', 'conv'],
                     help="'conv': the reference entry points' truncated real-space kernel (17 taps), for comparison")
