@@ -10,6 +10,9 @@
 
 #include "../../include/bdof.h"
 #include "bdof_kernels.h"
+#include "bdof_generic.h"
+#include <rocfft/rocfft.h>
+#include <map>
 
 #define BDOF_ERR_ARG (-1)
 #define BDOF_ERR_STATE (-2)
@@ -36,6 +39,12 @@ struct bdof_ctx {
     std::complex<double> ksum{1.0, 0.0};
     float k_conv = 0.f;
     cf *bufC = nullptr, *conv_scal = nullptr;
+    // generic-size engine (rocFFT): one plan pair per batch size
+    bool generic = false;
+    std::map<int, std::pair<rocfft_plan, rocfft_plan>> gplans;
+    rocfft_execution_info ginfo = nullptr;
+    void* gwork = nullptr;
+    size_t gwork_sz = 0;
     int det_mode = BDOF_DET_NONE, variant = BDOF_VARIANT_NUMPY_SKIP_LAST;
     bool have_physics = false, have_probe = false, tape_valid = false, last_valid = false;
     ObjView obj{};
@@ -265,6 +274,143 @@ static int ensure_modulation(bdof_ctx* c) {
     return 0;
 }
 
+
+// =================================================================================================
+// Generic-size engine (rocFFT).  Fields are real-space [b][x][y] in bufA; the tape holds phi_z.
+// =================================================================================================
+static bool g_rocfft_ready = false;
+
+#define RFC(c, call)                                                                                \
+    do {                                                                                            \
+        rocfft_status s_ = (call);                                                                  \
+        if (s_ != rocfft_status_success) return fail((c), BDOF_ERR_STATE, std::string(#call) + ": rocfft status " + std::to_string((int)s_)); \
+    } while (0)
+
+static int generic_plans(bdof_ctx* c, int B, rocfft_plan* fwd, rocfft_plan* inv) {
+    if (!g_rocfft_ready) { RFC(c, rocfft_setup()); g_rocfft_ready = true; }
+    auto it = c->gplans.find(B);
+    if (it == c->gplans.end()) {
+        const size_t lengths[2] = {(size_t)c->NY, (size_t)c->NX};      // fastest dimension first
+        rocfft_plan pf = nullptr, pi = nullptr;
+        RFC(c, rocfft_plan_create(&pf, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_single, 2, lengths, (size_t)B, nullptr));
+        RFC(c, rocfft_plan_create(&pi, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_single, 2, lengths, (size_t)B, nullptr));
+        size_t w1 = 0, w2 = 0;
+        RFC(c, rocfft_plan_get_work_buffer_size(pf, &w1));
+        RFC(c, rocfft_plan_get_work_buffer_size(pi, &w2));
+        const size_t need = std::max(w1, w2);
+        if (need > c->gwork_sz) {
+            HIPC(c, hipStreamSynchronize(c->stream));
+            if (c->gwork) (void)hipFree(c->gwork);
+            c->gwork = nullptr;
+            HIPC(c, hipMalloc(&c->gwork, need));
+            c->gwork_sz = need;
+        }
+        it = c->gplans.emplace(B, std::make_pair(pf, pi)).first;
+    }
+    if (!c->ginfo) {
+        RFC(c, rocfft_execution_info_create(&c->ginfo));
+        RFC(c, rocfft_execution_info_set_stream(c->ginfo, (void*)c->stream));
+    }
+    if (c->gwork_sz) RFC(c, rocfft_execution_info_set_work_buffer(c->ginfo, c->gwork, c->gwork_sz));
+    *fwd = it->second.first;
+    *inv = it->second.second;
+    return 0;
+}
+
+static int g_elem_grid(const bdof_ctx* c, size_t n) { return (int)std::min<size_t>((n + 255) / 256, (size_t)c->ncu * 16); }
+
+// one transfer-function step in place: field <- F^-1' ( h * F field )
+static int generic_prop(bdof_ctx* c, int B, rocfft_plan pf, rocfft_plan pi, cf* field, const cf* h, int conj_h) {
+    ProfScope ps(c, BDOF_K_COL_PROP);
+    void* buf[1] = {field};
+    RFC(c, rocfft_execute(pf, buf, nullptr, c->ginfo));
+    const size_t n = (size_t)B * c->NX * c->NY;
+    hipLaunchKernelGGL(k_g_hmul, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, field, h, B, c->NX, c->NY, conj_h);
+    RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo));
+    return 0;
+}
+
+// Forward sweep; leaves the field the detector starts from in bufA (eps part) and returns its carrier.
+static int generic_forward_sweep(bdof_ctx* c, int B, bool tape, rocfft_plan pf, rocfft_plan pi, std::complex<double>* carrier_out) {
+    const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+    const size_t n = (size_t)B * c->NX * c->NY;
+    const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
+    std::complex<double> a = c->a0;
+    int r;
+    for (int z = 0; z < c->S; ++z) {
+        {
+            ProfScope ps(c, BDOF_K_ROW_FWD);
+            GModArgs m{c->bufA, z == 0 ? c->probe : nullptr, tape ? c->tape + (size_t)z * fld : nullptr, c->obj, B, c->NX, c->NY, z,
+                       make_float2((float)a.real(), (float)a.imag())};
+            hipLaunchKernelGGL(k_g_modulate, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, m);
+        }
+        const bool last = z == c->S - 1;
+        if (!last || (tf_all && c->det_mode != BDOF_DET_FAR)) {
+            if ((r = generic_prop(c, B, pf, pi, c->bufA, c->hs, 0))) return r;
+            a *= c->h00;
+        }
+    }
+    if (c->det_mode == BDOF_DET_NEAR) {
+        if ((r = generic_prop(c, B, pf, pi, c->bufA, c->hdet, 0))) return r;
+        a *= c->hdet00;
+    } else if (c->det_mode == BDOF_DET_FAR) {
+        void* buf[1] = {c->bufA};
+        RFC(c, rocfft_execute(pf, buf, nullptr, c->ginfo));
+        a *= (double)c->NX * (double)c->NY;
+    }
+    *carrier_out = a;
+    return 0;
+}
+
+static int generic_forward(bdof_ctx* c, int B, void* out_wave, bool keep_tape) {
+    rocfft_plan pf, pi;
+    int r = generic_plans(c, B, &pf, &pi);
+    if (r) return r;
+    std::complex<double> a;
+    if ((r = generic_forward_sweep(c, B, keep_tape, pf, pi, &a))) return r;
+    if (out_wave) {
+        const size_t n = (size_t)B * c->NX * c->NY;
+        GLossArgs la{c->bufA, (cf*)out_wave, nullptr, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
+                     make_float2((float)a.real(), (float)a.imag()), 0.f};
+        hipLaunchKernelGGL(k_g_loss, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, la);
+    }
+    return 0;
+}
+
+static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wave) {
+    rocfft_plan pf, pi;
+    int r = generic_plans(c, B, &pf, &pi);
+    if (r) return r;
+    const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+    const size_t n = (size_t)B * c->NX * c->NY;
+    const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
+    std::complex<double> a;
+    if ((r = generic_forward_sweep(c, B, true, pf, pi, &a))) return r;
+    const int egrid = g_elem_grid(c, n);
+    {
+        ProfScope ps(c, BDOF_K_LOSS);
+        GLossArgs la{c->bufA, (cf*)out_wave, meas, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
+                     make_float2((float)a.real(), (float)a.imag()), 2.f / ((float)B * (float)c->NX * (float)c->NY)};
+        hipLaunchKernelGGL(k_g_loss, dim3(egrid), dim3(256), 0, c->stream, la);
+    }
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, egrid, 1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
+    // adjoint of the detector step: bufA now holds the seed G(d)
+    void* buf[1] = {c->bufA};
+    if (c->det_mode == BDOF_DET_NEAR) {
+        if ((r = generic_prop(c, B, pf, pi, c->bufA, c->hdet, 1))) return r;
+    } else if (c->det_mode == BDOF_DET_FAR) {
+        RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo));            // F^H = unnormalised inverse
+    }
+    for (int z = c->S - 1; z >= 0; --z) {
+        const bool prop_after = z < c->S - 1 || (tf_all && c->det_mode != BDOF_DET_FAR);
+        if (prop_after && (r = generic_prop(c, B, pf, pi, c->bufA, c->hs, 1))) return r;
+        ProfScope ps(c, BDOF_K_ROW_BWD);
+        GBwdArgs ba{c->bufA, c->tape + (size_t)z * fld, c->grot, c->obj, B, c->NX, c->NY, z, c->k, carrier_at(c, z)};
+        hipLaunchKernelGGL(k_g_bwd, dim3(egrid), dim3(256), 0, c->stream, ba);
+    }
+    return 0;
+}
+
 static int check_ready(bdof_ctx* c, int B) {
     if (!c) return BDOF_ERR_ARG;
     if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
@@ -306,7 +452,15 @@ int bdof_ctx_create(bdof_ctx** out, int device, void* stream) {
     return 0;
 }
 
+static void free_generic(bdof_ctx* c) {
+    for (auto& kv : c->gplans) { (void)rocfft_plan_destroy(kv.second.first); (void)rocfft_plan_destroy(kv.second.second); }
+    c->gplans.clear();
+    if (c->ginfo) { (void)rocfft_execution_info_destroy(c->ginfo); c->ginfo = nullptr; }
+    if (c->gwork) { (void)hipFree(c->gwork); c->gwork = nullptr; c->gwork_sz = 0; }
+}
+
 static void free_workspace(bdof_ctx* c) {
+    free_generic(c);
     void* ptrs[] = {c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->bufC = c->conv_scal = nullptr;
@@ -350,17 +504,20 @@ static int upload_twiddle(bdof_ctx* c, int N, cf** dst) {
 
 int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) {
     if (!c) return BDOF_ERR_ARG;
-    if (!supported_n(NY) || !supported_n(NX))
-        return fail(c, BDOF_ERR_SIZE, "NY and NX must be powers of two in [64, 1024]");
-    if (S < 1 || Bmax < 1) return fail(c, BDOF_ERR_ARG, "S and Bmax must be >= 1");
+    if (NY < 1 || NX < 1 || S < 1 || Bmax < 1) return fail(c, BDOF_ERR_ARG, "NY, NX, S and Bmax must be >= 1");
+    const bool generic = (with_grad & 2) != 0 || !supported_n(NY) || !supported_n(NX);
+    if (generic && (size_t)NY * NX > ((size_t)1 << 26)) return fail(c, BDOF_ERR_SIZE, "wavefield too large");
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipStreamSynchronize(c->stream));
     free_workspace(c);
-    c->NY = NY; c->NX = NX; c->S = S; c->Bmax = Bmax; c->with_grad = with_grad != 0;
+    c->NY = NY; c->NX = NX; c->S = S; c->Bmax = Bmax; c->with_grad = (with_grad & 1) != 0;
+    c->generic = generic;
     c->have_physics = c->have_probe = c->tape_valid = false;
     int r;
-    if ((r = upload_twiddle(c, NY, &c->twY))) return r;
-    if ((r = upload_twiddle(c, NX, &c->twX))) return r;
+    if (!generic) {
+        if ((r = upload_twiddle(c, NY, &c->twY))) return r;
+        if ((r = upload_twiddle(c, NX, &c->twX))) return r;
+    }
     const size_t fld = (size_t)Bmax * NX * NY;
     HIPC(c, hipMalloc((void**)&c->hs, sizeof(cf) * NX * NY));
     HIPC(c, hipMalloc((void**)&c->hdet, sizeof(cf) * NX * NY));
@@ -463,6 +620,13 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     if ((r = ensure_modulation(c))) return r;
+    if (c->generic) {
+        if (keep_tape) return fail(c, BDOF_ERR_STATE, "the per-slice history is not kept by the generic-size engine");
+        if ((r = generic_forward(c, B, out_wave, false))) return r;
+        c->tape_valid = c->last_valid = false;
+        HIPC(c, hipGetLastError());
+        return 0;
+    }
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
     forward_sweep(c, B, keep_tape ? TAPE_HISTORY : TAPE_NONE);
     c->tape_valid = keep_tape != 0;
@@ -515,6 +679,12 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     if ((r = ensure_modulation(c))) return r;
+    if (c->generic) {
+        if ((r = generic_loss_grad(c, B, meas, out_wave))) return r;
+        c->tape_valid = c->last_valid = false;
+        HIPC(c, hipGetLastError());
+        return 0;
+    }
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     const float NYf = (float)c->NY;
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
@@ -554,7 +724,8 @@ int bdof_set_conv(bdof_ctx* c, const float* ky, const float* kx, int ks, double 
     if (!c || !ky || !kx) return BDOF_ERR_ARG;
     if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
     if (ks < 1 || ks > BDOF_CONV_MAXK || ks % 2 == 0) return fail(c, BDOF_ERR_ARG, "kernel_size must be odd and <= 33");
-    if (c->NX % BDOF_CONV_TX || c->NY % BDOF_CONV_TY) return fail(c, BDOF_ERR_SIZE, "conv propagator tiles are 32 x 64");
+    if (c->generic || c->NX % BDOF_CONV_TX || c->NY % BDOF_CONV_TY)
+        return fail(c, BDOF_ERR_SIZE, "the conv propagator needs power-of-two wavefields (tiles are 32 x 64)");
     HIPC(c, hipSetDevice(c->device));
     for (int i = 0; i < ks; ++i) {
         c->taps.ky[i] = make_float2(ky[2 * i], ky[2 * i + 1]);
@@ -756,7 +927,7 @@ int bdof_rotation_adjoint(bdof_ctx* c, int B, const int* angle_of_b, void* gvol,
     if (!c->grot) return fail(c, BDOF_ERR_STATE, "no gradient workspace (configure with_grad=1)");
     if (!c->adj_off) return fail(c, BDOF_ERR_STATE, "bdof_set_rotation_adjoint has not been called");
     if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
-    if (c->NY % 2) return fail(c, BDOF_ERR_SIZE, "NY must be even");
+    if (c->NY % 2) return fail(c, BDOF_ERR_SIZE, "the rotation adjoint needs an even NY");
     HIPC(c, hipSetDevice(c->device));
     ProfScope ps(c, BDOF_K_ROT_ADJ);
     RotAdjArgs a{c->grot, (float2*)gvol, c->adj_off, c->adj_order, angle_of_b, B, c->S * c->NX, c->adj_ndest, c->NY, accumulate, scale,

@@ -1,0 +1,110 @@
+// Generic-size engine: any NY x NX (e.g. the 72 x 72 ptychography probe of cnn_propagator/reconstruct_ptycho.py:106).
+// The 2-D transforms are rocFFT's (batched, in place); everything else is the same physics as the fused engine written as
+// point-wise kernels on real-space fields [b][x][y] (frequency domain [b][kx][ky]).  Unfused, so it moves ~2.5x the bytes
+// of the fused row kernels — it exists for coverage of sizes without a hand-written plan and as an on-device cross-check.
+#pragma once
+#include "bdof_kernels.h"
+
+struct GModArgs {
+    cf* field;           // [B][NX][NY] eps part, updated in place
+    const cf* probe;     // nullable: [NX][NY] eps part of the probe (first slice: field is written, not read)
+    cf* tape;            // nullable: phi_z (eps part)
+    ObjView obj;
+    int B, NX, NY, z;
+    cf carrier;
+};
+
+__device__ __forceinline__ float2 g_mod_value(const ObjView& o, int b, int x, int y, int z, int NX) {
+    const long long srow = obj_src_row(o, b, x, z, NX);
+    const int yg = y + (o.yoff ? o.yoff[b] : 0);
+    const int yc = min(max(yg, 0), o.volNY - 1);
+    const float2 v = o.vol[(size_t)(srow >= 0 ? srow : 0) * o.volNY + yc];
+    const bool in = srow >= 0 && yg == yc;
+    return make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_g_modulate(GModArgs a) {
+    const size_t n = (size_t)a.B * a.NX * a.NY;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = idx % a.NY;
+        const size_t r = idx / a.NY;
+        const int x = r % a.NX, b = r / a.NX;
+        const cf e = a.probe ? a.probe[(size_t)x * a.NY + y] : a.field[idx];
+        const cf phi = modulate_eps(e, a.carrier, g_mod_value(a.obj, b, x, y, a.z, a.NX));
+        a.field[idx] = phi;
+        if (a.tape) a.tape[idx] = phi;
+    }
+}
+
+// field[b][kx][ky] *= h[ky][kx] (the transfer-function table is kept in the fused engine's [ky][kx] order)
+__global__ __launch_bounds__(256) void k_g_hmul(cf* field, const cf* h, int B, int NX, int NY, int conj_h) {
+    const size_t n = (size_t)B * NX * NY;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ky = idx % NY;
+        const int kx = (idx / NY) % NX;
+        cf t = h[(size_t)ky * NX + kx];
+        if (conj_h) t.y = -t.y;
+        field[idx] = cmul(field[idx], t);
+    }
+}
+
+struct GLossArgs {
+    cf* field;           // detector wave (eps part / far: un-shifted fft2), overwritten by the seed when meas != null
+    cf* out_wave;        // nullable; real detectors [b][x][y], far field [b][ky][kx]
+    const float* meas;   // nullable; same order as out_wave
+    double* partial;     // [2 * gridDim.x]
+    int B, NX, NY, far;
+    cf carrier;          // real detectors: added everywhere; far: added to the DC bin of every batch element
+    float seed_scale;
+};
+
+__global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
+    const size_t n = (size_t)a.B * a.NX * a.NY;
+    double acc = 0.0, acc2 = 0.0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = idx % a.NY;
+        const size_t r = idx / a.NY;
+        const int x = r % a.NX, b = r / a.NX;
+        cf d = a.field[idx];
+        if (!a.far || (x == 0 && y == 0)) d = cadd(d, a.carrier);
+        const size_t oidx = a.far ? ((size_t)b * a.NY + y) * a.NX + x : idx;
+        if (a.out_wave) a.out_wave[oidx] = d;
+        if (a.meas) a.field[idx] = loss_seed(d, a.meas[oidx], a.seed_scale, acc, acc2);
+    }
+    if (a.meas) {
+        __shared__ double w1[4], w2[4];
+        acc = wave_reduce_sum(acc);
+        acc2 = wave_reduce_sum(acc2);
+        if ((threadIdx.x & 63) == 0) { w1[threadIdx.x >> 6] = acc; w2[threadIdx.x >> 6] = acc2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            a.partial[2 * blockIdx.x] = w1[0] + w1[1] + w1[2] + w1[3];
+            a.partial[2 * blockIdx.x + 1] = w2[0] + w2[1] + w2[2] + w2[3];
+        }
+    }
+}
+
+struct GBwdArgs {
+    cf* g;               // G(phi_z) in, G(psi_z) out (in place)
+    const cf* tape;      // phi_z (eps part)
+    float2* grot;
+    ObjView obj;
+    int B, NX, NY, z;
+    float k;
+    cf carrier;
+};
+
+__global__ __launch_bounds__(256) void k_g_bwd(GBwdArgs a) {
+    const size_t n = (size_t)a.B * a.NX * a.NY;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = idx % a.NY;
+        const size_t r = idx / a.NY;
+        const int x = r % a.NX, b = r / a.NX;
+        const cf G = a.g[idx];
+        const cf phi = cadd(a.tape[idx], a.carrier);
+        const cf t = cmulc(G, phi);
+        a.grot[(((size_t)b * a.obj.S + a.z) * a.NX + x) * a.NY + y] = make_float2(a.k * t.y, -a.k * t.x);
+        const float2 m1 = g_mod_value(a.obj, b, x, y, a.z, a.NX);
+        a.g[idx] = cmulc(G, make_float2(1.f + m1.x, m1.y));
+    }
+}

@@ -20,13 +20,16 @@ def _idx_buf(ctx, values):
 class MultisliceEngine(object):
     """One wavefield geometry (NY x NX x S) on one GPU."""
 
-    def __init__(self, ny, nx, n_slice, batch_max, with_grad=True, device=0, stream=None):
+    def __init__(self, ny, nx, n_slice, batch_max, with_grad=True, device=0, stream=None, force_generic=False):
+        """Powers of two in 64..1024 run on the fused kernels, every other size on the generic engine (rocFFT);
+        force_generic=True sends any size there (on-device cross-check of the fused path)."""
         self.ctx = _lib.Context(device, stream)
         self.lib = self.ctx.lib
         self.h = self.ctx.handle
         self.ny, self.nx, self.n_slice, self.batch_max = int(ny), int(nx), int(n_slice), int(batch_max)
         self.with_grad = bool(with_grad)
-        self.ctx.check(self.lib.bdof_configure(self.h, self.ny, self.nx, self.n_slice, self.batch_max, int(with_grad)))
+        self.ctx.check(self.lib.bdof_configure(self.h, self.ny, self.nx, self.n_slice, self.batch_max,
+                                               int(bool(with_grad)) | (2 if force_generic else 0)))
         self.det_mode = _lib.DET_NONE
         self._keep = {}          # device buffers that must outlive the calls that registered them
         self._tables = None

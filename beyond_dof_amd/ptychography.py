@@ -2,9 +2,9 @@
 GPU.  Same keyword surface (unknown keywords ignored), `exchange/data` HDF5 of shape (n_theta, n_pos, py, px) read
 lazily per minibatch, same outputs.
 
-Differences: FFT propagator instead of the truncated real-space convolution; probe_size must be a
-supported FFT length (64 ... 1024, powers of two) — the reference drivers' 72 x 72 needs a radix-3 plan this round does
-not have and is rejected loudly; Q9 dynamic dropping is a no-op in the reference and is not run; the intermediate TIFF
+Differences: by default the FFT propagator instead of the truncated real-space convolution
+(propagator='conv' selects the latter for power-of-two probes); probe sizes that are powers of two (64 ... 1024) run on
+the fused kernels, any other size (the reference drivers' 72 x 72) on the rocFFT engine; Q9 dynamic dropping is a no-op in the reference and is not run; the intermediate TIFF
 is behind save_intermediate; n_epochs='auto' stops at max_nepochs.
 """
 import os

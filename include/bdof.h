@@ -38,8 +38,10 @@ const char* bdof_last_error(const bdof_ctx* ctx);
 int bdof_sync(bdof_ctx* ctx);
 int bdof_device_count(void);
 
-/* Workspace for wavefields of NY x NX (powers of two, 64..1024), S slices, up to Bmax wavefields per
- * launch.  with_grad != 0 also allocates the tape (S fields per wavefield) and the
+/* Workspace for wavefields of NY x NX, S slices, up to Bmax wavefields per launch.  Powers of two in 64..1024 run on the
+ * fused hand-written FFT kernels; every other size (e.g. the 72 x 72 probes of reconstruct_ptycho.py:106) runs on the
+ * generic-size engine (rocFFT + point-wise kernels), as does any size when bit 1 of with_grad is set (cross-checks).
+ * Bit 0 of with_grad also allocates the tape (S fields per wavefield) and the
  * rotated-frame gradient.  Replaces the per-call allocations of multislice_propagate_batch_numpy
  * (cnn_propagator/np_funcs.py:20,43) and of autograd's tape (cnn_propagator/fullfield.py:329). */
 int bdof_configure(bdof_ctx* ctx, int NY, int NX, int S, int Bmax, int with_grad);

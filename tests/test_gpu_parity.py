@@ -139,7 +139,7 @@ def test_edge_cases(engine_mod):
 def test_error_behaviour(engine_mod):
     from beyond_dof_amd import _lib
     with pytest.raises(_lib.BdofError):
-        engine_mod.MultisliceEngine(72, 72, 4, 1)                 # not a supported FFT length
+        engine_mod.MultisliceEngine(0, 64, 4, 1)                  # empty wavefield
     eng = engine_mod.MultisliceEngine(64, 64, 4, 2, with_grad=False)
     eng.set_physics(5000., 1e-7, None)
     eng.set_probe(np.ones((64, 64)), np.zeros((64, 64)))
