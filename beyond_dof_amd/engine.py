@@ -2,6 +2,7 @@
 array conventions ((B, Y, X, S) objects, (B, Y, X) waves, (Y, X, Z) volumes) and the device layout.
 All arithmetic of the hot path runs in libbdof.so; there is no CPU fallback."""
 import ctypes
+import os
 
 import numpy as np
 
@@ -29,7 +30,7 @@ class MultisliceEngine(object):
         self.ny, self.nx, self.n_slice, self.batch_max = int(ny), int(nx), int(n_slice), int(batch_max)
         self.with_grad = bool(with_grad)
         self.ctx.check(self.lib.bdof_configure(self.h, self.ny, self.nx, self.n_slice, self.batch_max,
-                                               int(bool(with_grad)) | (2 if force_generic else 0)))
+                                               int(bool(with_grad)) | (2 if (force_generic or os.environ.get('BDOF_FORCE_GENERIC')) else 0)))
         self.det_mode = _lib.DET_NONE
         self._keep = {}          # device buffers that must outlive the calls that registered them
         self._tables = None
