@@ -769,7 +769,7 @@ template <bool BWD, int H> static int launch_conv_h(bdof_ctx* c, ConvArgs& a) {
     }
     const int tiles = a.B * (a.NX / BDOF_CONV_TX) * (a.NY / BDOF_CONV_TY);
     const int grid = balanced_grid(c, tiles, 2);
-    hipLaunchKernelGGL((k_conv<BWD, H>), dim3(grid), dim3(256), lds, c->stream, a);
+    hipLaunchKernelGGL((k_conv<BWD, H>), dim3(grid), dim3(BDOF_CONV_THREADS), lds, c->stream, a);
     return 0;
 }
 

@@ -768,9 +768,11 @@ __device__ __forceinline__ void conv_window(const cf (&win)[R + 2 * H], const fl
 }
 
 // H = (ks - 1) / 2 as a template parameter (2, 4, 8, 16 instantiated; H = 0 selects the generic runtime-ks loops)
+#define BDOF_CONV_THREADS 512
 template <bool BWD, int H>
-__global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
-    constexpr int TX = BDOF_CONV_TX, TY = BDOF_CONV_TY, R = 8;
+__global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
+    // R outputs per thread in the y pass (384 windows per tile), R2 in the x pass (512 windows: every thread busy)
+    constexpr int TX = BDOF_CONV_TX, TY = BDOF_CONV_TY, R = 8, R2 = 4;
     const int h = H > 0 ? H : (a.taps.ks - 1) / 2;
     const int TXH = TX + 2 * h, TYH = TY + 2 * h;
     // odd row strides: pass 1 runs with consecutive lanes on consecutive ROWS (each lane slides its own window along y),
@@ -818,16 +820,16 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
         }
         __syncthreads();
         // pass along x (window of R consecutive x for one y), then the pointwise physics
-        for (int t = threadIdx.x; t < (TX / R) * TY; t += blockDim.x) {
-            const int i0 = (t / TY) * R, j = t % TY;
-            cf o[R];
+        for (int t = threadIdx.x; t < (TX / R2) * TY; t += blockDim.x) {
+            const int i0 = (t / TY) * R2, j = t % TY;
+            cf o[R2];
             if constexpr (H > 0) {
-                cf win[R + 2 * H];
+                cf win[R2 + 2 * H];
 #pragma unroll
-                for (int q = 0; q < R + 2 * H; ++q) win[q] = M[(i0 + q) * SM + j];
-                conv_window<BWD, H, R>(win, a.taps.kx, o);
+                for (int q = 0; q < R2 + 2 * H; ++q) win[q] = M[(i0 + q) * SM + j];
+                conv_window<BWD, H, R2>(win, a.taps.kx, o);
             } else {
-                for (int q = 0; q < R; ++q) {
+                for (int q = 0; q < R2; ++q) {
                     cf acc = make_float2(0.f, 0.f);
                     for (int d = -h; d <= h; ++d) {
                         const cf f = M[(i0 + q + h + (BWD ? d : -d)) * SM + j];
@@ -840,18 +842,18 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
             const int yg = y + (a.obj.yoff ? a.obj.yoff[b] : 0);
             const int yc = min(max(yg, 0), a.obj.volNY - 1);
             // batch the dependent loads (row table -> modulation row, tape): issued as R independent requests each
-            long long srow[R];
-            float2 m1[R];
-            cf tp[R];
+            long long srow[R2];
+            float2 m1[R2];
+            cf tp[R2];
 #pragma unroll
-            for (int q = 0; q < R; ++q) srow[q] = a.zmod >= 0 ? obj_src_row(a.obj, b, x0 + i0 + q, a.zmod, a.NX) : -1;
+            for (int q = 0; q < R2; ++q) srow[q] = a.zmod >= 0 ? obj_src_row(a.obj, b, x0 + i0 + q, a.zmod, a.NX) : -1;
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
+            for (int q = 0; q < R2; ++q) {
                 m1[q] = a.obj.vol[(size_t)(srow[q] >= 0 ? srow[q] : 0) * a.obj.volNY + yc];
                 if constexpr (BWD) tp[q] = a.tape[((size_t)b * a.NX + x0 + i0 + q) * a.NY + y];
             }
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
+            for (int q = 0; q < R2; ++q) {
                 const cf acc = BWD ? cmulc(o[q], a.taps.e) : cmul(o[q], a.taps.e);
                 const int x = x0 + i0 + q;
                 const size_t off = ((size_t)b * a.NX + x) * a.NY + y;
