@@ -213,13 +213,14 @@ __device__ __forceinline__ void line_fft_partial(cf (&u)[8], const FftTw<N>& tw,
     }
 }
 
-// The last stage (radix 8, p = N/8) for butterfly j of a line whose image is `lds`; the twiddles come
-// from the global table (exp(-2 pi i q / N)).  On exit u[q] is the output at position j + q*N/8.
+// The last stage (radix 8, p = N/8) for butterfly j of a line whose image is `lds`; `tail` is the LDS copy
+// [m-1][j] of the twiddles exp(-2 pi i m j / N) (fill_tail_table).  On exit u[q] is the output at position j + q*N/8.
 template <int N, int SIGN, class L>
-__device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* __restrict__ table) {
+__device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* tail) {
+    constexpr int T = N / 8;
     cf w[7];
 #pragma unroll
-    for (int m = 1; m < 8; ++m) w[m - 1] = table[m * j];
+    for (int m = 1; m < 8; ++m) w[m - 1] = tail[(m - 1) * T + j];
     stage_read<N, 8>(u, j, lds);
 #pragma unroll
     for (int m = 1; m < 8; ++m) {
@@ -228,4 +229,15 @@ __device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* 
         u[m] = cmul(u[m], t);
     }
     dft8<SIGN>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+}
+
+// tail[(m-1)*T + j] = table[m*j]: row per m, so that lanes with consecutive j read consecutive slots.
+// Must be called by every thread of the workgroup (ends with a barrier).
+template <int N> __device__ __forceinline__ void fill_tail_table(const cf* __restrict__ table, cf* tail) {
+    constexpr int T = N / 8;
+    for (int e = threadIdx.x; e < 7 * T; e += blockDim.x) {
+        const int m = e / T + 1, j = e - (m - 1) * T;
+        tail[e] = table[m * j];
+    }
+    __syncthreads();
 }

@@ -55,8 +55,7 @@ template <int T> struct RowLds {
 // Called by all threads between two workgroup barriers.
 // ---------------------------------------------------------------------------------------------
 template <int N, int SIGN>
-__device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, size_t ld, float scale,
-                                                const cf* __restrict__ table) {
+__device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, size_t ld, float scale, const cf* tail) {
     typedef RowCfg<N> C;
 #pragma nounroll
     for (int pass = 0; pass < C::PASSES; ++pass) {
@@ -64,7 +63,7 @@ __device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, 
         const int r = q % C::TILE, j = q / C::TILE;
         RowLds<C::T> lds{smem + r * C::RS};
         cf u[8];
-        last_stage<N, SIGN>(u, j, lds, table);
+        last_stage<N, SIGN>(u, j, lds, tail);
 #pragma unroll
         for (int m = 0; m < 8; ++m) dst[(size_t)(j + m * C::T) * ld + r] = cscale(u[m], scale);
     }
@@ -180,6 +179,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
     __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
     FftTw<NY> tw;
     tw.load(a.twiddle, tid, smem_tw);
+    __shared__ cf smem_tail[7 * C::T];
+    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
         }
         if constexpr (TSTORE) {
             __syncthreads();
-            transposed_tail<NY, -1>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, a.twiddle);
+            transposed_tail<NY, -1>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
             __syncthreads();
         }
     }
@@ -242,6 +243,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_pro
     __shared__ cf smem_tw[FftTw<NX>::LDS_CNT];
     FftTw<NX> tw;
     tw.load(a.twiddle, tid, smem_tw);
+    __shared__ cf smem_tail[7 * C::T];
+    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
     const int ntiles = a.B * a.NY / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_pro
             line_fft_partial<NX, +1>(u, tw, tid, lds);
         }
         __syncthreads();
-        transposed_tail<NX, +1>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, a.twiddle);
+        transposed_tail<NX, +1>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, smem_tail);
         __syncthreads();
     }
 }
@@ -335,6 +338,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
     __shared__ cf smem_tw[FftTw<N>::LDS_CNT];
     FftTw<N> tw;
     tw.load(a.twiddle, tid, smem_tw);
+    __shared__ cf smem_tail[7 * C::T];
+    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
     const int ntiles = a.B * a.R / C::TILE;
     double acc = 0.0, acc2 = 0.0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
         if constexpr (TSTORE) {
             if (a.out_hyb) {
                 __syncthreads();
-                transposed_tail<N, -S1>(smem, a.out_hyb + (size_t)b * N * a.R + r0, a.R, a.out_scale, a.twiddle);
+                transposed_tail<N, -S1>(smem, a.out_hyb + (size_t)b * N * a.R + r0, a.R, a.out_scale, smem_tail);
                 __syncthreads();
             }
         }
@@ -426,6 +431,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
     __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
     FftTw<NY> tw;
     tw.load(a.twiddle, tid, smem_tw);
+    __shared__ cf smem_tail[7 * C::T];
+    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -457,7 +464,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
         }
         if (a.gout) {
             __syncthreads();
-            transposed_tail<NY, -1>(smem, a.gout + (size_t)b * NY * a.NX + x0, a.NX, 1.f, a.twiddle);
+            transposed_tail<NY, -1>(smem, a.gout + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
             __syncthreads();
         }
     }
@@ -992,6 +999,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_rea
     __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
     FftTw<NY> tw;
     tw.load(a.twiddle, tid, smem_tw);
+    __shared__ cf smem_tail[7 * C::T];
+    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -1007,7 +1016,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_rea
             line_fft_partial<NY, -1>(u, tw, tid, lds);
         }
         __syncthreads();
-        transposed_tail<NY, -1>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, a.twiddle);
+        transposed_tail<NY, -1>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
         __syncthreads();
     }
 }
