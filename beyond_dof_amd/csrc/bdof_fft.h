@@ -83,9 +83,15 @@ template <int N> struct FftTw {
     const cf* mid;      // LDS table of the middle stages
 
     // table[j] = exp(-2 pi i j / N), j in [0, N).  Must be called by every thread of the workgroup.
-    __device__ __forceinline__ void load(const cf* __restrict__ table, int tid, cf* lds_mid) {
-#pragma unroll
-        for (int m = 1; m < 8; ++m) w[m - 1] = table[m * tid];
+    // lds_mid: LDS_CNT slots; lds_tail: 7*N/8 slots laid out [m-1][j] = table[m*j] (also the tail stage's twiddles):
+    // one cooperative fill, one barrier, and the per-lane last-stage factors are read back from LDS instead of being
+    // gathered from global memory by every wave (kernel start-up is amortised over only ~2 tiles per workgroup).
+    __device__ __forceinline__ void load(const cf* __restrict__ table, int tid, cf* lds_mid, cf* lds_tail) {
+        constexpr int T = N / 8;
+        for (int e = threadIdx.x; e < 7 * T; e += blockDim.x) {
+            const int m = e / T + 1, j = e - (m - 1) * T;
+            lds_tail[e] = table[m * j];
+        }
         for (int e = threadIdx.x; e < M1_CNT + M2_CNT; e += blockDim.x) {
             int k, m, step;
             if (e < M1_CNT) { k = e / D1; m = e % D1 + 1; step = N / (M1_P * M1_R); }
@@ -94,6 +100,8 @@ template <int N> struct FftTw {
         }
         mid = lds_mid;
         __syncthreads();
+#pragma unroll
+        for (int m = 1; m < 8; ++m) w[m - 1] = lds_tail[(m - 1) * T + tid];
     }
 };
 
@@ -229,15 +237,4 @@ __device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* 
         u[m] = cmul(u[m], t);
     }
     dft8<SIGN>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
-}
-
-// tail[(m-1)*T + j] = table[m*j]: row per m, so that lanes with consecutive j read consecutive slots.
-// Must be called by every thread of the workgroup (ends with a barrier).
-template <int N> __device__ __forceinline__ void fill_tail_table(const cf* __restrict__ table, cf* tail) {
-    constexpr int T = N / 8;
-    for (int e = threadIdx.x; e < 7 * T; e += blockDim.x) {
-        const int m = e / T + 1, j = e - (m - 1) * T;
-        tail[e] = table[m * j];
-    }
-    __syncthreads();
 }

@@ -178,9 +178,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
     FftTw<NY> tw;
-    tw.load(a.twiddle, tid, smem_tw);
     __shared__ cf smem_tail[7 * C::T];
-    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
+    tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -242,9 +241,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_pro
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     __shared__ cf smem_tw[FftTw<NX>::LDS_CNT];
     FftTw<NX> tw;
-    tw.load(a.twiddle, tid, smem_tw);
     __shared__ cf smem_tail[7 * C::T];
-    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
+    tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NY / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -337,9 +335,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     __shared__ cf smem_tw[FftTw<N>::LDS_CNT];
     FftTw<N> tw;
-    tw.load(a.twiddle, tid, smem_tw);
     __shared__ cf smem_tail[7 * C::T];
-    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
+    tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.R / C::TILE;
     double acc = 0.0, acc2 = 0.0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -430,9 +427,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
     FftTw<NY> tw;
-    tw.load(a.twiddle, tid, smem_tw);
     __shared__ cf smem_tail[7 * C::T];
-    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
+    tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -998,9 +994,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_rea
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
     FftTw<NY> tw;
-    tw.load(a.twiddle, tid, smem_tw);
     __shared__ cf smem_tail[7 * C::T];
-    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
+    tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;

@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
         CK(hipFree(ca)); CK(hipFree(cb));
     }
     const int tiles = B * N / RowCfg<N>::TILE;
-    for (int per_cu : {1, 2}) {
+    for (int per_cu : {2, 3, 4}) {
         const int grid = balanced(tiles, ncu * per_cu);
         printf("-- %d WG/CU cap, grid %d (tiles %d)\n", per_cu, grid, tiles);
         {

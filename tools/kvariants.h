@@ -11,9 +11,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void kv_prop(R
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     __shared__ cf smem_tw[FftTw<NX>::LDS_CNT];
     FftTw<NX> tw;
-    tw.load(a.twiddle, tid, smem_tw);
     __shared__ cf smem_tail[7 * C::T];
-    fill_tail_table<C::T * 8>(a.twiddle, smem_tail);
+    tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NY / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
