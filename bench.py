@@ -174,20 +174,31 @@ def main():
         px = mb * n * n
         roof = None
         if prof:
+            # A batch may run as `groups` sub-batches on concurrent streams (bdof_set_streams): every per-slice launch
+            # then carries 1/groups of the batch and shares the chip with the same launch of the other groups, so the
+            # chip-wide rate of the kernel is groups x (bytes of one launch / its duration).  Both figures are reported.
+            groups = solver.eng.batch_groups(mb)
             per_class = {}
             for name, bpp in BYTES_PER_PX.items():
                 cnt, ms = prof[name]
                 if cnt:
-                    npx = px * (S if name == 'rot_adjoint' else 1)
-                    per_class[name] = {'timed_launches': cnt, 'avg_ms': ms / cnt, 'GBps': bpp * npx / (ms / cnt * 1e-3) / 1e9}
+                    g = 1 if name == 'rot_adjoint' else groups
+                    nbytes = bpp * px * (S if name == 'rot_adjoint' else 1) / g
+                    per_class[name] = {'timed_launches': cnt, 'avg_ms': ms / cnt, 'bytes_per_launch': nbytes,
+                                       'concurrent_launches': g, 'GBps_one_launch': nbytes / (ms / cnt * 1e-3) / 1e9,
+                                       'GBps': g * nbytes / (ms / cnt * 1e-3) / 1e9}
             launches_per_step = {'row_fwd': S, 'col_prop': 2 * S, 'row_bwd': S, 'rot_adjoint': 1}
-            dom = max(per_class, key=lambda k: per_class[k]['avg_ms'] * launches_per_step[k])
+            dom = max(per_class, key=lambda k: per_class[k]['avg_ms'] * launches_per_step[k] * (1 if k == 'rot_adjoint' else groups))
             ach = per_class[dom]['GBps']
             tb = pmc_traffic(dom, n, mb)
+            g = per_class[dom]['concurrent_launches']
             roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': ach * 1e9 / HBM_PEAK,
-                    'traffic': None if tb is None else tb / (per_class[dom]['avg_ms'] * 1e-3) / 1e9,
-                    'traffic_bytes_per_launch': tb, 'algorithmic_bytes_per_launch': BYTES_PER_PX[dom] * px * (S if dom == 'rot_adjoint' else 1),
+                    'traffic': None if tb is None else g * tb / (per_class[dom]['avg_ms'] * 1e-3) / 1e9,
+                    'concurrent_launches': g,
+                    'note': 'achieved = concurrent_launches x algorithmic bytes of one launch / its average duration'
+                            if g > 1 else 'achieved = algorithmic bytes of one launch / its average duration',
+                    'traffic_bytes_per_launch': tb, 'algorithmic_bytes_per_launch': per_class[dom]['bytes_per_launch'],
                     'traffic_source': 'profiles/r01_pmc_traffic_bench.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE x1)' if tb else None,
                     'per_kernel': per_class,
                     'whole_step_frac': 104.0 * n * n * (slice_steps / world) / elapsed / HBM_PEAK}

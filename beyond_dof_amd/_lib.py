@@ -42,6 +42,8 @@ _SIGNATURES = {
     'bdof_adam_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
                        + [ctypes.c_float] * 8 + [ctypes.c_int, ctypes.c_int]),
     'bdof_mask_shrink': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_float]),
+    'bdof_set_streams': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'bdof_batch_groups': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_profile_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_profile_read': (ctypes.c_int, [_vp, ctypes.c_int, _c_int_p, ctypes.POINTER(ctypes.c_double)]),
     'bdof_malloc': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <complex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,10 +19,17 @@
 #define BDOF_ERR_STATE (-2)
 #define BDOF_ERR_SIZE (-3)
 
+#define BDOF_MAX_GROUPS 4
 struct bdof_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // dual-stream split of a batch (see batch_groups): the sub-batch the launchers currently work on
+    hipStream_t side[BDOF_MAX_GROUPS - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[BDOF_MAX_GROUPS - 1] = {};
+    int n_streams = -1;                          // -1 auto (1 or 2), else the number of groups to split a batch in
+    int sub_b0 = 0, sub_part = 0;
+    hipStream_t sub_stream = nullptr;
     int ncu = 256;
     int NY = 0, NX = 0, S = 0, Bmax = 0;
     bool with_grad = false;
@@ -118,11 +126,11 @@ struct ProfScope {
         }
         idx = c->ev_next;
         c->ev_next += 2;
-        (void)hipEventRecord(c->ev_pool[idx], c->stream);
+        (void)hipEventRecord(c->ev_pool[idx], c->sub_stream ? c->sub_stream : c->stream);
     }
     ~ProfScope() {
         if (!on) return;
-        (void)hipEventRecord(c->ev_pool[idx + 1], c->stream);
+        (void)hipEventRecord(c->ev_pool[idx + 1], c->sub_stream ? c->sub_stream : c->stream);
         c->ev_used.emplace_back(cls, (int)idx);
     }
 };
@@ -161,19 +169,79 @@ template <int N> static int rows_grid(const bdof_ctx* c, int B, int R) {
         default: break;                                        \
     }
 
+// ---- sub-batches --------------------------------------------------------------------------------
+// A batch whose tile count fills the chip's workgroup slots badly (25 wavefields of 512 rows = 800 tiles on 512 slots:
+// every launch runs as two rounds at 78 % occupancy) is split in two groups that run the same kernel sequence on two
+// streams: the groups have no dependencies on each other, so one group's kernels fill the slots the other leaves idle
+// and the per-launch round quantisation disappears.  Launchers address the current group through c->sub_*.
+struct Group { int b0, B; hipStream_t st; };
+
+static int batch_groups(bdof_ctx* c, int B, int rows_per_b, int tile, Group (&g)[BDOF_MAX_GROUPS]) {
+    g[0] = Group{0, B, c->stream};
+    const int slots = c->ncu * 2;
+    const long tiles = (long)B * rows_per_b / tile;
+    const long rounds = (tiles + slots - 1) / slots;
+    const double util = (double)tiles / (double)(rounds * slots);
+    int n = c->n_streams;
+    (void)util;
+    if (n < 0) n = (B >= 4 && tiles >= slots) ? 2 : 1;      // measured: +3..12 % from 512 tiles up, a loss below
+    if (n > BDOF_MAX_GROUPS) n = BDOF_MAX_GROUPS;
+    if (n > B) n = B;
+    if (n <= 1) return 1;
+    for (int i = 0, b0 = 0; i < n; ++i) {
+        const int Bg = B / n + (i < B % n ? 1 : 0);
+        g[i] = Group{b0, Bg, i == 0 ? c->stream : c->side[i - 1]};
+        b0 += Bg;
+    }
+    return n;
+}
+static void use_group(bdof_ctx* c, const Group& g, int part_off = 0) {
+    c->sub_b0 = g.b0;
+    c->sub_stream = g.st;
+    c->sub_part = part_off;
+}
+static void use_whole(bdof_ctx* c) { c->sub_b0 = 0; c->sub_stream = c->stream; c->sub_part = 0; }
+static int fork_streams(bdof_ctx* c, int ngroups) {
+    if (ngroups < 2) return 0;
+    HIPC(c, hipEventRecord(c->ev_fork, c->stream));
+    for (int i = 1; i < ngroups; ++i) HIPC(c, hipStreamWaitEvent(c->side[i - 1], c->ev_fork, 0));
+    return 0;
+}
+static int join_streams(bdof_ctx* c, int ngroups) {
+    use_whole(c);
+    for (int i = 1; i < ngroups; ++i) {
+        HIPC(c, hipEventRecord(c->ev_join[i - 1], c->side[i - 1]));
+        HIPC(c, hipStreamWaitEvent(c->stream, c->ev_join[i - 1], 0));
+    }
+    return 0;
+}
+
+static ObjView sub_obj(const bdof_ctx* c) {
+    ObjView o = c->obj;
+    const int b0 = c->sub_b0;
+    if (b0) {
+        if (o.tab) { o.angle_of_b += b0; }
+        else { o.vol += (size_t)b0 * c->S * c->NX * o.volNY; }
+        if (o.xoff) o.xoff += b0;
+        if (o.yoff) o.yoff += b0;
+    }
+    return o;
+}
+template <class T> static T* sub_field(const bdof_ctx* c, T* p) { return p ? p + (size_t)c->sub_b0 * c->NX * c->NY : p; }
+
 // A_z: L1 (or the probe) -> L2 (tstore) or L1 (plain)
 static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore, cf* phi_out = nullptr) {
     ProfScope ps(c, BDOF_K_ROW_FWD);
-    RowFwdArgs a{in, c->probe, out, phi_out, c->obj, B, c->NX, z, c->k, carrier_at(c, z), c->twY};
+    RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), sub_field(c, phi_out), sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY};
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
         if (z == 0) {
-            if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, true, true>), grid, blk, 0, c->stream, a);
-            else hipLaunchKernelGGL((k_row_fwd<N_, true, false>), grid, blk, 0, c->stream, a);
+            if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, true, true>), grid, blk, 0, c->sub_stream, a);
+            else hipLaunchKernelGGL((k_row_fwd<N_, true, false>), grid, blk, 0, c->sub_stream, a);
         } else {
-            if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, false, true>), grid, blk, 0, c->stream, a);
-            else hipLaunchKernelGGL((k_row_fwd<N_, false, false>), grid, blk, 0, c->stream, a);
+            if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, false, true>), grid, blk, 0, c->sub_stream, a);
+            else hipLaunchKernelGGL((k_row_fwd<N_, false, false>), grid, blk, 0, c->sub_stream, a);
         }
     });
 }
@@ -181,18 +249,19 @@ static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, boo
 // B: L2 -> L1
 static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf* h, float scale, int conj_h) {
     ProfScope ps(c, BDOF_K_COL_PROP);
-    RowPropArgs a{in, out, h, B, c->NY, scale, conj_h, c->twX};
+    RowPropArgs a{sub_field(c, in), sub_field(c, out), h, B, c->NY, scale, conj_h, c->twX};
     DISPATCH_N(c->NX, {
-        hipLaunchKernelGGL((k_row_prop<N_>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((k_row_prop<N_>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
     });
 }
 
 // A'_z: L1 (g) + phi tape -> L2 (g)
 static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout) {
     ProfScope ps(c, BDOF_K_ROW_BWD);
-    RowBwdArgs a{gin, tape, gout, c->grot, c->obj, B, c->NX, z, c->k, carrier_at(c, z), c->twY};
+    RowBwdArgs a{sub_field(c, gin), sub_field(c, tape), sub_field(c, gout), c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY, sub_obj(c),
+                 B, c->NX, z, c->k, carrier_at(c, z), c->twY};
     DISPATCH_N(c->NY, {
-        hipLaunchKernelGGL((k_row_bwd<N_>), dim3(rows_grid<N_>(c, B, c->NX)), dim3(BDOF_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((k_row_bwd<N_>), dim3(rows_grid<N_>(c, B, c->NX)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
     });
 }
 
@@ -200,12 +269,13 @@ static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* t
 static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool tstore, cf* out_wave, const float* meas,
                             float in_scale, float out_scale, float seed_scale, cf carrier) {
     ProfScope ps(c, BDOF_K_LOSS);
-    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NX, in_scale, out_scale, seed_scale, carrier, c->twY};
+    LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NX,
+               in_scale, out_scale, seed_scale, carrier, c->twY};
     int grid = 0;
     DISPATCH_N(c->NY, {
         grid = rows_grid<N_>(c, B, c->NX);
-        if (tstore) hipLaunchKernelGGL((k_row_loss<N_, false, true>), dim3(grid), dim3(BDOF_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_row_loss<N_, false, false>), dim3(grid), dim3(BDOF_THREADS), 0, c->stream, a);
+        if (tstore) hipLaunchKernelGGL((k_row_loss<N_, false, true>), dim3(grid), dim3(BDOF_THREADS), 0, c->sub_stream, a);
+        else hipLaunchKernelGGL((k_row_loss<N_, false, false>), dim3(grid), dim3(BDOF_THREADS), 0, c->sub_stream, a);
     });
     return grid;
 }
@@ -214,11 +284,12 @@ static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool 
 static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* out_wave, const float* meas, float in_scale,
                            float out_scale, float seed_scale) {
     ProfScope ps(c, BDOF_K_LOSS);
-    LossArgs a{in, out_hyb, out_wave, meas, c->partial, B, c->NY, in_scale, out_scale, seed_scale, carrier_det(c), c->twX};
+    LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NY,
+               in_scale, out_scale, seed_scale, carrier_det(c), c->twX};
     int grid = 0;
     DISPATCH_N(c->NX, {
         grid = rows_grid<N_>(c, B, c->NY);
-        hipLaunchKernelGGL((k_row_loss<N_, true, true>), dim3(grid), dim3(BDOF_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((k_row_loss<N_, true, true>), dim3(grid), dim3(BDOF_THREADS), 0, c->sub_stream, a);
     });
     return grid;
 }
@@ -234,7 +305,7 @@ static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* ou
 enum { TAPE_NONE = 0, TAPE_HISTORY = 1, TAPE_PHI = 2 };
 // TAPE_HISTORY keeps psi_hat_{z+1} (the transfer-function step's output) per slice: probe_array of np_funcs.py:43.
 // TAPE_PHI keeps the real-space phi_z written by A_z: what the adjoint needs, without a third transform in A'_z.
-static void forward_sweep(bdof_ctx* c, int B, int tape_mode) {
+static void forward_sweep(bdof_ctx* c, const Group* groups, int ngroups, int tape_mode) {
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
     for (int z = 0; z < c->S; ++z) {
@@ -242,15 +313,19 @@ static void forward_sweep(bdof_ctx* c, int B, int tape_mode) {
         if (z > 0) in = tape_mode == TAPE_HISTORY ? c->tape + (size_t)(z - 1) * fld : c->bufB;
         cf* phi = tape_mode == TAPE_PHI ? c->tape + (size_t)z * fld : nullptr;
         const bool last = z == c->S - 1;
-        if (!last) {
-            launch_row_fwd(c, B, z, in, c->bufA, true, phi);
-            launch_row_prop(c, B, c->bufA, tape_mode == TAPE_HISTORY ? c->tape + (size_t)z * fld : c->bufB, c->hs, 1.f, 0);
-        } else if (c->det_mode == BDOF_DET_NONE && !tf_all) {
-            launch_row_fwd(c, B, z, in, c->bufA, false, phi);
-        } else {
-            launch_row_fwd(c, B, z, in, c->bufA, true, phi);
-            if (c->det_mode == BDOF_DET_NONE) launch_row_prop(c, B, c->bufA, c->bufB, c->hs, 1.f, 0);
-            else if (c->det_mode == BDOF_DET_NEAR) launch_row_prop(c, B, c->bufA, c->bufB, tf_all ? c->hcomb : c->hdet, 1.f, 0);
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const int B = groups[gi].B;
+            use_group(c, groups[gi]);
+            if (!last) {
+                launch_row_fwd(c, B, z, in, c->bufA, true, phi);
+                launch_row_prop(c, B, c->bufA, tape_mode == TAPE_HISTORY ? c->tape + (size_t)z * fld : c->bufB, c->hs, 1.f, 0);
+            } else if (c->det_mode == BDOF_DET_NONE && !tf_all) {
+                launch_row_fwd(c, B, z, in, c->bufA, false, phi);
+            } else {
+                launch_row_fwd(c, B, z, in, c->bufA, true, phi);
+                if (c->det_mode == BDOF_DET_NONE) launch_row_prop(c, B, c->bufA, c->bufB, c->hs, 1.f, 0);
+                else if (c->det_mode == BDOF_DET_NEAR) launch_row_prop(c, B, c->bufA, c->bufB, tf_all ? c->hcomb : c->hdet, 1.f, 0);
+            }
         }
     }
 }
@@ -448,6 +523,13 @@ int bdof_ctx_create(bdof_ctx** out, int device, void* stream) {
         if (e != hipSuccess) { delete c; return (int)e; }
         c->own_stream = true;
     }
+    (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    for (int i = 0; i < BDOF_MAX_GROUPS - 1; ++i) {
+        (void)hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
+    }
+    c->sub_stream = c->stream;
+    if (const char* e = std::getenv("BDOF_STREAMS")) c->n_streams = std::atoi(e);
     *out = c;
     return 0;
 }
@@ -478,6 +560,11 @@ void bdof_ctx_destroy(bdof_ctx* c) {
     if (c->heavy) (void)hipFree(c->heavy);
     if (c->mod) (void)hipFree(c->mod);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < BDOF_MAX_GROUPS - 1; ++i) {
+        if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -628,7 +715,11 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
         return 0;
     }
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
-    forward_sweep(c, B, keep_tape ? TAPE_HISTORY : TAPE_NONE);
+    Group groups[BDOF_MAX_GROUPS];
+    const int ng = batch_groups(c, B, c->NX, 16, groups);
+    if ((r = fork_streams(c, ng))) return r;
+    forward_sweep(c, groups, ng, keep_tape ? TAPE_HISTORY : TAPE_NONE);
+    if ((r = join_streams(c, ng))) return r;
     c->tape_valid = keep_tape != 0;
     c->last_valid = false;
     if (out_wave) {
@@ -688,29 +779,40 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     const float NYf = (float)c->NY;
     const bool tf_all = c->variant == BDOF_VARIANT_TF_ALL;
-    forward_sweep(c, B, TAPE_PHI);
+    Group groups[BDOF_MAX_GROUPS];
+    const int ng = batch_groups(c, B, c->NX, 16, groups);
+    if ((r = fork_streams(c, ng))) return r;
+    forward_sweep(c, groups, ng, TAPE_PHI);
     c->tape_valid = false;      // the tape now holds phi_z, not the per-slice history
     c->last_valid = false;
     const float seed_scale = 2.f / ((float)B * (float)c->NX * (float)c->NY);
     int npart = 0;
     // Detector + seed.  Afterwards bufB holds g_hat(phi_{S-1}) (L1 order, normalised hybrid).
-    if (c->det_mode == BDOF_DET_FAR) {
-        npart = launch_loss_far(c, B, c->bufA, c->bufB, (cf*)out_wave, meas, 1.f, 1.f, seed_scale);
-    } else if (c->det_mode == BDOF_DET_NONE && !tf_all) {
-        npart = launch_loss_real(c, B, c->bufA, c->bufB, false, (cf*)out_wave, meas, 1.f / NYf, 1.f / NYf, seed_scale, carrier_det(c));
-    } else {
-        // the detector wave came out of a transfer-function step: seed -> R (transposed) -> adjoint step
-        const cf* h = c->det_mode == BDOF_DET_NONE ? c->hs : (tf_all ? c->hcomb : c->hdet);
-        npart = launch_loss_real(c, B, c->bufB, c->bufA, true, (cf*)out_wave, meas, 1.f, 1.f, seed_scale, carrier_det(c));
-        launch_row_prop(c, B, c->bufA, c->bufB, h, 1.f, 1);
+    for (int gi = 0; gi < ng; ++gi) {
+        const int Bg = groups[gi].B;
+        use_group(c, groups[gi], npart);
+        if (c->det_mode == BDOF_DET_FAR) {
+            npart += launch_loss_far(c, Bg, c->bufA, c->bufB, (cf*)out_wave, meas, 1.f, 1.f, seed_scale);
+        } else if (c->det_mode == BDOF_DET_NONE && !tf_all) {
+            npart += launch_loss_real(c, Bg, c->bufA, c->bufB, false, (cf*)out_wave, meas, 1.f / NYf, 1.f / NYf, seed_scale, carrier_det(c));
+        } else {
+            // the detector wave came out of a transfer-function step: seed -> R (transposed) -> adjoint step
+            const cf* h = c->det_mode == BDOF_DET_NONE ? c->hs : (tf_all ? c->hcomb : c->hdet);
+            npart += launch_loss_real(c, Bg, c->bufB, c->bufA, true, (cf*)out_wave, meas, 1.f, 1.f, seed_scale, carrier_det(c));
+            launch_row_prop(c, Bg, c->bufA, c->bufB, h, 1.f, 1);
+        }
     }
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, npart,
-                       1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
     // backward sweep: A'_z (L1 -> L2), then the adjoint transfer-function step (L2 -> L1)
     for (int z = c->S - 1; z >= 0; --z) {
-        launch_row_bwd(c, B, z, c->bufB, c->tape + (size_t)z * fld, z > 0 ? c->bufA : nullptr);
-        if (z > 0) launch_row_prop(c, B, c->bufA, c->bufB, c->hs, 1.f, 1);
+        for (int gi = 0; gi < ng; ++gi) {
+            use_group(c, groups[gi]);
+            launch_row_bwd(c, groups[gi].B, z, c->bufB, c->tape + (size_t)z * fld, z > 0 ? c->bufA : nullptr);
+            if (z > 0) launch_row_prop(c, groups[gi].B, c->bufA, c->bufB, c->hs, 1.f, 1);
+        }
     }
+    if ((r = join_streams(c, ng))) return r;
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, npart,
+                       1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -987,6 +1089,20 @@ int bdof_mask_shrink(bdof_ctx* c, const void* x, float* mask, size_t n, float th
     hipLaunchKernelGGL(k_mask_shrink, dim3(grid), dim3(256), 0, c->stream, (const float2*)x, mask, n, thresh);
     HIPC(c, hipGetLastError());
     return 0;
+}
+
+int bdof_set_streams(bdof_ctx* c, int n) {
+    if (!c) return -1;
+    if (n == 0 || n > BDOF_MAX_GROUPS) return fail(c, -2, "bdof_set_streams: n must be -1 or 1..4");
+    c->n_streams = n < 0 ? -1 : n;
+    return 0;
+}
+
+int bdof_batch_groups(bdof_ctx* c, int B) {
+    if (!c || B < 1 || !c->NX) return -1;
+    if (c->generic) return 1;
+    Group g[BDOF_MAX_GROUPS];
+    return batch_groups(c, B, c->NX, 16, g);
 }
 
 int bdof_profile_enable(bdof_ctx* c, int enable) {

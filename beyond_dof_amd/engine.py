@@ -185,6 +185,13 @@ class MultisliceEngine(object):
                                                lr, b1, b2, eps, int(i_batch), int(clip)))
 
     # ---- profiling -----------------------------------------------------------------------------
+    def set_streams(self, n=-1):
+        """Number of concurrent sub-batches of the fused FFT engine (-1: automatic, see include/bdof.h)."""
+        self.ctx.check(self.lib.bdof_set_streams(self.h, int(n)))
+
+    def batch_groups(self, B):
+        return int(self.lib.bdof_batch_groups(self.h, int(B)))
+
     def profile_enable(self, on=True, stride=1):
         self.ctx.check(self.lib.bdof_profile_enable(self.h, int(stride) if on else 0))
 

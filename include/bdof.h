@@ -122,7 +122,15 @@ int bdof_adam_step(bdof_ctx* ctx, const void* x_old, void* x_new, const void* g,
 /* Shrink-wrap (cnn_propagator/fullfield.py:365-368): mask[i] *= (delta[i] > thresh) over n voxels. */
 int bdof_mask_shrink(bdof_ctx* ctx, const void* x, float* mask, size_t n, float thresh);
 
-/* Per-kernel-class timing with HIP events on the ctx stream (bench.py roofline leg).  enable = 0 off, 1 every launch,
+/* Sub-batch streams of the fused FFT engine.  A batch whose tiles (B*NX/16 workgroups per launch) cover at least the
+ * chip's resident workgroup slots is split in groups that run the same kernel sequence concurrently on side streams
+ * (no dependencies between wavefields of one minibatch: fullfield.py:95-103 is a plain loop over the batch), so the
+ * partly filled last round of one launch is covered by the other group's kernels.  n = -1 automatic (1 or 2 groups),
+ * 1..4 fixed.  bdof_batch_groups returns the number of groups a batch of B wavefields runs as. */
+int bdof_set_streams(bdof_ctx* ctx, int n);
+int bdof_batch_groups(bdof_ctx* ctx, int B);
+
+/* Per-kernel-class timing with HIP events on the stream of each launch (bench.py roofline leg).  enable = 0 off, 1 every launch,
  * n > 1 every n-th launch of the per-slice kernel classes (two event records per launch cost ~9 us of stream time). */
 int bdof_profile_enable(bdof_ctx* ctx, int enable);
 int bdof_profile_read(bdof_ctx* ctx, int kernel_class, int* n_launches, double* total_ms);
