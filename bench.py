@@ -109,6 +109,12 @@ def main():
                     help='HIP-event time every n-th launch of the per-slice kernels (each timed launch costs ~9 us of stream time)')
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: native libraries that print there (RCCL's version banner does) are sent to
+    # stderr by pointing fd 1 at fd 2 for the rest of the run; the JSON line goes to a private copy of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -215,7 +221,8 @@ def main():
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n, args.cpu_slices)
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + '\n')
+        real_stdout.flush()
     sys.stdout.flush()
     comm.close()
 

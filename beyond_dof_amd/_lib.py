@@ -2,6 +2,7 @@
 missing or no GPU is present, using the product path raises."""
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -23,6 +24,7 @@ _SIGNATURES = {
     'bdof_ctx_destroy': (None, [_vp]),
     'bdof_last_error': (ctypes.c_char_p, [_vp]),
     'bdof_sync': (ctypes.c_int, [_vp]),
+    'bdof_stream': (_vp, [_vp]),
     'bdof_device_count': (ctypes.c_int, []),
     'bdof_configure': (ctypes.c_int, [_vp] + [ctypes.c_int] * 5),
     'bdof_set_physics': (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
@@ -38,9 +40,12 @@ _SIGNATURES = {
     'bdof_get_loss': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double)]),
     'bdof_grot': (_vp, [_vp]),
     'bdof_rotation_adjoint': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float]),
+    'bdof_rotation_adjoint_rows': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]),
     'bdof_window_rotation_adjoint': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_float]),
     'bdof_adam_step': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
                        + [ctypes.c_float] * 8 + [ctypes.c_int, ctypes.c_int]),
+    'bdof_adam_step_slab': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+                            + [ctypes.c_float] * 8 + [ctypes.c_int] * 4),
     'bdof_mask_shrink': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_float]),
     'bdof_set_streams': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_batch_groups': (ctypes.c_int, [_vp, ctypes.c_int]),
@@ -62,6 +67,9 @@ class BdofError(RuntimeError):
     pass
 
 
+TORCH_FIRST = False
+
+
 def load():
     """Load libbdof.so (build it with `python -c "import __graft_entry__ as g; g.build()"`)."""
     global _lib
@@ -69,6 +77,21 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise BdofError('HIP extension not built: {} is missing (run __graft_entry__.build())'.format(LIB_PATH))
+    # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's, requested under another file name): whichever of
+    # torch and libbdof.so is loaded first decides which HIP runtime the process gets, and when libbdof.so comes first
+    # torch loads a SECOND runtime that cannot see the GPU.  Whenever the process is going to use torch.distributed
+    # (multi-rank launch, or the switches below) torch is therefore imported before the library.
+    global TORCH_FIRST
+    # more hardware queues than HIP's default of 4, so that the sub-batch streams (include/bdof.h, bdof_set_streams) are not
+    # folded onto a queue shared with torch's / RCCL's streams; only effective if the HIP runtime is not initialised yet
+    # (the library checks by measurement which of its streams really run concurrently).
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    if 'torch' in sys.modules:
+        TORCH_FIRST = True
+    elif (int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('BDOF_FORCE_TORCH_COMM')
+          or os.environ.get('BDOF_PRELOAD_TORCH')):
+        import torch  # noqa: F401
+        TORCH_FIRST = True
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)

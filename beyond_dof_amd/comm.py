@@ -24,6 +24,11 @@ class PseudoComm(object):
     def allreduce_sum_host(self, arr):
         return arr
 
+    def pipelined_allreduce(self, buf, bounds, produce, consume, stream_ptr=0, lookahead=2):
+        for c in range(len(bounds) - 1):
+            produce(c)
+            consume(c)
+
     def bcast_host(self, arr, root=0):
         return arr
 
@@ -35,6 +40,10 @@ class TorchComm(object):
     """torch.distributed group.  Device buffers are all-reduced in place through RCCL."""
 
     def __init__(self, backend=None):
+        from . import _lib
+        if backend != 'gloo' and _lib._lib is not None and not _lib.TORCH_FIRST and _lib._lib.bdof_device_count() > 0:
+            raise RuntimeError('libbdof.so was loaded before torch: the process would hold two HIP runtimes and torch could '
+                               'not see the GPU.  Import torch first, or set BDOF_PRELOAD_TORCH=1 (WORLD_SIZE > 1 does it).')
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -78,6 +87,35 @@ class TorchComm(object):
         if t.is_cuda:
             self.torch.cuda.current_stream().synchronize()
         return buf
+
+    def pipelined_allreduce(self, buf, bounds, produce, consume, stream_ptr=0, lookahead=2):
+        """Slab-wise SUM all-reduce of `buf` overlapped with its producer and consumer.  For slab c (flat element range
+        bounds[c]:bounds[c+1]): produce(c) enqueues the kernels that fill it on the HIP stream `stream_ptr`; the slab is
+        then all-reduced asynchronously (RCCL's stream is ordered after the producer through the current-stream
+        semantics of torch.distributed); consume(c) is enqueued on the same stream, behind a stream-side wait for the
+        collective, `lookahead` slabs later — so the producer of slab c+1.. and the consumer of slab c-2.. run while slab
+        c is on the wire.  No host synchronisation.  CPU tensors (gloo): the same sequence, synchronously."""
+        torch, dist = self.torch, self.dist
+        t = self.as_tensor(buf).view(-1)
+        n = len(bounds) - 1
+        if not t.is_cuda:
+            for c in range(n):
+                produce(c)
+                dist.all_reduce(t[bounds[c]:bounds[c + 1]], op=dist.ReduceOp.SUM)
+                consume(c)
+            return
+        stream = torch.cuda.ExternalStream(stream_ptr) if stream_ptr else torch.cuda.current_stream()
+        works = []
+        with torch.cuda.stream(stream):
+            for c in range(n):
+                produce(c)
+                works.append(dist.all_reduce(t[bounds[c]:bounds[c + 1]], op=dist.ReduceOp.SUM, async_op=True))
+                if c >= lookahead:
+                    works[c - lookahead].wait()
+                    consume(c - lookahead)
+            for c in range(max(0, n - lookahead), n):
+                works[c].wait()
+                consume(c)
 
     def allreduce_sum_host(self, arr):
         t = self.torch.from_numpy(np.ascontiguousarray(arr))

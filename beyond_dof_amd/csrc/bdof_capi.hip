@@ -25,7 +25,9 @@ struct bdof_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // dual-stream split of a batch (see batch_groups): the sub-batch the launchers currently work on
-    hipStream_t side[BDOF_MAX_GROUPS - 1] = {};
+    hipStream_t side[BDOF_MAX_GROUPS - 1] = {};   // side streams PROVEN to run concurrently with the ctx stream (probe_side_streams)
+    int n_side = -1;                             // -1: not probed yet
+    std::vector<hipStream_t> side_all;           // every candidate created (kept until the ctx dies)
     hipEvent_t ev_fork = nullptr, ev_join[BDOF_MAX_GROUPS - 1] = {};
     int n_streams = -1;                          // -1 auto (1 or 2), else the number of groups to split a batch in
     int sub_b0 = 0, sub_part = 0;
@@ -176,17 +178,64 @@ template <int N> static int rows_grid(const bdof_ctx* c, int B, int R) {
 // and the per-launch round quantisation disappears.  Launchers address the current group through c->sub_*.
 struct Group { int b0, B; hipStream_t st; };
 
+// HIP maps streams onto a small pool of hardware queues (4 per process by default, GPU_MAX_HW_QUEUES): two streams that
+// share a queue run their kernels one after the other, and which streams collide depends on every other stream in the
+// process (torch's, RCCL's ...).  Splitting a batch over two such streams only adds launches.  So side streams are
+// admitted by measurement: a 200-us spin kernel on each of two streams takes ~200 us when they overlap, ~400 when not.
+__global__ void k_spin(long long ticks, int* sink) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {}
+    if (sink && ticks < 0) *sink = 1;
+}
+
+static bool streams_overlap(bdof_ctx* c, hipStream_t a, hipStream_t b) {
+    hipEvent_t e0, e1, ef, ej;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return false;
+    (void)hipEventCreateWithFlags(&ef, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+    const long long ticks = 20000;                 // wall_clock64 counts at 100 MHz: 200 us
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {            // the first round also pays the lazy creation of the queues
+        (void)hipEventRecord(e0, a);
+        (void)hipEventRecord(ef, a);
+        (void)hipStreamWaitEvent(b, ef, 0);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, ticks, (int*)nullptr);
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, ticks, (int*)nullptr);
+        (void)hipEventRecord(ej, b);
+        (void)hipStreamWaitEvent(a, ej, 0);
+        (void)hipEventRecord(e1, a);
+        if (hipStreamSynchronize(a) != hipSuccess) { best = 1e30f; break; }
+        float ms = 1e30f;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(ef); (void)hipEventDestroy(ej);
+    (void)c;
+    return best < 0.3f;                            // 0.2 ms when concurrent, 0.4 ms when serialised
+}
+
+static void probe_side_streams(bdof_ctx* c) {
+    c->n_side = 0;
+    for (int cand = 0; cand < 8 && c->n_side < BDOF_MAX_GROUPS - 1; ++cand) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        c->side_all.push_back(s);
+        bool ok = streams_overlap(c, c->stream, s);
+        for (int i = 0; ok && i < c->n_side; ++i) ok = streams_overlap(c, c->side[i], s);
+        if (ok) c->side[c->n_side++] = s;
+    }
+}
+
 static int batch_groups(bdof_ctx* c, int B, int rows_per_b, int tile, Group (&g)[BDOF_MAX_GROUPS]) {
     g[0] = Group{0, B, c->stream};
     const int slots = c->ncu * 2;
     const long tiles = (long)B * rows_per_b / tile;
-    const long rounds = (tiles + slots - 1) / slots;
-    const double util = (double)tiles / (double)(rounds * slots);
     int n = c->n_streams;
-    (void)util;
     if (n < 0) n = (B >= 4 && tiles >= slots) ? 2 : 1;      // measured: +3..12 % from 512 tiles up, a loss below
     if (n > BDOF_MAX_GROUPS) n = BDOF_MAX_GROUPS;
     if (n > B) n = B;
+    if (n <= 1) return 1;
+    if (c->n_side < 0) probe_side_streams(c);
+    if (n > 1 + c->n_side) n = 1 + c->n_side;
     if (n <= 1) return 1;
     for (int i = 0, b0 = 0; i < n; ++i) {
         const int Bg = B / n + (i < B % n ? 1 : 0);
@@ -524,10 +573,7 @@ int bdof_ctx_create(bdof_ctx** out, int device, void* stream) {
         c->own_stream = true;
     }
     (void)hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    for (int i = 0; i < BDOF_MAX_GROUPS - 1; ++i) {
-        (void)hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking);
-        (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
-    }
+    for (int i = 0; i < BDOF_MAX_GROUPS - 1; ++i) (void)hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming);
     c->sub_stream = c->stream;
     if (const char* e = std::getenv("BDOF_STREAMS")) c->n_streams = std::atoi(e);
     *out = c;
@@ -560,10 +606,9 @@ void bdof_ctx_destroy(bdof_ctx* c) {
     if (c->heavy) (void)hipFree(c->heavy);
     if (c->mod) (void)hipFree(c->mod);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
-    for (int i = 0; i < BDOF_MAX_GROUPS - 1; ++i) {
-        if (c->side[i]) { (void)hipStreamSynchronize(c->side[i]); (void)hipStreamDestroy(c->side[i]); }
+    for (hipStream_t s : c->side_all) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    for (int i = 0; i < BDOF_MAX_GROUPS - 1; ++i)
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
-    }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1024,23 +1069,31 @@ int bdof_get_loss(bdof_ctx* c, double* loss) {
 
 void* bdof_grot(bdof_ctx* c) { return c ? (void*)c->grot : nullptr; }
 
-int bdof_rotation_adjoint(bdof_ctx* c, int B, const int* angle_of_b, void* gvol, int accumulate, float scale) {
+int bdof_rotation_adjoint_rows(bdof_ctx* c, int B, const int* angle_of_b, void* gvol, int row0, int n_rows, int accumulate,
+                               float scale) {
     if (!c || !gvol || !angle_of_b) return BDOF_ERR_ARG;
     if (!c->grot) return fail(c, BDOF_ERR_STATE, "no gradient workspace (configure with_grad=1)");
     if (!c->adj_off) return fail(c, BDOF_ERR_STATE, "bdof_set_rotation_adjoint has not been called");
     if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
     if (c->NY % 2) return fail(c, BDOF_ERR_SIZE, "the rotation adjoint needs an even NY");
+    if (row0 < 0 || n_rows < 0 || (long long)row0 + n_rows > c->adj_ndest) return fail(c, BDOF_ERR_ARG, "destination rows outside the volume");
+    if (n_rows == 0) return 0;
     HIPC(c, hipSetDevice(c->device));
     ProfScope ps(c, BDOF_K_ROT_ADJ);
     RotAdjArgs a{c->grot, (float2*)gvol, c->adj_off, c->adj_order, angle_of_b, B, c->S * c->NX, c->adj_ndest, c->NY, accumulate, scale,
-                 c->heavy, c->heavy + 1};
+                 c->heavy, c->heavy + 1, row0, row0 + n_rows};
     HIPC(c, hipMemsetAsync(c->heavy, 0, sizeof(int), c->stream));
-    int need = (c->adj_ndest + 3) / 4;
+    int need = (n_rows + 3) / 4;
     int grid = need < c->ncu * 8 ? need : c->ncu * 8;
     hipLaunchKernelGGL(k_rot_adjoint, dim3(grid), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(k_rot_adjoint_heavy, dim3(c->ncu * 8), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;
+}
+
+int bdof_rotation_adjoint(bdof_ctx* c, int B, const int* angle_of_b, void* gvol, int accumulate, float scale) {
+    if (!c) return BDOF_ERR_ARG;
+    return bdof_rotation_adjoint_rows(c, B, angle_of_b, gvol, 0, c->adj_ndest, accumulate, scale);
 }
 
 int bdof_window_rotation_adjoint(bdof_ctx* c, int B, int angle, const int* xoff, const int* yoff, void* gvol,
@@ -1061,25 +1114,36 @@ int bdof_window_rotation_adjoint(bdof_ctx* c, int B, int angle, const int* xoff,
     return 0;
 }
 
-int bdof_adam_step(bdof_ctx* c, const void* x_old, void* x_new, const void* g, void* m, void* v, const float* mask,
-                   int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
-                   float lr, float b1, float b2, float eps, int i_batch, int clip) {
+int bdof_adam_step_slab(bdof_ctx* c, const void* x_old, void* x_new, const void* g, void* m, void* v, const float* mask,
+                        int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
+                        float lr, float b1, float b2, float eps, int i_batch, int clip, int x0, int nx) {
     if (!c || !x_old || !x_new || !g || !m || !v) return BDOF_ERR_ARG;
     if (x_old == x_new) return fail(c, BDOF_ERR_ARG, "x_new must not alias x_old (the TV stencil reads pre-update neighbours)");
     if (NXv < 1 || NZv < 1 || NYv < 1 || i_batch < 0) return fail(c, BDOF_ERR_ARG, "bad volume shape / i_batch");
+    if (x0 < 0 || nx < 0 || (long long)x0 + nx > NXv) return fail(c, BDOF_ERR_ARG, "slab outside the volume");
+    if (nx == 0) return 0;
     HIPC(c, hipSetDevice(c->device));
     ProfScope ps(c, BDOF_K_ADAM);
     const double bc1 = 1.0 - std::pow((double)b1, (double)(i_batch + 1));
     const double bc2 = 1.0 - std::pow((double)b2, (double)(i_batch + 1));
     AdamArgs a{(const float2*)x_old, (float2*)x_new, (const float2*)g, (float2*)m, (float2*)v, mask, NXv, NZv, NYv,
-               g_scale, alpha_d, alpha_b, gamma, lr, b1, b2, eps, (float)(1.0 / bc1), (float)(1.0 / bc2), clip};
-    const size_t n = (size_t)NXv * NZv * NYv;
+               g_scale, alpha_d, alpha_b, gamma, lr, b1, b2, eps, (float)(1.0 / bc1), (float)(1.0 / bc2), clip, x0, x0 + nx};
+    const size_t n = (size_t)nx * NZv * NYv;
     size_t need = (n + 255) / 256;
     int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
     hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;
 }
+
+int bdof_adam_step(bdof_ctx* c, const void* x_old, void* x_new, const void* g, void* m, void* v, const float* mask,
+                   int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
+                   float lr, float b1, float b2, float eps, int i_batch, int clip) {
+    return bdof_adam_step_slab(c, x_old, x_new, g, m, v, mask, NXv, NZv, NYv, g_scale, alpha_d, alpha_b, gamma, lr, b1, b2, eps,
+                               i_batch, clip, 0, NXv);
+}
+
+void* bdof_stream(bdof_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int bdof_mask_shrink(bdof_ctx* c, const void* x, float* mask, size_t n, float thresh) {
     if (!c || !x || !mask) return BDOF_ERR_ARG;

@@ -483,6 +483,7 @@ struct RotAdjArgs {
     float scale;
     int* heavy_count;         // device counter (zeroed before the launch)
     int* heavy_rows;          // [n_dest] destination rows whose source list does not fit a wave's LDS list
+    int d0, d1;               // destination rows handled by this launch: [d0, d1)
 };
 
 #define BDOF_ROTADJ_MAXLIST 256      // per wave; longer lists (clamped border rows) take the direct path
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256) void k_rot_adjoint(RotAdjArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int* list = lists[wave];
     const int nv = a.NY / 2;                    // float4 = two (delta,beta) pairs
-    for (int d = blockIdx.x * 4 + wave; d < a.n_dest; d += gridDim.x * 4) {
+    for (int d = a.d0 + blockIdx.x * 4 + wave; d < a.d1; d += gridDim.x * 4) {
         int total = 0;
         for (int b0 = 0; b0 < a.B; b0 += 64) {
             const int b = b0 + lane;
@@ -630,13 +631,15 @@ struct AdamArgs {
     float alpha_d, alpha_b, gamma;
     float lr, b1, b2, eps, inv_bc1, inv_bc2;   // inv_bc = 1 / (1 - b^(i_batch+1))
     int clip;              // max(x, 0)
+    int x0, x1;            // slab of the volume updated by this launch: x in [x0, x1)  (the stencil reads beyond it)
 };
 
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) - (v < 0.f); }
 
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
-    const size_t n = (size_t)a.NXv * a.NZv * a.NYv;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    const size_t slab = (size_t)a.NZv * a.NYv;
+    const size_t n = (size_t)a.x1 * slab;
+    for (size_t idx = (size_t)a.x0 * slab + (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const int y = idx % a.NYv;
         const size_t r = idx / a.NYv;
         const int z = r % a.NZv;

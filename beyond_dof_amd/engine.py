@@ -178,11 +178,16 @@ class MultisliceEngine(object):
         self.ctx.sync()
 
     def adam_step(self, x_old, x_new, g, m, v, mask, shape_xzy, i_batch, lr, g_scale=1.0, alpha_d=0.0, alpha_b=0.0,
-                  gamma=0.0, b1=0.9, b2=0.999, eps=1e-8, clip=True):
+                  gamma=0.0, b1=0.9, b2=0.999, eps=1e-8, clip=True, slab=None):
+        """slab = (x0, nx): update only that range of x-planes (pipelined with the gradient all-reduce)."""
         nxv, nzv, nyv = [int(s) for s in shape_xzy]
-        self.ctx.check(self.lib.bdof_adam_step(self.h, _lib._ptr(x_old), _lib._ptr(x_new), _lib._ptr(g), _lib._ptr(m),
-                                               _lib._ptr(v), _lib._ptr(mask), nxv, nzv, nyv, g_scale, alpha_d, alpha_b, gamma,
-                                               lr, b1, b2, eps, int(i_batch), int(clip)))
+        x0, nx = (0, nxv) if slab is None else (int(slab[0]), int(slab[1]))
+        self.ctx.check(self.lib.bdof_adam_step_slab(self.h, _lib._ptr(x_old), _lib._ptr(x_new), _lib._ptr(g), _lib._ptr(m),
+                                                    _lib._ptr(v), _lib._ptr(mask), nxv, nzv, nyv, g_scale, alpha_d, alpha_b,
+                                                    gamma, lr, b1, b2, eps, int(i_batch), int(clip), x0, nx))
+
+    def stream_ptr(self):
+        return int(self.lib.bdof_stream(self.h) or 0)
 
     # ---- profiling -----------------------------------------------------------------------------
     def set_streams(self, n=-1):

@@ -36,6 +36,7 @@ int bdof_ctx_create(bdof_ctx** out, int device, void* stream);
 void bdof_ctx_destroy(bdof_ctx* ctx);
 const char* bdof_last_error(const bdof_ctx* ctx);
 int bdof_sync(bdof_ctx* ctx);
+void* bdof_stream(bdof_ctx* ctx);   /* the ctx's hipStream_t, for ordering foreign work (collectives) against it */
 int bdof_device_count(void);
 
 /* Workspace for wavefields of NY x NX, S slices, up to Bmax wavefields per launch.  Powers of two in 64..1024 run on the
@@ -105,6 +106,11 @@ void* bdof_grot(bdof_ctx* ctx);      /* device [B][S][NX][NY] pairs */
 /* Adjoint of the rotation gather: gvol[dest][y] (+)= scale * sum over the batch of the rows gathered
  * from dest.  gvol: device [n_dest][NY] pairs. */
 int bdof_rotation_adjoint(bdof_ctx* ctx, int B, const int* angle_of_b, void* gvol, int accumulate, float scale);
+/* The same for destination rows [row0, row0 + n_rows) only (gvol is still the base of the whole gradient volume): lets
+ * the host pipeline rotation adjoint -> all-reduce -> Adam slab by slab, hiding them behind the collective
+ * (comm.Allreduce(this_grads, grads), cnn_propagator/fullfield.py:348-351). */
+int bdof_rotation_adjoint_rows(bdof_ctx* ctx, int B, const int* angle_of_b, void* gvol, int row0, int n_rows, int accumulate,
+                               float scale);
 
 /* Ptychography: adjoint of rotate + zero-pad + per-position window (cnn_propagator/ptychography.py:32-34,42-73) for a
  * batch whose elements all use rotation angle `angle` and windows at (xoff[b], yoff[b]); gvol: device [n_dest][volNY] pairs. */
@@ -118,6 +124,10 @@ int bdof_window_rotation_adjoint(bdof_ctx* ctx, int B, int angle, const int* xof
 int bdof_adam_step(bdof_ctx* ctx, const void* x_old, void* x_new, const void* g, void* m, void* v, const float* mask,
                    int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
                    float lr, float b1, float b2, float eps, int i_batch, int clip);
+/* The same for the slab x in [x0, x0 + nx) of the [X][Z][Y] volume (all pointers are still those of the whole volume). */
+int bdof_adam_step_slab(bdof_ctx* ctx, const void* x_old, void* x_new, const void* g, void* m, void* v, const float* mask,
+                        int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
+                        float lr, float b1, float b2, float eps, int i_batch, int clip, int x0, int nx);
 
 /* Shrink-wrap (cnn_propagator/fullfield.py:365-368): mask[i] *= (delta[i] > thresh) over n voxels. */
 int bdof_mask_shrink(bdof_ctx* ctx, const void* x, float* mask, size_t n, float thresh);

@@ -87,3 +87,71 @@ def test_reconstruct_fullfield_end_to_end(tmp_path, monkeypatch):
     l1 = s.loss_and_grad(sched[0])
     assert l1 < l0
     assert os.path.exists(os.path.join('case', 'out2', 'intermediate', 'current.tiff'))
+
+
+class _LoopbackComm(object):
+    """One rank that still runs the reduce branch of FullfieldSolver.step (through PseudoComm's slab loop)."""
+    size, rank, local_rank, always_reduce = 1, 0, 0, True
+
+    def __init__(self):
+        from beyond_dof_amd.comm import PseudoComm
+        self._p = PseudoComm()
+        self.calls = []
+
+    def pipelined_allreduce(self, buf, bounds, produce, consume, stream_ptr=0, lookahead=2):
+        self.calls.append(list(bounds))
+        return self._p.pipelined_allreduce(buf, bounds, produce, consume, stream_ptr, lookahead)
+
+
+def _two_steps(solver, sched, **kw):
+    solver.reset_moments()
+    for i, idx in enumerate(sched):
+        solver.step(i, idx, 1e-7, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11, **kw)
+    return solver.get_volume()
+
+
+def _slab_case(comm, check_calls=False):
+    from beyond_dof_amd.solver import FullfieldSolver
+    rng = np.random.default_rng(1)
+    n, n_theta, mb = 64, 8, 4
+    coords = orc.rotation_lookup([n, n, n], n_theta)
+    meas = 1 + 0.05 * rng.normal(size=(n_theta, n, n))
+    init_d = np.clip(rng.normal(8.7e-7, 1e-7, size=(n, n, n)), 0, None)
+    sched = [np.arange(0, 4), np.arange(4, 8)]
+    vols = []
+    for n_slabs, c in ((1, None), (5, comm), (64, comm)):
+        s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, coord_ls=coords, comm=c)
+        s.set_measurements(meas)
+        s.set_volume(init_d, 0.1 * init_d)
+        vols.append(_two_steps(s, sched, n_slabs=n_slabs))
+    for v in vols[1:]:
+        assert np.array_equal(v[0], vols[0][0]) and np.array_equal(v[1], vols[0][1])
+    assert not np.array_equal(vols[0][0], init_d)
+
+
+def test_slab_pipelined_step_is_bit_identical():
+    """rotation adjoint -> all-reduce -> Adam, slab by slab (FullfieldSolver.step with more than one rank), gives the very
+    same volume as the whole-volume sequence (loop-back comm: the slab kernels and their ordering)."""
+    import __graft_entry__ as entry
+    entry.build()
+    comm = _LoopbackComm()
+    _slab_case(comm)
+    assert len(comm.calls) == 4 and len(comm.calls[0]) == 6 and len(comm.calls[-1]) == 65
+
+
+def test_slab_pipelined_step_through_rccl():
+    """The same through torch.distributed / RCCL on one rank: asynchronous all-reduce per slab, ordered against the ctx
+    stream without host synchronisation.  Runs in a child process: torch has to be loaded before libbdof.so
+    (beyond_dof_amd/_lib.py), which this process can no longer guarantee."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import sys; sys.path.insert(0, {0!r}); sys.path.insert(0, {1!r})\n'
+            'import test_gpu_fullfield as t\n'
+            'from beyond_dof_amd.comm import TorchComm\n'
+            'c = TorchComm("nccl"); assert c.always_reduce\n'
+            't._slab_case(c); c.close(); print("SLAB_RCCL_OK")\n').format(root, os.path.join(root, 'tests'))
+    env = dict(os.environ, BDOF_FORCE_TORCH_COMM='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1',
+               LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b'SLAB_RCCL_OK' in r.stdout, r.stdout.decode()[-3000:]

@@ -115,7 +115,8 @@ def test_sub_batch_streams_are_bit_identical(engine_mod, fp, variant):
     base = None
     for n in (1, 2, 3, 4):
         eng.set_streams(n)
-        assert eng.batch_groups(B) == n
+        groups = eng.batch_groups(B)           # side streams are admitted by a concurrency probe: at most n
+        assert 1 <= groups <= n and (n < 2 or groups >= 2)
         wave = eng.forward(B)
         loss = eng.loss_grad(B, meas)
         gd, gb = eng.grad_batch_to_host(B)
