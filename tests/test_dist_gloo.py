@@ -47,6 +47,25 @@ def _worker(rank, world, port, out_dir):
     g = torch.from_numpy(np.stack([gd, gb]))
     comm.allreduce_sum_device(g)
     g = g.numpy() / comm.size
+    # the slab pipeline of FullfieldSolver.step: produce slab c, all-reduce it, consume it — same result, fixed order
+    g2 = torch.zeros(g.size, dtype=torch.float64)
+    src = torch.from_numpy(np.stack([gd, gb])).reshape(-1)
+    bounds = [0, 100, 101, 700, g2.numel()]
+    log, seen = [], []
+
+    def produce(c):
+        log.append(('p', c))
+        g2[bounds[c]:bounds[c + 1]] = src[bounds[c]:bounds[c + 1]]
+
+    def consume(c):
+        log.append(('c', c))
+        seen.append(g2[bounds[c]:bounds[c + 1]].clone())
+
+    comm.pipelined_allreduce(g2, bounds, produce, consume)
+    assert [e for e in log if e[0] == 'p'] == [('p', c) for c in range(4)]
+    assert [e for e in log if e[0] == 'c'] == [('c', c) for c in range(4)]
+    assert all(log.index(('p', c)) < log.index(('c', c)) for c in range(4))
+    assert np.array_equal(torch.cat(seen).numpy() / comm.size, g.reshape(-1))
     loss_sum = comm.allreduce_sum_host(np.array([float(rank + 1)]))
     idx = comm.bcast_host(np.arange(4) if rank == 0 else np.zeros(4, dtype=np.int64), root=0)
     comm.Barrier()
