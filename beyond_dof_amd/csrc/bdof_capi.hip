@@ -66,6 +66,9 @@ struct bdof_ctx {
     int n_angles = 0;
     const int *adj_off = nullptr, *adj_order = nullptr;
     int adj_ndest = 0;
+    float2* winpad = nullptr;                   // [S][volNX][volNY] rotated-frame gradient of the ptychography windows
+    size_t winpad_sz = 0;
+    int* win_angle = nullptr;                   // device copy of the batch's angle index
     int* heavy = nullptr;                       // [1 + n_dest]: counter + deferred rows of the rotation adjoint
     // profiling
     bool prof = false;
@@ -604,6 +607,8 @@ void bdof_ctx_destroy(bdof_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     free_workspace(c);
     if (c->heavy) (void)hipFree(c->heavy);
+    if (c->winpad) (void)hipFree(c->winpad);
+    if (c->win_angle) (void)hipFree(c->win_angle);
     if (c->mod) (void)hipFree(c->mod);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
     for (hipStream_t s : c->side_all) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
@@ -1104,12 +1109,39 @@ int bdof_window_rotation_adjoint(bdof_ctx* c, int B, int angle, const int* xoff,
     if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
     if (angle < 0 || angle >= c->n_angles) return fail(c, BDOF_ERR_ARG, "angle index outside the rotation tables");
     HIPC(c, hipSetDevice(c->device));
+    if (c->obj.volNY % 2) return fail(c, BDOF_ERR_SIZE, "the rotation adjoint needs an even volume NY");
     ProfScope ps(c, BDOF_K_ROT_ADJ);
     const int n_src = c->S * c->obj.volNX;
     WinAdjArgs a{c->grot, (float2*)gvol, c->adj_off + (size_t)angle * (c->adj_ndest + 1), c->adj_order + (size_t)angle * n_src,
                  xoff, yoff, B, c->S, c->NX, c->NY, c->obj.volNX, c->obj.volNY, c->adj_ndest, accumulate, scale};
-    int grid = c->adj_ndest < c->ncu * 16 ? c->adj_ndest : c->ncu * 16;
-    hipLaunchKernelGGL(k_window_rot_adjoint, dim3(grid), dim3(256), 0, c->stream, a);
+    if (B > BDOF_WIN_MAXLIST) {
+        // more windows than the overlap-add kernel lists per column: direct (slow) gather
+        int grid = c->adj_ndest < c->ncu * 16 ? c->adj_ndest : c->ncu * 16;
+        hipLaunchKernelGGL(k_window_rot_adjoint, dim3(grid), dim3(256), 0, c->stream, a);
+        HIPC(c, hipGetLastError());
+        return 0;
+    }
+    const size_t need = sizeof(float2) * (size_t)n_src * c->obj.volNY;
+    if (c->winpad_sz < need) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (c->winpad) (void)hipFree(c->winpad);
+        c->winpad = nullptr; c->winpad_sz = 0;
+        HIPC(c, hipMalloc((void**)&c->winpad, need));
+        c->winpad_sz = need;
+    }
+    if (!c->win_angle) HIPC(c, hipMalloc((void**)&c->win_angle, sizeof(int)));
+    HIPC(c, hipMemsetD32Async((hipDeviceptr_t)c->win_angle, angle, 1, c->stream));
+    // stage 1: windows -> rotated frame
+    const int z_per_wg = 8;
+    hipLaunchKernelGGL(k_window_overlap_add, dim3(c->obj.volNX, (c->S + z_per_wg - 1) / z_per_wg), dim3(256), 0, c->stream, a,
+                       c->winpad, z_per_wg);
+    // stage 2: rotated frame -> volume (the full-field rotation adjoint with a batch of one)
+    RotAdjArgs r{c->winpad, (float2*)gvol, c->adj_off, c->adj_order, c->win_angle, 1, n_src, c->adj_ndest, c->obj.volNY, accumulate,
+                 scale, c->heavy, c->heavy + 1, 0, c->adj_ndest};
+    HIPC(c, hipMemsetAsync(c->heavy, 0, sizeof(int), c->stream));
+    const int needwg = (c->adj_ndest + 3) / 4;
+    hipLaunchKernelGGL(k_rot_adjoint, dim3(needwg < c->ncu * 8 ? needwg : c->ncu * 8), dim3(256), 0, c->stream, r);
+    hipLaunchKernelGGL(k_rot_adjoint_heavy, dim3(c->ncu * 8), dim3(256), 0, c->stream, r);
     HIPC(c, hipGetLastError());
     return 0;
 }

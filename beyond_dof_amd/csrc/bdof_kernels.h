@@ -696,6 +696,42 @@ struct WinAdjArgs {
     float scale;
 };
 
+// Stage 1: overlap-add of the window-frame gradients into the rotated frame, pad[z][xg][y] = sum over the windows b that
+// cover (xg, y) of grot[b][z][xg - xoff[b]][y - yoff[b]]  (adjoint of the window cut + zero padding; pixels of a window
+// that lie outside the volume are dropped).  One workgroup per (xg, chunk of z): it first collects the windows covering
+// its xg in LDS (a scan over B offsets), then streams their rows.  Fixed summation order (by b) -> deterministic.
+// Stage 2 is the plain rotation adjoint (k_rot_adjoint) of `pad` as a one-element batch.
+#define BDOF_WIN_MAXLIST 1024
+__global__ __launch_bounds__(256) void k_window_overlap_add(WinAdjArgs a, float2* pad, int z_per_wg) {
+    __shared__ int lb[BDOF_WIN_MAXLIST], ly[BDOF_WIN_MAXLIST], lx[BDOF_WIN_MAXLIST];
+    __shared__ int nlist;
+    const int xg = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int b = 0; b < a.B; ++b) {
+            const int xw = xg - a.xoff[b];
+            if (xw >= 0 && xw < a.NX && n < BDOF_WIN_MAXLIST) { lb[n] = b; lx[n] = xw; ly[n] = a.yoff[b]; ++n; }
+        }
+        nlist = n;
+    }
+    __syncthreads();
+    const int n = nlist;
+    const int z0 = blockIdx.y * z_per_wg, z1 = min(a.S, z0 + z_per_wg);
+    for (int z = z0; z < z1; ++z) {
+        for (int y = threadIdx.x; y < a.volNY; y += blockDim.x) {
+            float2 acc = make_float2(0.f, 0.f);
+            for (int e = 0; e < n; ++e) {
+                const int yw = y - ly[e];
+                if (yw < 0 || yw >= a.NY) continue;
+                const float2 g = a.grot[(((size_t)lb[e] * a.S + z) * a.NX + lx[e]) * a.NY + yw];
+                acc.x += g.x;
+                acc.y += g.y;
+            }
+            pad[((size_t)z * a.volNX + xg) * a.volNY + y] = acc;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_window_rot_adjoint(WinAdjArgs a) {
     for (int d = blockIdx.x; d < a.n_dest; d += gridDim.x) {
         const int e0 = a.off[d], e1 = a.off[d + 1];

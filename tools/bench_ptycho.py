@@ -1,0 +1,43 @@
+"""cfg5 timing: 256^3 object, gaussian probe, 20 x 20 scan positions, far field, all positions of one angle
+per Adam step.  usage: python tools/bench_ptycho.py [probe_size] [n_pos_side] [steps]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry  # noqa: E402
+
+entry.build()
+from beyond_dof_amd import util  # noqa: E402
+from beyond_dof_amd.solver import PtychoSolver  # noqa: E402
+gaussian_probe = util.gaussian_probe
+
+ps = int(sys.argv[1]) if len(sys.argv) > 1 else 72
+side = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+n, n_theta = 256, 8
+rng = np.random.default_rng(5)
+pos = np.array([(y, x) for y in np.arange(side) * 12 + 14 for x in np.arange(side) * 12 + 14])
+mb = len(pos)
+pr, pi = gaussian_probe((ps, ps), 6., 6., 0.5)
+t0 = time.time()
+coords = util.rotation_lookup([n, n, n], n_theta)
+s = PtychoSolver([n, n, n], [ps, ps], pos, n_theta, mb, 5000., 1e-7, pr, pi, coord_ls=coords)
+d = rng.random((n, n, n), dtype=np.float32) * 1e-6
+s.set_volume(d, 0.1 * d)
+meas = np.abs(rng.normal(1.0, 0.1, size=(mb, ps, ps))).astype(np.float32) * ps
+print('setup %.1f s' % (time.time() - t0), flush=True)
+s.reset_moments()
+for it in range(1 + steps):
+    if it == 1:
+        s.ctx.sync()
+        t0 = time.perf_counter()
+    s.loss_and_grad(it % n_theta, np.arange(mb), meas, want_loss=False)
+    s.adam_update(it, 1e-7)
+s.ctx.sync()
+dt = (time.perf_counter() - t0) / steps
+px = ps * ps
+print('probe %d^2, %d positions, %d slices: %.2f ms per Adam step, %.0f slice-steps/s, %.1f GB/s at 104 B/px' %
+      (ps, mb, n, dt * 1e3, mb * n / dt, 104.0 * px * mb * n / dt / 1e9))
