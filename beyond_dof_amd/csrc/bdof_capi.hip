@@ -12,6 +12,7 @@
 #include "../../include/bdof.h"
 #include "bdof_kernels.h"
 #include "bdof_generic.h"
+#include "bdof_resident.h"
 #include <rocfft/rocfft.h>
 #include <map>
 
@@ -49,6 +50,9 @@ struct bdof_ctx {
     std::complex<double> ksum{1.0, 0.0};
     float k_conv = 0.f;
     cf *bufC = nullptr, *conv_scal = nullptr;
+    // LDS-resident engine (small square fields, bdof_resident.h)
+    bool resident = false, res_dirty = true;
+    cf *hsT = nullptr, *hdetT = nullptr, *twR = nullptr, *res_carrier = nullptr;
     // generic-size engine (rocFFT): one plan pair per batch size
     bool generic = false;
     std::map<int, std::pair<rocfft_plan, rocfft_plan>> gplans;
@@ -538,6 +542,52 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
     return 0;
 }
 
+// ---- LDS-resident engine ---------------------------------------------------------------------------
+template <int N> static int resident_launch(bdof_ctx* c, const ResArgs& a, int grid) {
+    const size_t lds = sizeof(cf) * ((size_t)N * (N | 1) + N);
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIPC(c, hipFuncSetAttribute((const void*)k_resident<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_resident<N>), dim3(grid), dim3(ResPlan<N>::T), lds, c->stream, a);
+    return 0;
+}
+
+static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, bool do_grad) {
+    if (c->res_dirty) {
+        std::vector<cf> car(c->S);
+        for (int z = 0; z < c->S; ++z) car[z] = carrier_at(c, z);
+        HIPC(c, hipStreamSynchronize(c->stream));
+        HIPC(c, hipMemcpy(c->res_carrier, car.data(), sizeof(cf) * c->S, hipMemcpyHostToDevice));
+        c->res_dirty = false;
+    }
+    ProfScope ps(c, BDOF_K_ROW_FWD);
+    const bool grad = do_grad && meas;
+    ResArgs a{c->probe, c->hsT, c->hdetT, grad ? c->tape : nullptr, (size_t)c->Bmax * c->NX * c->NY, c->grot, c->obj, c->res_carrier,
+              carrier_det(c), meas, (cf*)out_wave, c->partial, c->twR, B, c->S, c->det_mode,
+              c->variant == BDOF_VARIANT_TF_ALL ? 1 : 0, grad ? 1 : 0, c->k, 2.f / ((float)B * (float)c->NX * (float)c->NY)};
+    const int grid = B < c->npartial ? B : c->npartial;
+    int r = 0;
+    switch (c->NX) {
+        case 32: r = resident_launch<32>(c, a, grid); break;
+        case 36: r = resident_launch<36>(c, a, grid); break;
+        case 48: r = resident_launch<48>(c, a, grid); break;
+        case 64: r = resident_launch<64>(c, a, grid); break;
+        case 72: r = resident_launch<72>(c, a, grid); break;
+        case 80: r = resident_launch<80>(c, a, grid); break;
+        case 96: r = resident_launch<96>(c, a, grid); break;
+        case 128: r = resident_launch<128>(c, a, grid); break;
+        default: return fail(c, BDOF_ERR_SIZE, "no resident plan for this size");
+    }
+    if (r) return r;
+    if (meas)
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, grid, 1.0 / ((double)B * c->NX * c->NY),
+                           c->loss_dev);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
 static int check_ready(bdof_ctx* c, int B) {
     if (!c) return BDOF_ERR_ARG;
     if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
@@ -592,8 +642,10 @@ static void free_generic(bdof_ctx* c) {
 
 static void free_workspace(bdof_ctx* c) {
     free_generic(c);
-    void* ptrs[] = {c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
+    void* ptrs[] = {c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
+    c->resident = false;
     c->bufC = c->conv_scal = nullptr;
     c->have_conv = false;
     c->twY = c->twX = c->hs = c->hdet = c->hcomb = c->probe = c->bufA = c->bufB = c->tape = nullptr;
@@ -649,8 +701,16 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     free_workspace(c);
     c->NY = NY; c->NX = NX; c->S = S; c->Bmax = Bmax; c->with_grad = (with_grad & 1) != 0;
     c->generic = generic;
+    c->resident = (with_grad & 6) == 0 && NX == NY && resident_supported(NX) && !std::getenv("BDOF_NO_RESIDENT");
+    c->res_dirty = true;
     c->have_physics = c->have_probe = c->tape_valid = false;
     int r;
+    if (c->resident) {
+        if ((r = upload_twiddle(c, NX, &c->twR))) return r;
+        HIPC(c, hipMalloc((void**)&c->hsT, sizeof(cf) * NX * NY));
+        HIPC(c, hipMalloc((void**)&c->hdetT, sizeof(cf) * NX * NY));
+        HIPC(c, hipMalloc((void**)&c->res_carrier, sizeof(cf) * (size_t)S));
+    }
     if (!generic) {
         if ((r = upload_twiddle(c, NY, &c->twY))) return r;
         if ((r = upload_twiddle(c, NX, &c->twX))) return r;
@@ -694,7 +754,22 @@ int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det
         HIPC(c, hipMemcpyAsync(c->hcomb, comb.data(), bytes, hipMemcpyHostToDevice, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
     }
+    if (c->resident) {
+        // the resident kernel multiplies the field image [kx][ky] element by element: tables in that order
+        const int N = c->NX;
+        std::vector<float> t((size_t)2 * N * N);
+        for (int pass = 0; pass < (hs_det ? 2 : 1); ++pass) {
+            const float* src = pass ? hs_det : hs;
+            for (int ky = 0; ky < N; ++ky)
+                for (int kx = 0; kx < N; ++kx) {
+                    t[2 * ((size_t)kx * N + ky)] = src[2 * ((size_t)ky * N + kx)];
+                    t[2 * ((size_t)kx * N + ky) + 1] = src[2 * ((size_t)ky * N + kx) + 1];
+                }
+            HIPC(c, hipMemcpy(pass ? c->hdetT : c->hsT, t.data(), bytes, hipMemcpyHostToDevice));
+        }
+    }
     HIPC(c, hipStreamSynchronize(c->stream));
+    c->res_dirty = true;
     c->k = (float)k;
     c->h00 = std::complex<double>(h00[0], h00[1]);
     c->hdet00 = hdet00 ? std::complex<double>(hdet00[0], hdet00[1]) : std::complex<double>(1.0, 0.0);
@@ -711,6 +786,7 @@ int bdof_set_probe(bdof_ctx* c, const float* probe, double a0_re, double a0_im) 
     HIPC(c, hipMemcpyAsync(c->probe, probe, sizeof(cf) * c->NX * c->NY, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     c->a0 = std::complex<double>(a0_re, a0_im);
+    c->res_dirty = true;
     c->have_probe = true;
     return 0;
 }
@@ -757,6 +833,11 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     if ((r = ensure_modulation(c))) return r;
+    if (c->resident && !keep_tape) {
+        if ((r = resident_run(c, B, nullptr, out_wave, false))) return r;
+        c->tape_valid = c->last_valid = false;
+        return 0;
+    }
     if (c->generic) {
         if (keep_tape) return fail(c, BDOF_ERR_STATE, "the per-slice history is not kept by the generic-size engine");
         if ((r = generic_forward(c, B, out_wave, false))) return r;
@@ -820,6 +901,11 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     if ((r = ensure_modulation(c))) return r;
+    if (c->resident) {
+        if ((r = resident_run(c, B, meas, out_wave, true))) return r;
+        c->tape_valid = c->last_valid = false;
+        return 0;
+    }
     if (c->generic) {
         if ((r = generic_loss_grad(c, B, meas, out_wave))) return r;
         c->tape_valid = c->last_valid = false;

@@ -1,0 +1,259 @@
+// LDS-resident engine for small square wavefields (N <= 128: the 72 x 72 probes of cnn_propagator/reconstruct_ptycho.py:106).
+//
+// A whole N x N complex field fits in one CU's LDS (72 x 73 x 8 B = 42 KB), so ONE workgroup carries one wavefield through
+// ALL slices without the field ever leaving the CU: forward sweep (np_funcs.py:37-43), detector step (:45-61), loss and
+// seed (ptychography.py:79 / fullfield.py:106), adjoint sweep — one launch per minibatch instead of ~8 per
+// slice.  HBM traffic per pixel per slice-step drops from the 104 B of the streaming engines to 40 B:
+//   forward  : modulation factor 8 + phi tape write 8                          (the transfer function is L2-resident)
+//   backward : tape read 8 + modulation factor 8 + gradient write 8
+// The 2-D transforms are in-place Stockham passes over the LDS image (radices 2/3/4/5/8/9; every thread reads all its
+// butterflies, barrier, writes them to the autosort positions, barrier).  Lines-fastest thread mapping + odd row pitch
+// make every LDS access of a pass conflict-free in both directions.  Index math: tools/resident_fft_model.py.
+#pragma once
+#include "bdof_generic.h"
+
+template <int N> struct ResPlan;      // radices of the Stockham passes of one line, and the workgroup size
+template <> struct ResPlan<32> { static constexpr int n = 2, R0 = 8, R1 = 4, R2 = 1, T = 64; };
+template <> struct ResPlan<36> { static constexpr int n = 2, R0 = 4, R1 = 9, R2 = 1, T = 64; };
+template <> struct ResPlan<48> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 3, T = 128; };
+template <> struct ResPlan<64> { static constexpr int n = 2, R0 = 8, R1 = 8, R2 = 1, T = 256; };
+template <> struct ResPlan<72> { static constexpr int n = 2, R0 = 8, R1 = 9, R2 = 1, T = 256; };
+template <> struct ResPlan<80> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 5, T = 384; };
+template <> struct ResPlan<96> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 3, T = 512; };
+template <> struct ResPlan<128> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 4, T = 512; };
+
+static inline bool resident_supported(int n) {
+    return n == 32 || n == 36 || n == 48 || n == 64 || n == 72 || n == 80 || n == 96 || n == 128;
+}
+
+template <int SIGN> __device__ __forceinline__ void dft3(cf& a0, cf& a1, cf& a2) {
+    const cf t1 = cadd(a1, a2);
+    const cf t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
+    const cf d = csub(a1, a2);
+    const float h = 0.86602540378443865f * (float)SIGN;
+    const cf t3 = make_float2(-h * d.y, h * d.x);                    // SIGN * i * sqrt(3)/2 * (a1 - a2)
+    a0 = cadd(a0, t1);
+    a1 = cadd(t2, t3);
+    a2 = csub(t2, t3);
+}
+
+template <int SIGN> __device__ __forceinline__ void dft5(cf& a0, cf& a1, cf& a2, cf& a3, cf& a4) {
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+    const float s1 = 0.95105651629515357f * (float)SIGN, s2 = 0.58778525229247313f * (float)SIGN;
+    const cf t1 = cadd(a1, a4), t2 = cadd(a2, a3), t3 = csub(a1, a4), t4 = csub(a2, a3);
+    const cf m1 = make_float2(a0.x + c1 * t1.x + c2 * t2.x, a0.y + c1 * t1.y + c2 * t2.y);
+    const cf m2 = make_float2(a0.x + c2 * t1.x + c1 * t2.x, a0.y + c2 * t1.y + c1 * t2.y);
+    const cf p1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    const cf p2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    const cf n1 = make_float2(-p1.y, p1.x), n2 = make_float2(-p2.y, p2.x);      // i * p (SIGN already in s1, s2)
+    a0 = cadd(a0, cadd(t1, t2));
+    a1 = cadd(m1, n1);
+    a4 = csub(m1, n1);
+    a2 = cadd(m2, n2);
+    a3 = csub(m2, n2);
+}
+
+template <int SIGN> __device__ __forceinline__ void dft9(cf (&u)[9]) {
+    dft3<SIGN>(u[0], u[3], u[6]);
+    dft3<SIGN>(u[1], u[4], u[7]);
+    dft3<SIGN>(u[2], u[5], u[8]);
+    const float s = (float)SIGN;
+    const cf w1 = make_float2(0.76604444311897804f, s * 0.64278760968653933f);
+    const cf w2 = make_float2(0.17364817766693035f, s * 0.98480775301220806f);
+    const cf w4 = make_float2(-0.93969262078590838f, s * 0.34202014332566873f);
+    u[4] = cmul(u[4], w1);
+    u[7] = cmul(u[7], w2);
+    u[5] = cmul(u[5], w2);
+    u[8] = cmul(u[8], w4);
+    dft3<SIGN>(u[0], u[1], u[2]);
+    dft3<SIGN>(u[3], u[4], u[5]);
+    dft3<SIGN>(u[6], u[7], u[8]);
+    // u[3 k1 + k2] holds X[k1 + 3 k2]: transpose
+    cf t;
+    t = u[1]; u[1] = u[3]; u[3] = t;
+    t = u[2]; u[2] = u[6]; u[6] = t;
+    t = u[5]; u[5] = u[7]; u[7] = t;
+}
+
+template <int R, int SIGN> __device__ __forceinline__ void res_dft(cf (&u)[R]) {
+    if constexpr (R == 2) dft2<SIGN>(u[0], u[1]);
+    else if constexpr (R == 3) dft3<SIGN>(u[0], u[1], u[2]);
+    else if constexpr (R == 4) dft4<SIGN>(u[0], u[1], u[2], u[3]);
+    else if constexpr (R == 5) dft5<SIGN>(u[0], u[1], u[2], u[3], u[4]);
+    else if constexpr (R == 8) dft8<SIGN>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+    else if constexpr (R == 9) dft9<SIGN>(u);
+}
+
+// One Stockham pass (radix R, NS = product of the earlier radices) over the N lines of the field, in place.
+// ALONG_Y: lines are the rows x (elements contiguous); else lines are the columns y (element stride P).
+template <int N, int R, int NS, int SIGN, bool ALONG_Y, int T>
+__device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid) {
+    constexpr int P = N | 1;
+    constexpr int NB = N * (N / R);
+    constexpr int CNT = (NB + T - 1) / T;
+    constexpr int ES = ALONG_Y ? 1 : P;
+    cf u[CNT][R];
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        const int q = tid + c * T;
+        if (CNT * T == NB || q < NB) {
+            const int line = q % N, j = q / N;
+            const cf* src = f + (ALONG_Y ? line * P : line) + j * ES;
+#pragma unroll
+            for (int m = 0; m < R; ++m) u[c][m] = src[m * (N / R) * ES];
+            if constexpr (NS > 1) {
+                const int k = j % NS;
+#pragma unroll
+                for (int m = 1; m < R; ++m) {
+                    cf w = tw[k * m * (N / (NS * R))];
+                    if constexpr (SIGN > 0) w.y = -w.y;
+                    u[c][m] = cmul(u[c][m], w);
+                }
+            }
+            res_dft<R, SIGN>(u[c]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CNT; ++c) {
+        const int q = tid + c * T;
+        if (CNT * T == NB || q < NB) {
+            const int line = q % N, j = q / N;
+            const int k = j % NS;
+            cf* dst = f + (ALONG_Y ? line * P : line) + ((j / NS) * NS * R + k) * ES;
+#pragma unroll
+            for (int m = 0; m < R; ++m) dst[m * NS * ES] = u[c][m];
+        }
+    }
+    __syncthreads();
+}
+
+template <int N, int SIGN, bool ALONG_Y> __device__ __forceinline__ void res_lines(cf* f, const cf* tw, int tid) {
+    typedef ResPlan<N> Pl;
+    res_pass<N, Pl::R0, 1, SIGN, ALONG_Y, Pl::T>(f, tw, tid);
+    res_pass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, Pl::T>(f, tw, tid);
+    if constexpr (Pl::n > 2) res_pass<N, Pl::R2, Pl::R0 * Pl::R1, SIGN, ALONG_Y, Pl::T>(f, tw, tid);
+}
+
+// un-normalised 2-D DFT of the field image f[x * P + y], SIGN = -1 forward, +1 inverse
+template <int N, int SIGN> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid) {
+    res_lines<N, SIGN, true>(f, tw, tid);
+    res_lines<N, SIGN, false>(f, tw, tid);
+}
+
+struct ResArgs {
+    const cf* probe;       // [N][N] eps part of the probe, [x][y]
+    const cf* hsT;         // [kx][ky] transfer function / (N*N)
+    const cf* hdetT;       // [kx][ky] detector transfer function / (N*N)   (near field)
+    cf* tape;              // nullable: phi_z tape, slice z of wavefield b at tape + z * tape_stride + b * N * N
+    size_t tape_stride;
+    float2* grot;          // [B][S][N][N]
+    ObjView obj;
+    const cf* carrier;     // device [S]: a_z
+    cf carrier_det;        // constant part of the detector wave (far field: DC bin value)
+    const float* meas;     // nullable; real detectors [b][x][y], far field [b][ky][kx]
+    cf* out_wave;          // nullable; same order as meas
+    double* partial;       // [2 * gridDim.x]
+    const cf* twiddle;     // [N] exp(-2 pi i k / N)
+    int B, S, det_mode, tf_all, do_grad;
+    float k, seed_scale;
+};
+
+template <int N, bool CONJ> __device__ __forceinline__ void res_hmul(cf* f, const cf* hT, int tid) {
+    constexpr int P = N | 1, T = ResPlan<N>::T;
+    for (int e = tid; e < N * N; e += T) {
+        const int x = e / N, y = e - x * N;
+        cf h = hT[e];
+        if constexpr (CONJ) h.y = -h.y;
+        f[x * P + y] = cmul(f[x * P + y], h);
+    }
+    __syncthreads();
+}
+
+// F^-1 (h .) F   (CONJ: the adjoint step, conj(h))
+template <int N, bool CONJ> __device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid) {
+    res_fft2<N, -1>(f, tw, tid);
+    res_hmul<N, CONJ>(f, hT, tid);
+    res_fft2<N, +1>(f, tw, tid);
+}
+
+template <int N>
+__global__ __launch_bounds__(ResPlan<N>::T) void k_resident(ResArgs a) {
+    constexpr int P = N | 1, T = ResPlan<N>::T;
+    extern __shared__ __align__(16) unsigned char res_smem[];
+    cf* f = reinterpret_cast<cf*>(res_smem);
+    cf* tw = f + N * P;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < N; e += T) tw[e] = a.twiddle[e];
+    double acc = 0.0, acc2 = 0.0;
+    for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        __syncthreads();
+        for (int e = tid; e < N * N; e += T) {
+            const int x = e / N, y = e - x * N;
+            f[x * P + y] = a.probe[e];
+        }
+        __syncthreads();
+        // ---- forward sweep --------------------------------------------------------------------
+        for (int z = 0; z < a.S; ++z) {
+            const cf car = a.carrier[z];
+            cf* tape = a.tape ? a.tape + (size_t)z * a.tape_stride + (size_t)b * N * N : nullptr;
+            for (int e = tid; e < N * N; e += T) {
+                const int x = e / N, y = e - x * N;
+                const cf phi = modulate_eps(f[x * P + y], car, g_mod_value(a.obj, b, x, y, z, N));
+                f[x * P + y] = phi;
+                if (tape) tape[e] = phi;
+            }
+            __syncthreads();
+            const bool last = z == a.S - 1;
+            if (!last || (a.tf_all && a.det_mode != BDOF_DET_FAR)) res_prop<N, false>(f, a.hsT, tw, tid);
+        }
+        if (a.det_mode == BDOF_DET_NEAR) res_prop<N, false>(f, a.hdetT, tw, tid);
+        else if (a.det_mode == BDOF_DET_FAR) res_fft2<N, -1>(f, tw, tid);
+        // ---- detector wave, loss, seed --------------------------------------------------------
+        const bool far = a.det_mode == BDOF_DET_FAR;
+        for (int e = tid; e < N * N; e += T) {
+            const int x = e / N, y = e - x * N;
+            cf d = f[x * P + y];
+            if (!far || e == 0) d = cadd(d, a.carrier_det);
+            const size_t o = (size_t)b * N * N + (far ? y * N + x : e);
+            if (a.out_wave) a.out_wave[o] = d;
+            if (a.meas) f[x * P + y] = loss_seed(d, a.meas[o], a.seed_scale, acc, acc2);
+        }
+        __syncthreads();
+        if (!a.do_grad || !a.meas) continue;
+        // ---- adjoint sweep --------------------------------------------------------------------
+        if (a.det_mode == BDOF_DET_NEAR) res_prop<N, true>(f, a.hdetT, tw, tid);
+        else if (far) res_fft2<N, +1>(f, tw, tid);                     // F^H = un-normalised inverse
+        for (int z = a.S - 1; z >= 0; --z) {
+            const bool prop_after = z < a.S - 1 || (a.tf_all && !far);
+            if (prop_after) res_prop<N, true>(f, a.hsT, tw, tid);
+            const cf car = a.carrier[z];
+            const cf* tape = a.tape + (size_t)z * a.tape_stride + (size_t)b * N * N;
+            float2* gdst = a.grot + ((size_t)b * a.S + z) * N * N;
+            for (int e = tid; e < N * N; e += T) {
+                const int x = e / N, y = e - x * N;
+                const cf G = f[x * P + y];
+                const cf phi = cadd(tape[e], car);
+                const cf t = cmulc(G, phi);
+                gdst[e] = make_float2(a.k * t.y, -a.k * t.x);
+                const float2 m1 = g_mod_value(a.obj, b, x, y, z, N);
+                f[x * P + y] = cmulc(G, make_float2(1.f + m1.x, m1.y));
+            }
+            __syncthreads();
+        }
+    }
+    if (a.meas) {
+        __shared__ double w1[16], w2[16];
+        acc = wave_reduce_sum(acc);
+        acc2 = wave_reduce_sum(acc2);
+        __syncthreads();
+        if ((tid & 63) == 0) { w1[tid >> 6] = acc; w2[tid >> 6] = acc2; }
+        __syncthreads();
+        if (tid == 0) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int i = 0; i < T / 64; ++i) { s1 += w1[i]; s2 += w2[i]; }
+            a.partial[2 * blockIdx.x] = s1;
+            a.partial[2 * blockIdx.x + 1] = s2;
+        }
+    }
+}
