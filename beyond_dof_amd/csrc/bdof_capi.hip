@@ -51,7 +51,7 @@ struct bdof_ctx {
     float k_conv = 0.f;
     cf *bufC = nullptr, *conv_scal = nullptr;
     // LDS-resident engine (small square fields, bdof_resident.h)
-    bool resident = false, res_dirty = true;
+    bool resident = false, res_dirty = true, res_always = false;
     cf *hsT = nullptr, *hdetT = nullptr, *twR = nullptr, *res_carrier = nullptr;
     // generic-size engine (rocFFT): one plan pair per batch size
     bool generic = false;
@@ -543,15 +543,26 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
 }
 
 // ---- LDS-resident engine ---------------------------------------------------------------------------
-template <int N> static int resident_launch(bdof_ctx* c, const ResArgs& a, int grid) {
-    const size_t lds = sizeof(cf) * ((size_t)N * (N | 1) + N);
+template <int N, int T, int WPE> static int resident_launch_t(bdof_ctx* c, const ResArgs& a, int grid) {
+    const size_t lds = sizeof(cf) * ((size_t)N * (N | 1) + N) + sizeof(long long) * 3 * N;
     static bool attr_set = false;
     if (!attr_set) {
-        HIPC(c, hipFuncSetAttribute((const void*)k_resident<N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPC(c, hipFuncSetAttribute((const void*)k_resident<N, T, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_resident<N>), dim3(grid), dim3(ResPlan<N>::T), lds, c->stream, a);
+    hipLaunchKernelGGL((k_resident<N, T, WPE>), dim3(grid), dim3(T), lds, c->stream, a);
     return 0;
+}
+template <int N> static int resident_launch(bdof_ctx* c, const ResArgs& a, int grid) {
+    return resident_launch_t<N, ResPlan<N>::T, ResPlan<N>::WPE>(c, a, grid);
+}
+
+// One workgroup per wavefield: against the streaming kernels (sizes with a fused plan) the resident engine wins once the
+// batch fills a good part of the chip (measured at 64^2 / 128^2: 400 / 100 wavefields 4.6x / 1.5x faster, 25 slower);
+// sizes without a fused plan always take it (the alternative is the unfused rocFFT engine).
+static bool use_resident(const bdof_ctx* c, int B) {
+    if (!c->resident) return false;
+    return c->generic || c->res_always || B * 4 >= c->ncu;
 }
 
 static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, bool do_grad) {
@@ -574,7 +585,12 @@ static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, b
         case 36: r = resident_launch<36>(c, a, grid); break;
         case 48: r = resident_launch<48>(c, a, grid); break;
         case 64: r = resident_launch<64>(c, a, grid); break;
-        case 72: r = resident_launch<72>(c, a, grid); break;
+        case 72: {
+            static const int t72 = std::getenv("BDOF_RES_T72") ? std::atoi(std::getenv("BDOF_RES_T72")) : 0;   // tuning switch
+            if (t72 == 512) r = resident_launch_t<72, 512, 4>(c, a, grid);
+            else r = resident_launch<72>(c, a, grid);
+            break;
+        }
         case 80: r = resident_launch<80>(c, a, grid); break;
         case 96: r = resident_launch<96>(c, a, grid); break;
         case 128: r = resident_launch<128>(c, a, grid); break;
@@ -702,6 +718,7 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     c->NY = NY; c->NX = NX; c->S = S; c->Bmax = Bmax; c->with_grad = (with_grad & 1) != 0;
     c->generic = generic;
     c->resident = (with_grad & 6) == 0 && NX == NY && resident_supported(NX) && !std::getenv("BDOF_NO_RESIDENT");
+    c->res_always = (with_grad & 8) != 0 || std::getenv("BDOF_FORCE_RESIDENT");
     c->res_dirty = true;
     c->have_physics = c->have_probe = c->tape_valid = false;
     int r;
@@ -833,7 +850,7 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     if ((r = ensure_modulation(c))) return r;
-    if (c->resident && !keep_tape) {
+    if (use_resident(c, B) && !keep_tape) {
         if ((r = resident_run(c, B, nullptr, out_wave, false))) return r;
         c->tape_valid = c->last_valid = false;
         return 0;
@@ -901,7 +918,7 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     if ((r = ensure_modulation(c))) return r;
-    if (c->resident) {
+    if (use_resident(c, B)) {
         if ((r = resident_run(c, B, meas, out_wave, true))) return r;
         c->tape_valid = c->last_valid = false;
         return 0;

@@ -13,14 +13,14 @@
 #include "bdof_generic.h"
 
 template <int N> struct ResPlan;      // radices of the Stockham passes of one line, and the workgroup size
-template <> struct ResPlan<32> { static constexpr int n = 2, R0 = 8, R1 = 4, R2 = 1, T = 64; };
-template <> struct ResPlan<36> { static constexpr int n = 2, R0 = 4, R1 = 9, R2 = 1, T = 64; };
-template <> struct ResPlan<48> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 3, T = 128; };
-template <> struct ResPlan<64> { static constexpr int n = 2, R0 = 8, R1 = 8, R2 = 1, T = 256; };
-template <> struct ResPlan<72> { static constexpr int n = 2, R0 = 8, R1 = 9, R2 = 1, T = 256; };
-template <> struct ResPlan<80> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 5, T = 384; };
-template <> struct ResPlan<96> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 3, T = 512; };
-template <> struct ResPlan<128> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 4, T = 512; };
+template <> struct ResPlan<32> { static constexpr int n = 2, R0 = 8, R1 = 4, R2 = 1, T = 64, WPE = 2; };
+template <> struct ResPlan<36> { static constexpr int n = 2, R0 = 4, R1 = 9, R2 = 1, T = 128, WPE = 2; };
+template <> struct ResPlan<48> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 3, T = 192, WPE = 3; };
+template <> struct ResPlan<64> { static constexpr int n = 2, R0 = 8, R1 = 8, R2 = 1, T = 512, WPE = 4; };
+template <> struct ResPlan<72> { static constexpr int n = 2, R0 = 8, R1 = 9, R2 = 1, T = 704, WPE = 6; };   // 648 / 576 butterflies per pass: one per thread
+template <> struct ResPlan<80> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 5, T = 512, WPE = 4; };
+template <> struct ResPlan<96> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 3, T = 768, WPE = 3; };
+template <> struct ResPlan<128> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 4, T = 1024, WPE = 4; };
 
 static inline bool resident_supported(int n) {
     return n == 32 || n == 36 || n == 48 || n == 64 || n == 72 || n == 80 || n == 96 || n == 128;
@@ -88,6 +88,9 @@ template <int R, int SIGN> __device__ __forceinline__ void res_dft(cf (&u)[R]) {
 // ALONG_Y: lines are the rows x (elements contiguous); else lines are the columns y (element stride P).
 template <int N, int R, int NS, int SIGN, bool ALONG_Y, int T>
 __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid) {
+    // every index below is invariant across slices: without this the compiler hoists the address math of all 16 passes
+    // out of the slice loop and keeps it in registers (250+ VGPRs, spills).  Recomputing it per pass is a few VALU ops.
+    asm volatile("" : "+v"(tid));
     constexpr int P = N | 1;
     constexpr int NB = N * (N / R);
     constexpr int CNT = (NB + T - 1) / T;
@@ -128,17 +131,17 @@ __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid) {
     __syncthreads();
 }
 
-template <int N, int SIGN, bool ALONG_Y> __device__ __forceinline__ void res_lines(cf* f, const cf* tw, int tid) {
+template <int N, int T, int SIGN, bool ALONG_Y> __device__ __forceinline__ void res_lines(cf* f, const cf* tw, int tid) {
     typedef ResPlan<N> Pl;
-    res_pass<N, Pl::R0, 1, SIGN, ALONG_Y, Pl::T>(f, tw, tid);
-    res_pass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, Pl::T>(f, tw, tid);
-    if constexpr (Pl::n > 2) res_pass<N, Pl::R2, Pl::R0 * Pl::R1, SIGN, ALONG_Y, Pl::T>(f, tw, tid);
+    res_pass<N, Pl::R0, 1, SIGN, ALONG_Y, T>(f, tw, tid);
+    res_pass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, T>(f, tw, tid);
+    if constexpr (Pl::n > 2) res_pass<N, Pl::R2, Pl::R0 * Pl::R1, SIGN, ALONG_Y, T>(f, tw, tid);
 }
 
 // un-normalised 2-D DFT of the field image f[x * P + y], SIGN = -1 forward, +1 inverse
-template <int N, int SIGN> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid) {
-    res_lines<N, SIGN, true>(f, tw, tid);
-    res_lines<N, SIGN, false>(f, tw, tid);
+template <int N, int T, int SIGN> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid) {
+    res_lines<N, T, SIGN, true>(f, tw, tid);
+    res_lines<N, T, SIGN, false>(f, tw, tid);
 }
 
 struct ResArgs {
@@ -159,8 +162,9 @@ struct ResArgs {
     float k, seed_scale;
 };
 
-template <int N, bool CONJ> __device__ __forceinline__ void res_hmul(cf* f, const cf* hT, int tid) {
-    constexpr int P = N | 1, T = ResPlan<N>::T;
+template <int N, int T, bool CONJ> __device__ __forceinline__ void res_hmul(cf* f, const cf* hT, int tid) {
+    asm volatile("" : "+v"(tid));
+    constexpr int P = N | 1;
     for (int e = tid; e < N * N; e += T) {
         const int x = e / N, y = e - x * N;
         cf h = hT[e];
@@ -171,46 +175,99 @@ template <int N, bool CONJ> __device__ __forceinline__ void res_hmul(cf* f, cons
 }
 
 // F^-1 (h .) F   (CONJ: the adjoint step, conj(h))
-template <int N, bool CONJ> __device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid) {
-    res_fft2<N, -1>(f, tw, tid);
-    res_hmul<N, CONJ>(f, hT, tid);
-    res_fft2<N, +1>(f, tw, tid);
+template <int N, int T, bool CONJ> __device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid) {
+    res_fft2<N, T, -1>(f, tw, tid);
+    res_hmul<N, T, CONJ>(f, hT, tid);
+    res_fft2<N, T, +1>(f, tw, tid);
 }
 
-template <int N>
-__global__ __launch_bounds__(ResPlan<N>::T) void k_resident(ResArgs a) {
-    constexpr int P = N | 1, T = ResPlan<N>::T;
+// Global loads of a slice are issued one propagation step ahead of their use (software pipeline): the modulation factors
+// (and, in the adjoint sweep, the tape) of the NEXT slice are in flight while the current slice's transforms run in LDS.
+// The object rows feeding each field row (rotation table + window offset) are looked up two slices ahead and parked in a
+// 3-slot LDS ring, so that the factor loads themselves never wait on a dependent table load.
+template <int N, int T> struct ResPipe {
+    static constexpr int P = N | 1;
+    static constexpr int EPT = (N * N + T - 1) / T;      // field elements per thread
+
+    // object row of field row x = tid at slice z (-1: outside the volume / the sweep)
+    static __device__ __forceinline__ long long row_of(const ResArgs& a, int b, int z, int tid) {
+        if (tid >= N || z < 0 || z >= a.S) return -1;
+        return obj_src_row(a.obj, b, tid, z, N);
+    }
+    static __device__ __forceinline__ void load_factors(const ResArgs& a, const long long* rows, int y0, int tid, float2 (&m)[EPT]) {
+        asm volatile("" : "+v"(tid));
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = min(tid + i * T, N * N - 1);
+            const int x = e / N, y = e - x * N;
+            const long long srow = rows[x];
+            const int yg = y + y0;
+            const int yc = min(max(yg, 0), a.obj.volNY - 1);
+            const float2 v = a.obj.vol[(size_t)(srow >= 0 ? srow : 0) * a.obj.volNY + yc];
+            const bool in = srow >= 0 && yg == yc;
+            m[i] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
+        }
+    }
+    static __device__ __forceinline__ void load_field(const cf* src, int tid, cf (&t)[EPT]) {
+        asm volatile("" : "+v"(tid));
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) t[i] = src[min(tid + i * T, N * N - 1)];
+    }
+};
+
+// WPE = waves per SIMD the register allocation must leave room for (two workgroups per CU where the LDS image allows)
+template <int N, int T, int WPE>
+__global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
+    typedef ResPipe<N, T> Pipe;
+    constexpr int P = N | 1, EPT = Pipe::EPT;
     extern __shared__ __align__(16) unsigned char res_smem[];
     cf* f = reinterpret_cast<cf*>(res_smem);
     cf* tw = f + N * P;
+    long long* rowbuf = reinterpret_cast<long long*>(tw + N);      // [3][N]
     const int tid = threadIdx.x;
     for (int e = tid; e < N; e += T) tw[e] = a.twiddle[e];
     double acc = 0.0, acc2 = 0.0;
+    const bool far = a.det_mode == BDOF_DET_FAR;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+        const int y0 = a.obj.yoff ? a.obj.yoff[b] : 0;
         __syncthreads();
         for (int e = tid; e < N * N; e += T) {
             const int x = e / N, y = e - x * N;
             f[x * P + y] = a.probe[e];
         }
+        if (tid < N) {
+            rowbuf[tid] = Pipe::row_of(a, b, 0, tid);
+            rowbuf[N + tid] = Pipe::row_of(a, b, 1, tid);
+        }
         __syncthreads();
+        float2 m[EPT];
+        Pipe::load_factors(a, rowbuf, y0, tid, m);
         // ---- forward sweep --------------------------------------------------------------------
         for (int z = 0; z < a.S; ++z) {
+            const long long r2 = Pipe::row_of(a, b, z + 2, tid);
             const cf car = a.carrier[z];
             cf* tape = a.tape ? a.tape + (size_t)z * a.tape_stride + (size_t)b * N * N : nullptr;
-            for (int e = tid; e < N * N; e += T) {
-                const int x = e / N, y = e - x * N;
-                const cf phi = modulate_eps(f[x * P + y], car, g_mod_value(a.obj, b, x, y, z, N));
-                f[x * P + y] = phi;
-                if (tape) tape[e] = phi;
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int e = tl + i * T;
+                if (EPT * T == N * N || e < N * N) {
+                    const int x = e / N, y = e - x * N;
+                    const cf phi = modulate_eps(f[x * P + y], car, m[i]);
+                    f[x * P + y] = phi;
+                    if (tape) tape[e] = phi;
+                }
             }
             __syncthreads();
+            if (z + 1 < a.S) Pipe::load_factors(a, rowbuf + ((z + 1) % 3) * N, y0, tid, m);
+            if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;
             const bool last = z == a.S - 1;
-            if (!last || (a.tf_all && a.det_mode != BDOF_DET_FAR)) res_prop<N, false>(f, a.hsT, tw, tid);
+            if (!last || (a.tf_all && !far)) res_prop<N, T, false>(f, a.hsT, tw, tid);
         }
-        if (a.det_mode == BDOF_DET_NEAR) res_prop<N, false>(f, a.hdetT, tw, tid);
-        else if (a.det_mode == BDOF_DET_FAR) res_fft2<N, -1>(f, tw, tid);
+        if (a.det_mode == BDOF_DET_NEAR) res_prop<N, T, false>(f, a.hdetT, tw, tid);
+        else if (far) res_fft2<N, T, -1>(f, tw, tid);
         // ---- detector wave, loss, seed --------------------------------------------------------
-        const bool far = a.det_mode == BDOF_DET_FAR;
         for (int e = tid; e < N * N; e += T) {
             const int x = e / N, y = e - x * N;
             cf d = f[x * P + y];
@@ -219,27 +276,44 @@ __global__ __launch_bounds__(ResPlan<N>::T) void k_resident(ResArgs a) {
             if (a.out_wave) a.out_wave[o] = d;
             if (a.meas) f[x * P + y] = loss_seed(d, a.meas[o], a.seed_scale, acc, acc2);
         }
-        __syncthreads();
         if (!a.do_grad || !a.meas) continue;
         // ---- adjoint sweep --------------------------------------------------------------------
-        if (a.det_mode == BDOF_DET_NEAR) res_prop<N, true>(f, a.hdetT, tw, tid);
-        else if (far) res_fft2<N, +1>(f, tw, tid);                     // F^H = un-normalised inverse
+        if (tid < N) {
+            rowbuf[((a.S - 1) % 3) * N + tid] = Pipe::row_of(a, b, a.S - 1, tid);
+            rowbuf[((a.S + 1) % 3) * N + tid] = Pipe::row_of(a, b, a.S - 2, tid);      // (S - 2) mod 3
+        }
+        __syncthreads();
+        cf t[EPT];
+        Pipe::load_factors(a, rowbuf + ((a.S - 1) % 3) * N, y0, tid, m);
+        Pipe::load_field(a.tape + (size_t)(a.S - 1) * a.tape_stride + (size_t)b * N * N, tid, t);
+        if (a.det_mode == BDOF_DET_NEAR) res_prop<N, T, true>(f, a.hdetT, tw, tid);
+        else if (far) res_fft2<N, T, +1>(f, tw, tid);                  // F^H = un-normalised inverse
         for (int z = a.S - 1; z >= 0; --z) {
+            const long long r2 = Pipe::row_of(a, b, z - 2, tid);
             const bool prop_after = z < a.S - 1 || (a.tf_all && !far);
-            if (prop_after) res_prop<N, true>(f, a.hsT, tw, tid);
+            if (prop_after) res_prop<N, T, true>(f, a.hsT, tw, tid);
             const cf car = a.carrier[z];
-            const cf* tape = a.tape + (size_t)z * a.tape_stride + (size_t)b * N * N;
             float2* gdst = a.grot + ((size_t)b * a.S + z) * N * N;
-            for (int e = tid; e < N * N; e += T) {
-                const int x = e / N, y = e - x * N;
-                const cf G = f[x * P + y];
-                const cf phi = cadd(tape[e], car);
-                const cf t = cmulc(G, phi);
-                gdst[e] = make_float2(a.k * t.y, -a.k * t.x);
-                const float2 m1 = g_mod_value(a.obj, b, x, y, z, N);
-                f[x * P + y] = cmulc(G, make_float2(1.f + m1.x, m1.y));
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int e = tl + i * T;
+                if (EPT * T == N * N || e < N * N) {
+                    const int x = e / N, y = e - x * N;
+                    const cf G = f[x * P + y];
+                    const cf phi = cadd(t[i], car);
+                    const cf q = cmulc(G, phi);
+                    gdst[e] = make_float2(a.k * q.y, -a.k * q.x);
+                    f[x * P + y] = cmulc(G, make_float2(1.f + m[i].x, m[i].y));
+                }
             }
             __syncthreads();
+            if (z > 0) {
+                Pipe::load_factors(a, rowbuf + ((z - 1) % 3) * N, y0, tid, m);
+                Pipe::load_field(a.tape + (size_t)(z - 1) * a.tape_stride + (size_t)b * N * N, tid, t);
+            }
+            if (tid < N) rowbuf[((z + 1) % 3) * N + tid] = r2;           // (z - 2) mod 3
         }
     }
     if (a.meas) {

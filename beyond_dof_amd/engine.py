@@ -21,16 +21,22 @@ def _idx_buf(ctx, values):
 class MultisliceEngine(object):
     """One wavefield geometry (NY x NX x S) on one GPU."""
 
-    def __init__(self, ny, nx, n_slice, batch_max, with_grad=True, device=0, stream=None, force_generic=False):
-        """Powers of two in 64..1024 run on the fused kernels, every other size on the generic engine (rocFFT);
-        force_generic=True sends any size there (on-device cross-check of the fused path)."""
+    def __init__(self, ny, nx, n_slice, batch_max, with_grad=True, device=0, stream=None, force_generic=False, engine='auto'):
+        """Engines (include/bdof.h, bdof_configure): powers of two in 64..1024 run on the fused streaming kernels; small
+        square fields (32..128, e.g. the 72 x 72 ptychography probe) on the LDS-resident kernel when there is no fused plan
+        or the batch is large; every other size on the generic engine (rocFFT).  engine='generic' (= force_generic=True),
+        'streaming' (never resident) or 'resident' (resident for every batch size) pin the choice for cross-checks."""
+        if engine not in ('auto', 'generic', 'streaming', 'resident'):
+            raise ValueError('engine must be auto, generic, streaming or resident')
+        force_generic = force_generic or engine == 'generic'
         self.ctx = _lib.Context(device, stream)
         self.lib = self.ctx.lib
         self.h = self.ctx.handle
         self.ny, self.nx, self.n_slice, self.batch_max = int(ny), int(nx), int(n_slice), int(batch_max)
         self.with_grad = bool(with_grad)
         self.ctx.check(self.lib.bdof_configure(self.h, self.ny, self.nx, self.n_slice, self.batch_max,
-                                               int(bool(with_grad)) | (2 if (force_generic or os.environ.get('BDOF_FORCE_GENERIC')) else 0)))
+                                               int(bool(with_grad)) | (2 if (force_generic or os.environ.get('BDOF_FORCE_GENERIC')) else 0)
+                                               | (4 if engine == 'streaming' else 0) | (8 if engine == 'resident' else 0)))
         self.det_mode = _lib.DET_NONE
         self._keep = {}          # device buffers that must outlive the calls that registered them
         self._tables = None

@@ -39,11 +39,15 @@ int bdof_sync(bdof_ctx* ctx);
 void* bdof_stream(bdof_ctx* ctx);   /* the ctx's hipStream_t, for ordering foreign work (collectives) against it */
 int bdof_device_count(void);
 
-/* Workspace for wavefields of NY x NX, S slices, up to Bmax wavefields per launch.  Powers of two in 64..1024 run on the
- * fused hand-written FFT kernels; every other size (e.g. the 72 x 72 probes of reconstruct_ptycho.py:106) runs on the
- * generic-size engine (rocFFT + point-wise kernels), as does any size when bit 1 of with_grad is set (cross-checks).
- * Bit 0 of with_grad also allocates the tape (S fields per wavefield) and the
- * rotated-frame gradient.  Replaces the per-call allocations of multislice_propagate_batch_numpy
+/* Workspace for wavefields of NY x NX, S slices, up to Bmax wavefields per launch.  Three engines sit behind the same calls:
+ *   - fused streaming kernels (hand-written FFTs, field in HBM): NY, NX powers of two in 64..1024;
+ *   - LDS-resident kernel (the whole field stays in one CU's LDS through all slices, one launch per minibatch): square
+ *     fields of 32, 36, 48, 64, 72, 80, 96 or 128 pixels — the probes of the ptychography drivers
+ *     (cnn_propagator/reconstruct_ptycho.py:106); chosen when no fused plan exists or the batch has >= CUs/4 wavefields;
+ *   - generic-size engine (rocFFT + point-wise kernels): every other size.
+ * with_grad bits: 0 allocate the tape (S fields per wavefield) and the rotated-frame gradient; 1 force the generic-size
+ * engine (cross-checks); 2 never use the resident engine; 3 use it for every batch size.
+ * Replaces the per-call allocations of multislice_propagate_batch_numpy
  * (cnn_propagator/np_funcs.py:20,43) and of autograd's tape (cnn_propagator/fullfield.py:329). */
 int bdof_configure(bdof_ctx* ctx, int NY, int NX, int S, int Bmax, int with_grad);
 

