@@ -26,6 +26,12 @@ static inline bool resident_supported(int n) {
     return n == 32 || n == 36 || n == 48 || n == 64 || n == 72 || n == 80 || n == 96 || n == 128;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() on gfx9 also drains vmcnt, i.e. every barrier would wait
+// for the global loads prefetched for the next slice and for the tape / gradient stores of the previous one — one HBM round
+// trip per barrier.  Nothing here communicates between threads through global memory (a thread re-reads only the tape
+// elements it wrote itself), so waiting for the LDS counter is sufficient.
+__device__ __forceinline__ void res_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int SIGN> __device__ __forceinline__ void dft3(cf& a0, cf& a1, cf& a2) {
     const cf t1 = cadd(a1, a2);
     const cf t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
@@ -116,7 +122,7 @@ __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid) {
             res_dft<R, SIGN>(u[c]);
         }
     }
-    __syncthreads();
+    res_sync();
 #pragma unroll
     for (int c = 0; c < CNT; ++c) {
         const int q = tid + c * T;
@@ -128,7 +134,7 @@ __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid) {
             for (int m = 0; m < R; ++m) dst[m * NS * ES] = u[c][m];
         }
     }
-    __syncthreads();
+    res_sync();
 }
 
 template <int N, int T, int SIGN, bool ALONG_Y> __device__ __forceinline__ void res_lines(cf* f, const cf* tw, int tid) {
@@ -171,7 +177,7 @@ template <int N, int T, bool CONJ> __device__ __forceinline__ void res_hmul(cf* 
         if constexpr (CONJ) h.y = -h.y;
         f[x * P + y] = cmul(f[x * P + y], h);
     }
-    __syncthreads();
+    res_sync();
 }
 
 // F^-1 (h .) F   (CONJ: the adjoint step, conj(h))
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
     const bool far = a.det_mode == BDOF_DET_FAR;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const int y0 = a.obj.yoff ? a.obj.yoff[b] : 0;
-        __syncthreads();
+        res_sync();
         for (int e = tid; e < N * N; e += T) {
             const int x = e / N, y = e - x * N;
             f[x * P + y] = a.probe[e];
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
             rowbuf[tid] = Pipe::row_of(a, b, 0, tid);
             rowbuf[N + tid] = Pipe::row_of(a, b, 1, tid);
         }
-        __syncthreads();
+        res_sync();
         float2 m[EPT];
         Pipe::load_factors(a, rowbuf, y0, tid, m);
         // ---- forward sweep --------------------------------------------------------------------
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     if (tape) tape[e] = phi;
                 }
             }
-            __syncthreads();
+            res_sync();
             if (z + 1 < a.S) Pipe::load_factors(a, rowbuf + ((z + 1) % 3) * N, y0, tid, m);
             if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;
             const bool last = z == a.S - 1;
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
             rowbuf[((a.S - 1) % 3) * N + tid] = Pipe::row_of(a, b, a.S - 1, tid);
             rowbuf[((a.S + 1) % 3) * N + tid] = Pipe::row_of(a, b, a.S - 2, tid);      // (S - 2) mod 3
         }
-        __syncthreads();
+        res_sync();
         cf t[EPT];
         Pipe::load_factors(a, rowbuf + ((a.S - 1) % 3) * N, y0, tid, m);
         Pipe::load_field(a.tape + (size_t)(a.S - 1) * a.tape_stride + (size_t)b * N * N, tid, t);
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     f[x * P + y] = cmulc(G, make_float2(1.f + m[i].x, m[i].y));
                 }
             }
-            __syncthreads();
+            res_sync();
             if (z > 0) {
                 Pipe::load_factors(a, rowbuf + ((z - 1) % 3) * N, y0, tid, m);
                 Pipe::load_field(a.tape + (size_t)(z - 1) * a.tape_stride + (size_t)b * N * N, tid, t);
