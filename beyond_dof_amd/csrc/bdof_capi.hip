@@ -585,12 +585,7 @@ static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, b
         case 36: r = resident_launch<36>(c, a, grid); break;
         case 48: r = resident_launch<48>(c, a, grid); break;
         case 64: r = resident_launch<64>(c, a, grid); break;
-        case 72: {
-            static const int t72 = std::getenv("BDOF_RES_T72") ? std::atoi(std::getenv("BDOF_RES_T72")) : 0;   // tuning switch
-            if (t72 == 512) r = resident_launch_t<72, 512, 4>(c, a, grid);
-            else r = resident_launch<72>(c, a, grid);
-            break;
-        }
+        case 72: r = resident_launch<72>(c, a, grid); break;
         case 80: r = resident_launch<80>(c, a, grid); break;
         case 96: r = resident_launch<96>(c, a, grid); break;
         case 128: r = resident_launch<128>(c, a, grid); break;

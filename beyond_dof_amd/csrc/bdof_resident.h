@@ -13,14 +13,16 @@
 #include "bdof_generic.h"
 
 template <int N> struct ResPlan;      // radices of the Stockham passes of one line, and the workgroup size
-template <> struct ResPlan<32> { static constexpr int n = 2, R0 = 8, R1 = 4, R2 = 1, T = 64, WPE = 2; };
-template <> struct ResPlan<36> { static constexpr int n = 2, R0 = 4, R1 = 9, R2 = 1, T = 128, WPE = 2; };
-template <> struct ResPlan<48> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 3, T = 192, WPE = 3; };
-template <> struct ResPlan<64> { static constexpr int n = 2, R0 = 8, R1 = 8, R2 = 1, T = 512, WPE = 4; };
-template <> struct ResPlan<72> { static constexpr int n = 2, R0 = 8, R1 = 9, R2 = 1, T = 704, WPE = 6; };   // 648 / 576 butterflies per pass: one per thread
-template <> struct ResPlan<80> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 5, T = 512, WPE = 4; };
-template <> struct ResPlan<96> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 3, T = 768, WPE = 3; };
-template <> struct ResPlan<128> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 4, T = 1024, WPE = 4; };
+template <> struct ResPlan<32> { static constexpr int n = 2, R0 = 8, R1 = 4, R2 = 1, T = 64, WPE = 2; static constexpr bool FUSE = true; };
+template <> struct ResPlan<36> { static constexpr int n = 2, R0 = 4, R1 = 9, R2 = 1, T = 128, WPE = 2; static constexpr bool FUSE = true; };
+template <> struct ResPlan<48> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 3, T = 192, WPE = 3; static constexpr bool FUSE = true; };
+template <> struct ResPlan<64> { static constexpr int n = 2, R0 = 8, R1 = 8, R2 = 1, T = 512, WPE = 4; static constexpr bool FUSE = true; };
+// 72 (the reference drivers' probe): 648 / 576 butterflies per pass, one per thread; the epilogues of the fused form do not
+// fit the 80 registers that two 11-wave workgroups per CU leave (measured: fused, 576 threads 12.8 ms; this 11.9 ms)
+template <> struct ResPlan<72> { static constexpr int n = 2, R0 = 8, R1 = 9, R2 = 1, T = 704, WPE = 6; static constexpr bool FUSE = false; };
+template <> struct ResPlan<80> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 5, T = 512, WPE = 4; static constexpr bool FUSE = true; };
+template <> struct ResPlan<96> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 3, T = 768, WPE = 3; static constexpr bool FUSE = true; };
+template <> struct ResPlan<128> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 4, T = 1024, WPE = 4; static constexpr bool FUSE = true; };
 
 static inline bool resident_supported(int n) {
     return n == 32 || n == 36 || n == 48 || n == 64 || n == 72 || n == 80 || n == 96 || n == 128;
@@ -92,8 +94,17 @@ template <int R, int SIGN> __device__ __forceinline__ void res_dft(cf (&u)[R]) {
 
 // One Stockham pass (radix R, NS = product of the earlier radices) over the N lines of the field, in place.
 // ALONG_Y: lines are the rows x (elements contiguous); else lines are the columns y (element stride P).
-template <int N, int R, int NS, int SIGN, bool ALONG_Y, int T>
-__device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid) {
+// Epilogue hooks of a pass: `pre(c, m, line, pos)` is called in the read phase for the element the thread will write at
+// position `pos` of line `line` (global loads are issued here), `post(c, m, line, pos, v)` returns the value to store.
+// Only used on passes along x (lines = columns: consecutive lanes are consecutive y, so the global accesses coalesce).
+struct EpiNone {
+    static constexpr bool active = false, pre_in_pass = false;
+    __device__ __forceinline__ void pre(int, int, int, int) {}
+    __device__ __forceinline__ cf post(int, int, int, int, cf v) { return v; }
+};
+
+template <int N, int R, int NS, int SIGN, bool ALONG_Y, int T, class Epi>
+__device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid, Epi& epi) {
     // every index below is invariant across slices: without this the compiler hoists the address math of all 16 passes
     // out of the slice loop and keeps it in registers (250+ VGPRs, spills).  Recomputing it per pass is a few VALU ops.
     asm volatile("" : "+v"(tid));
@@ -110,6 +121,11 @@ __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid) {
             const cf* src = f + (ALONG_Y ? line * P : line) + j * ES;
 #pragma unroll
             for (int m = 0; m < R; ++m) u[c][m] = src[m * (N / R) * ES];
+            if constexpr (Epi::active && Epi::pre_in_pass) {
+                const int j0 = (j / NS) * NS * R + j % NS;
+#pragma unroll
+                for (int m = 0; m < R; ++m) epi.pre(c, m, line, j0 + m * NS);
+            }
             if constexpr (NS > 1) {
                 const int k = j % NS;
 #pragma unroll
@@ -128,26 +144,44 @@ __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid) {
         const int q = tid + c * T;
         if (CNT * T == NB || q < NB) {
             const int line = q % N, j = q / N;
-            const int k = j % NS;
-            cf* dst = f + (ALONG_Y ? line * P : line) + ((j / NS) * NS * R + k) * ES;
+            const int j0 = (j / NS) * NS * R + j % NS;
+            cf* dst = f + (ALONG_Y ? line * P : line) + j0 * ES;
 #pragma unroll
-            for (int m = 0; m < R; ++m) dst[m * NS * ES] = u[c][m];
+            for (int m = 0; m < R; ++m) dst[m * NS * ES] = epi.post(c, m, line, j0 + m * NS, u[c][m]);
         }
     }
     res_sync();
 }
 
-template <int N, int T, int SIGN, bool ALONG_Y> __device__ __forceinline__ void res_lines(cf* f, const cf* tw, int tid) {
+// radix and butterflies per thread of the LAST pass of a line (the one that carries an epilogue)
+template <int N, int T> struct ResLast {
     typedef ResPlan<N> Pl;
-    res_pass<N, Pl::R0, 1, SIGN, ALONG_Y, T>(f, tw, tid);
-    res_pass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, T>(f, tw, tid);
-    if constexpr (Pl::n > 2) res_pass<N, Pl::R2, Pl::R0 * Pl::R1, SIGN, ALONG_Y, T>(f, tw, tid);
+    static constexpr int R = Pl::n > 2 ? Pl::R2 : Pl::R1;
+    static constexpr int CNT = (N * (N / R) + T - 1) / T;
+};
+
+template <int N, int T, int SIGN, bool ALONG_Y, class Epi>
+__device__ __forceinline__ void res_lines(cf* f, const cf* tw, int tid, Epi& epi) {
+    typedef ResPlan<N> Pl;
+    EpiNone none;
+    res_pass<N, Pl::R0, 1, SIGN, ALONG_Y, T>(f, tw, tid, none);
+    if constexpr (Pl::n > 2) {
+        res_pass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, T>(f, tw, tid, none);
+        res_pass<N, Pl::R2, Pl::R0 * Pl::R1, SIGN, ALONG_Y, T>(f, tw, tid, epi);
+    } else {
+        res_pass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, T>(f, tw, tid, epi);
+    }
 }
 
-// un-normalised 2-D DFT of the field image f[x * P + y], SIGN = -1 forward, +1 inverse
+// un-normalised 2-D DFT of the field image f[x * P + y], SIGN = -1 forward, +1 inverse; `epi` rides on the last pass
+template <int N, int T, int SIGN, class Epi> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid, Epi& epi) {
+    EpiNone none;
+    res_lines<N, T, SIGN, true>(f, tw, tid, none);
+    res_lines<N, T, SIGN, false>(f, tw, tid, epi);
+}
 template <int N, int T, int SIGN> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid) {
-    res_lines<N, T, SIGN, true>(f, tw, tid);
-    res_lines<N, T, SIGN, false>(f, tw, tid);
+    EpiNone none;
+    res_fft2<N, T, SIGN>(f, tw, tid, none);
 }
 
 struct ResArgs {
@@ -168,23 +202,51 @@ struct ResArgs {
     float k, seed_scale;
 };
 
-template <int N, int T, bool CONJ> __device__ __forceinline__ void res_hmul(cf* f, const cf* hT, int tid) {
-    asm volatile("" : "+v"(tid));
-    constexpr int P = N | 1;
-    for (int e = tid; e < N * N; e += T) {
-        const int x = e / N, y = e - x * N;
-        cf h = hT[e];
-        if constexpr (CONJ) h.y = -h.y;
-        f[x * P + y] = cmul(f[x * P + y], h);
+// transfer-function multiply folded into the last pass of the forward transform: the thread writing element (kx, ky)
+// multiplies it by hT[kx][ky] on the way (no separate read-modify-write sweep of the LDS image)
+template <int N, int T, bool CONJ> struct EpiH {
+    static constexpr bool active = true, pre_in_pass = true;      // L2-resident table: the latency of one pass is enough
+    const cf* hT;
+    cf h[ResLast<N, T>::CNT][ResLast<N, T>::R];
+    __device__ __forceinline__ void pre(int c, int m, int line, int pos) { h[c][m] = hT[pos * N + line]; }
+    __device__ __forceinline__ cf post(int c, int m, int, int, cf v) {
+        cf w = h[c][m];
+        if constexpr (CONJ) w.y = -w.y;
+        return cmul(v, w);
     }
-    res_sync();
+};
+
+// Issue the loads of an epilogue ahead of the pass that consumes them: same (butterfly, output) -> (line, position) map as
+// the last pass along x of res_lines.
+template <int N, int T, class Epi> __device__ __forceinline__ void res_epi_prefetch(int tid, Epi& epi) {
+    if constexpr (Epi::active && !Epi::pre_in_pass) {
+        asm volatile("" : "+v"(tid));
+        constexpr int R = ResLast<N, T>::R, CNT = ResLast<N, T>::CNT, NS = N / R, NB = N * (N / R);
+#pragma unroll
+        for (int c = 0; c < CNT; ++c) {
+            const int q = tid + c * T;
+            if (CNT * T == NB || q < NB) {
+                const int line = q % N, j = q / N;
+                const int j0 = (j / NS) * NS * R + j % NS;
+#pragma unroll
+                for (int m = 0; m < R; ++m) epi.pre(c, m, line, j0 + m * NS);
+            }
+        }
+    }
 }
 
-// F^-1 (h .) F   (CONJ: the adjoint step, conj(h))
+// F^-1 (h .) F   (CONJ: the adjoint step, conj(h)); `epi` rides on the last pass of the inverse transform
+template <int N, int T, bool CONJ, class Epi>
+__device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid, Epi& epi) {
+    EpiH<N, T, CONJ> eh;
+    eh.hT = hT;
+    res_fft2<N, T, -1>(f, tw, tid, eh);
+    res_epi_prefetch<N, T>(tid, epi);
+    res_fft2<N, T, +1>(f, tw, tid, epi);
+}
 template <int N, int T, bool CONJ> __device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid) {
-    res_fft2<N, T, -1>(f, tw, tid);
-    res_hmul<N, T, CONJ>(f, hT, tid);
-    res_fft2<N, T, +1>(f, tw, tid);
+    EpiNone none;
+    res_prop<N, T, CONJ>(f, hT, tw, tid, none);
 }
 
 // Global loads of a slice are issued one propagation step ahead of their use (software pipeline): the modulation factors
@@ -222,10 +284,64 @@ template <int N, int T> struct ResPipe {
 };
 
 // WPE = waves per SIMD the register allocation must leave room for (two workgroups per CU where the LDS image allows)
+// Modulation of the NEXT slice folded into the last pass of a propagation step: the element (x, y) leaves the inverse
+// transform as psi_{z+1}(x, y), is multiplied by that slice's factor and stored as phi_{z+1} (LDS + tape).
+template <int N, int T> struct EpiMod {
+    static constexpr bool active = true, pre_in_pass = false;     // HBM loads: issued by res_epi_prefetch, four passes early
+    const ResArgs* a;
+    const long long* rows;     // object rows of slice z+1
+    cf* tape;                  // nullable: tape of slice z+1 for this wavefield
+    cf car;
+    int y0;
+    float2 fac[ResLast<N, T>::CNT][ResLast<N, T>::R];
+    __device__ __forceinline__ void pre(int c, int m, int line, int pos) {
+        const long long srow = rows[pos];
+        const int yg = line + y0;
+        const int yc = min(max(yg, 0), a->obj.volNY - 1);
+        const float2 v = a->obj.vol[(size_t)(srow >= 0 ? srow : 0) * a->obj.volNY + yc];
+        const bool in = srow >= 0 && yg == yc;
+        fac[c][m] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
+    }
+    __device__ __forceinline__ cf post(int c, int m, int line, int pos, cf v) {
+        const cf phi = modulate_eps(v, car, fac[c][m]);
+        if (tape) tape[pos * N + line] = phi;
+        return phi;
+    }
+};
+
+// Point-wise adjoint step of slice z folded into the last pass of the adjoint propagation that precedes it.
+template <int N, int T> struct EpiBwd {
+    static constexpr bool active = true, pre_in_pass = false;
+    const ResArgs* a;
+    const long long* rows;     // object rows of slice z
+    const cf* tape;
+    float2* gdst;
+    cf car;
+    int y0;
+    float2 fac[ResLast<N, T>::CNT][ResLast<N, T>::R];
+    cf tp[ResLast<N, T>::CNT][ResLast<N, T>::R];
+    __device__ __forceinline__ void pre(int c, int m, int line, int pos) {
+        const long long srow = rows[pos];
+        const int yg = line + y0;
+        const int yc = min(max(yg, 0), a->obj.volNY - 1);
+        const float2 v = a->obj.vol[(size_t)(srow >= 0 ? srow : 0) * a->obj.volNY + yc];
+        const bool in = srow >= 0 && yg == yc;
+        fac[c][m] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
+        tp[c][m] = tape[pos * N + line];
+    }
+    __device__ __forceinline__ cf post(int c, int m, int line, int pos, cf G) {
+        const cf phi = cadd(tp[c][m], car);
+        const cf q = cmulc(G, phi);
+        gdst[pos * N + line] = make_float2(a->k * q.y, -a->k * q.x);
+        return cmulc(G, make_float2(1.f + fac[c][m].x, fac[c][m].y));
+    }
+};
+
 template <int N, int T, int WPE>
 __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
     typedef ResPipe<N, T> Pipe;
     constexpr int P = N | 1, EPT = Pipe::EPT;
+    constexpr bool FUSE = ResPlan<N>::FUSE;      // point-wise steps folded into the neighbouring passes (EpiMod / EpiBwd)
     extern __shared__ __align__(16) unsigned char res_smem[];
     cf* f = reinterpret_cast<cf*>(res_smem);
     cf* tw = f + N * P;
@@ -246,7 +362,43 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
             rowbuf[N + tid] = Pipe::row_of(a, b, 1, tid);
         }
         res_sync();
+        // ---- forward sweep --------------------------------------------------------------------
         float2 m[EPT];
+        if constexpr (FUSE) {
+        {   // slice 0 is modulated on its own; every later slice inside the propagation step that produces it (EpiMod)
+            Pipe::load_factors(a, rowbuf, y0, tid, m);
+            const cf car = a.carrier[0];
+            cf* tape = a.tape ? a.tape + (size_t)b * N * N : nullptr;
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int e = tl + i * T;
+                if (EPT * T == N * N || e < N * N) {
+                    const int x = e / N, y = e - x * N;
+                    const cf phi = modulate_eps(f[x * P + y], car, m[i]);
+                    f[x * P + y] = phi;
+                    if (tape) tape[e] = phi;
+                }
+            }
+            res_sync();
+        }
+        for (int z = 0; z < a.S; ++z) {
+            const long long r2 = Pipe::row_of(a, b, z + 2, tid);
+            if (z + 1 < a.S) {
+                EpiMod<N, T> em;
+                em.a = &a;
+                em.rows = rowbuf + ((z + 1) % 3) * N;
+                em.tape = a.tape ? a.tape + (size_t)(z + 1) * a.tape_stride + (size_t)b * N * N : nullptr;
+                em.car = a.carrier[z + 1];
+                em.y0 = y0;
+                res_prop<N, T, false>(f, a.hsT, tw, tid, em);
+            } else if (a.tf_all && !far) {
+                res_prop<N, T, false>(f, a.hsT, tw, tid);
+            }
+            if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;      // read two propagation steps from now
+        }
+        } else {
         Pipe::load_factors(a, rowbuf, y0, tid, m);
         // ---- forward sweep --------------------------------------------------------------------
         for (int z = 0; z < a.S; ++z) {
@@ -271,6 +423,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
             const bool last = z == a.S - 1;
             if (!last || (a.tf_all && !far)) res_prop<N, T, false>(f, a.hsT, tw, tid);
         }
+        }
         if (a.det_mode == BDOF_DET_NEAR) res_prop<N, T, false>(f, a.hdetT, tw, tid);
         else if (far) res_fft2<N, T, -1>(f, tw, tid);
         // ---- detector wave, loss, seed --------------------------------------------------------
@@ -289,6 +442,49 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
             rowbuf[((a.S + 1) % 3) * N + tid] = Pipe::row_of(a, b, a.S - 2, tid);      // (S - 2) mod 3
         }
         res_sync();
+        if constexpr (FUSE) {
+        if (a.det_mode == BDOF_DET_NEAR) res_prop<N, T, true>(f, a.hdetT, tw, tid);
+        else if (far) res_fft2<N, T, +1>(f, tw, tid);                  // F^H = un-normalised inverse
+        for (int z = a.S - 1; z >= 0; --z) {
+            const long long r2 = Pipe::row_of(a, b, z - 2, tid);
+            const bool prop_after = z < a.S - 1 || (a.tf_all && !far);
+            const cf* tape = a.tape + (size_t)z * a.tape_stride + (size_t)b * N * N;
+            float2* gdst = a.grot + ((size_t)b * a.S + z) * N * N;
+            if (prop_after) {
+                EpiBwd<N, T> eb;
+                eb.a = &a;
+                eb.rows = rowbuf + (z % 3) * N;
+                eb.tape = tape;
+                eb.gdst = gdst;
+                eb.car = a.carrier[z];
+                eb.y0 = y0;
+                res_prop<N, T, true>(f, a.hsT, tw, tid, eb);
+            } else {
+                // the slice the adjoint sweep starts from when no transfer-function step follows the last slice
+                float2 m[EPT];
+                cf t[EPT];
+                Pipe::load_factors(a, rowbuf + (z % 3) * N, y0, tid, m);
+                Pipe::load_field(tape, tid, t);
+                const cf car = a.carrier[z];
+                int tl = tid;
+                asm volatile("" : "+v"(tl));
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    const int e = tl + i * T;
+                    if (EPT * T == N * N || e < N * N) {
+                        const int x = e / N, y = e - x * N;
+                        const cf G = f[x * P + y];
+                        const cf phi = cadd(t[i], car);
+                        const cf q = cmulc(G, phi);
+                        gdst[e] = make_float2(a.k * q.y, -a.k * q.x);
+                        f[x * P + y] = cmulc(G, make_float2(1.f + m[i].x, m[i].y));
+                    }
+                }
+                res_sync();
+            }
+            if (tid < N) rowbuf[((z + 1) % 3) * N + tid] = r2;           // slot of slice z - 2
+        }
+            } else {
         cf t[EPT];
         Pipe::load_factors(a, rowbuf + ((a.S - 1) % 3) * N, y0, tid, m);
         Pipe::load_field(a.tape + (size_t)(a.S - 1) * a.tape_stride + (size_t)b * N * N, tid, t);
@@ -321,6 +517,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
             }
             if (tid < N) rowbuf[((z + 1) % 3) * N + tid] = r2;           // (z - 2) mod 3
         }
+            }
     }
     if (a.meas) {
         __shared__ double w1[16], w2[16];
