@@ -28,12 +28,7 @@ from .util import print_flush
 PI = util.PI
 
 
-def upsample_2x(arr):
-    """cnn_propagator/util.py:350-360."""
-    from scipy.ndimage import gaussian_filter
-    out = np.zeros([arr.shape[0] * 2, arr.shape[1] * 2, arr.shape[2] * 2])
-    out[::2, ::2, ::2] = arr
-    return gaussian_filter(out, 1)
+upsample_2x = util.upsample_2x      # cnn_propagator/util.py:350-360
 
 
 def create_probe_initial_guess(data_fname, dist_nm, energy_ev, psize_nm):

@@ -23,6 +23,32 @@ def get_kernel(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=PI):
     return np.exp(1j * k * dist_nm) * np.exp(-1j * pi * lmbda_nm * dist_nm * (uu ** 2 + vv ** 2))
 
 
+def get_kernel_ir(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=PI):
+    """Impulse-response form of the Fresnel kernel (cnn_propagator/util.py:105-127): the real-space kernel sampled on the
+    pixel grid, Fourier transformed, times the pixel area.  The reference's propagator never selects it (np_funcs.py:55
+    forces 'TF'); kept as the `kernel='IR'` option of device_transfer_function."""
+    ny, nx = int(grid_shape[0]), int(grid_shape[1])
+    k = 2 * pi / lmbda_nm
+    sy, sx = voxel_nm[0] * ny, voxel_nm[1] * nx
+    x = np.arange(-sx / 2., -sx / 2. + sx, voxel_nm[1])
+    y = np.arange(-sy / 2., -sy / 2. + sy, voxel_nm[0])
+    xx, yy = np.meshgrid(x, y)
+    h = np.exp(1j * k * dist_nm) / (1j * lmbda_nm * dist_nm) * np.exp(1j * k / (2 * dist_nm) * (xx ** 2 + yy ** 2))
+    return np.fft.fftshift(np.fft.fft2(h)) * voxel_nm[0] * voxel_nm[1]
+
+
+def upsample_2x(arr):
+    """Multiscale hand-over (cnn_propagator/util.py:350-360): zero-stuffing by 2 along the three spatial axes followed by a
+    sigma-1 gaussian filter; 4-D arrays channel by channel."""
+    from scipy.ndimage import gaussian_filter
+    arr = np.asarray(arr)
+    if arr.ndim == 4:
+        return np.stack([upsample_2x(arr[..., i]) for i in range(arr.shape[3])], axis=3)
+    out = np.zeros([2 * n for n in arr.shape])
+    out[::2, ::2, ::2] = arr
+    return gaussian_filter(out, 1)
+
+
 def device_transfer_function(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI):
     """H prepared for libbdof: un-shifted [ky][kx], 1/(NX*NY) folded in, complex64."""
     h = get_kernel(dist_nm, lmbda_nm, voxel_nm, (ny, nx), pi=pi)

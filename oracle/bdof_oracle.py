@@ -40,6 +40,32 @@ def get_kernel(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=PI):
     return np.exp(1j * k * dist_nm) * np.exp(-1j * pi * lmbda_nm * dist_nm * (u ** 2 + v ** 2))
 
 
+def get_kernel_ir(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=PI):
+    """cnn_propagator/util.py:105-127 — impulse-response kernel: the real-space Fresnel kernel sampled on the pixel grid
+    (origin at -size/2), fft2 + fftshift, times the pixel area.  Dead code on the hot path (np_funcs.py:55 forces the
+    transfer-function form); restated for the `kernel='IR'` option."""
+    size_nm = np.array(voxel_nm) * np.array(grid_shape)
+    k = 2 * pi / lmbda_nm
+    ymin, xmin = np.array(size_nm)[:2] / -2.
+    dy, dx = voxel_nm[0:2]
+    x = np.arange(xmin, xmin + size_nm[1], dx)
+    y = np.arange(ymin, ymin + size_nm[0], dy)
+    x, y = np.meshgrid(x, y)
+    h = np.exp(1j * k * dist_nm) / (1j * lmbda_nm * dist_nm) * np.exp(1j * k / (2 * dist_nm) * (x ** 2 + y ** 2))
+    return np.fft.fftshift(np.fft.fft2(h)) * voxel_nm[0] * voxel_nm[1]
+
+
+def upsample_2x(arr):
+    """cnn_propagator/util.py:350-360 — multiscale hand-over: zero-stuff by 2 along the three spatial axes, gaussian
+    filter sigma 1 (scipy default mode 'reflect'); a 4-D array is treated channel by channel."""
+    from scipy.ndimage import gaussian_filter
+    if arr.ndim == 4:
+        return np.stack([upsample_2x(arr[..., i]) for i in range(arr.shape[3])], axis=3)
+    out = np.zeros([2 * n for n in arr.shape])
+    out[::2, ::2, ::2] = arr
+    return gaussian_filter(out, 1)
+
+
 def _propagate(wavefront, h):
     """cnn_propagator/np_funcs.py:42 — fft2 / fftshift / *h / ifftshift / ifft2."""
     return np.fft.ifft2(np.fft.ifftshift(np.fft.fftshift(np.fft.fft2(wavefront), axes=[1, 2]) * h, axes=[1, 2]))

@@ -4,6 +4,7 @@ Run only in the build container (needs /root/reference, which never travels):
 
     python tests/golden/make_golden.py            # G1-G6  -> tests/golden/*.npz
     /opt/conda/bin/python3.9 tests/golden/make_golden.py --h5   # G7 (h5py 3.3.0 lives there)
+    python tests/golden/make_golden.py --g8       # G8 (get_kernel_ir, upsample_2x)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -148,6 +149,22 @@ def main():
     print('golden vectors written to', HERE)
 
 
+def main_g8():
+    """G8: the two helpers off the hot path that the entry points can still reach (kernel='IR', multiscale)."""
+    ref_util, _ = _import_reference()
+    g8 = {}
+    for (Y, X) in [(8, 8), (9, 12), (32, 32)]:
+        for dist in [50.0, 1000.0]:
+            g8['Hir_{}_{}_{}'.format(Y, X, int(dist))] = ref_util.get_kernel_ir(dist, 0.248, [1., 1., 1.], [Y, X, 4])
+    rng = np.random.default_rng(8)
+    a3 = rng.normal(size=(3, 4, 5))
+    a4 = rng.normal(size=(2, 3, 2, 2))
+    g8['up_in3'], g8['up_out3'] = a3, ref_util.upsample_2x(a3)
+    g8['up_in4'], g8['up_out4'] = a4, ref_util.upsample_2x(a4)
+    np.savez_compressed(os.path.join(HERE, 'g8_kernel_ir_upsample.npz'), **g8)
+    print('wrote g8')
+
+
 def main_h5():
     """G7: exchange/data files written by h5py 3.3.0 (run under /opt/conda/bin/python3.9)."""
     import h5py
@@ -173,5 +190,7 @@ def main_h5():
 if __name__ == '__main__':
     if '--h5' in sys.argv:
         main_h5()
+    elif '--g8' in sys.argv:
+        main_g8()
     else:
         main()

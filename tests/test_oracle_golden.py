@@ -87,3 +87,23 @@ def test_g6_split_tasks(golden_dir):
     parts = orc.split_tasks(g['arr'], int(g['split_size']))
     assert [len(p) for p in parts] == list(g['lengths'])
     assert np.array_equal(np.concatenate(parts), g['concat'])
+
+
+def test_g8_kernel_ir_and_upsample(golden_dir):
+    """get_kernel_ir (cnn_propagator/util.py:105-127) and upsample_2x (:350-360): oracle and host code against the
+    reference's own outputs."""
+    from beyond_dof_amd import util
+    g = np.load(os.path.join(golden_dir, 'g8_kernel_ir_upsample.npz'))
+    n = 0
+    for key in g.files:
+        if not key.startswith('Hir_'):
+            continue
+        _, Y, X, dist = key.split('_')
+        for fn in (orc.get_kernel_ir, util.get_kernel_ir):
+            h = fn(float(dist), 0.248, [1., 1., 1.], [int(Y), int(X), 4])
+            np.testing.assert_allclose(h, g[key], rtol=1e-12, atol=1e-12 * np.abs(g[key]).max())
+        n += 1
+    assert n == 6
+    for tag in ('3', '4'):
+        for fn in (orc.upsample_2x, util.upsample_2x):
+            np.testing.assert_allclose(fn(g['up_in' + tag]), g['up_out' + tag], rtol=0, atol=1e-15)
