@@ -1,0 +1,46 @@
+"""Worker of tests/test_gpu_dist.py: one rank of a two-rank full-field reconstruction step sharing ONE GPU.
+The collective runs through gloo (RCCL refuses two ranks on one device); everything else — sharding of the minibatch,
+the HIP path, the slab-pipelined rotation adjoint / all-reduce / Adam — is what an N-GPU run executes."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def problem():
+    rng = np.random.default_rng(11)
+    n, n_theta, mb = 64, 8, 2
+    meas = 1 + 0.05 * rng.normal(size=(n_theta, n, n))
+    init_d = np.clip(rng.normal(8.7e-7, 1e-7, size=(n, n, n)), 0, None)
+    return n, n_theta, mb, meas, init_d
+
+
+def main(out_dir):
+    from beyond_dof_amd.comm import TorchComm, minibatch_schedule
+    from beyond_dof_amd.solver import FullfieldSolver
+    from beyond_dof_amd import util
+    comm = TorchComm('gloo')
+    n, n_theta, mb, meas, init_d = problem()
+    coords = util.rotation_lookup([n, n, n], n_theta)
+    s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, coord_ls=coords, comm=comm, device=0)
+    s.set_measurements(meas)
+    s.set_volume(init_d, 0.1 * init_d)
+    s.reset_moments()
+    sched = minibatch_schedule(n_theta, comm.size, mb, rng=np.random.RandomState(3))
+    losses = []
+    for i, chunk in enumerate(sched):
+        mine = chunk[comm.rank * mb:(comm.rank + 1) * mb]
+        losses.append(s.step(i, mine, 1e-7, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11, want_loss=True, n_slabs=4))
+    g = s.gradient_to_host()
+    d, b = s.get_volume()
+    np.savez(os.path.join(out_dir, 'rank{}.npz'.format(comm.rank)), d=d, b=b, gd=g[0], gb=g[1], losses=np.array(losses),
+             sched=np.array(sched))
+    comm.Barrier()
+    comm.close()
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])

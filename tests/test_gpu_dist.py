@@ -1,0 +1,74 @@
+"""Two ranks, one GPU: the N-rank Adam step (angle-sharded minibatch, slab-pipelined rotation adjoint -> all-reduce ->
+Adam) against the single-rank step on the union minibatch.  gloo carries the collective because RCCL does not accept two
+ranks on one device; the RCCL flavour of the same pipeline runs on one rank in test_gpu_fullfield.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_ranks_on_one_gpu_match_the_union_minibatch(tmp_path):
+    import __graft_entry__ as entry
+    entry.build()
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import _dist_gpu_worker as w
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
+                   LOCAL_RANK=str(rank))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_dist_gpu_worker.py'), str(tmp_path)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), '\n'.join(o[-3000:] for o in outs)
+    r0, r1 = np.load(str(tmp_path / 'rank0.npz')), np.load(str(tmp_path / 'rank1.npz'))
+    # every rank ends with the same volume, bit for bit (same reduced gradient, same Adam)
+    assert np.array_equal(r0['d'], r1['d']) and np.array_equal(r0['b'], r1['b'])
+    assert np.array_equal(r0['gd'], r1['gd'])
+
+    # single rank, union minibatch (cnn_propagator/fullfield.py:343-351: the ranks' chunks tile the sorted minibatch)
+    from beyond_dof_amd import util
+    from beyond_dof_amd.solver import FullfieldSolver
+    n, n_theta, mb, meas, init_d = w.problem()
+    coords = util.rotation_lookup([n, n, n], n_theta)
+    s = FullfieldSolver(n, n, n, n_theta, 2 * mb, 5000., 1e-7, free_prop_cm=1e-4, coord_ls=coords)
+    s.set_measurements(meas)
+    s.set_volume(init_d, 0.1 * init_d)
+    s.reset_moments()
+    sched = r0['sched']
+    losses = []
+    for i, chunk in enumerate(sched):
+        losses.append(s.step(i, chunk, 1e-7, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11, want_loss=True))
+    g = s.gradient_to_host()
+    # rank gradients are means over mb angles, summed over ranks and divided by size inside Adam: compare g / size
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert rel(r0['gd'] / 2, g[0]) <= 1e-5 and rel(r0['gb'] / 2, g[1]) <= 1e-5
+    # losses: mean over the rank's own angles; the union loss is the mean of the two
+    assert abs(0.5 * (r0['losses'][-1] + r1['losses'][-1]) - losses[-1]) <= 1e-5 * abs(losses[-1])
+    d, b = s.get_volume()
+    lr = 1e-7
+    diff = np.abs(d - r0['d'])
+    assert np.mean(diff > 0.05 * lr) < 2e-3          # Adam's first steps are sign-like: see test_gpu_fullfield.py
+    assert rel(r0['d'], d) <= 2e-3
