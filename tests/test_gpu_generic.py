@@ -105,3 +105,31 @@ def test_ptychography_with_72x72_probe(engine_mod):
     rl, rgd, rgb = orc.ptycho_loss_and_grad(od, ob, coords[i_theta], pos, pos, meas, prr, pii, psz, 5000., 1e-7)
     assert abs(loss - rl) <= 5e-5 * rl
     assert rel(gd, rgd) <= 1e-3 and rel(gb, rgb) <= 1e-3
+
+
+@pytest.mark.parametrize('n,S,fp', [(2048, 3, None), (4096, 2, 1e-4)])
+def test_cfg4_field_sizes_vs_oracle(engine_mod, n, S, fp):
+    """cfg4 (BASELINE configs[3]): a 512^2 probe zero-padded into a 2k / 4k field, whole-field FFT propagation — the sizes
+    beyond the fused plans run on the rocFFT engine.  Forward wave and loss + gradient against the float64 oracle."""
+    rng = np.random.default_rng(n)
+    delta = np.zeros((1, n, n, S), dtype=np.float32)
+    c0 = n // 2 - 256
+    delta[0, c0:c0 + 512, c0:c0 + 512, :] = rng.uniform(0, 5e-5, size=(512, 512, S))      # zone-plate-like strong phase object
+    beta = 0.1 * delta
+    yy, xx = np.mgrid[:n, :n]
+    inside = (abs(yy - n // 2) < 256) & (abs(xx - n // 2) < 256)
+    pr = inside * np.exp(-((yy - n / 2.) ** 2 + (xx - n / 2.) ** 2) / (2 * 90. ** 2))       # 512^2 probe in the padded field
+    pi = np.zeros((n, n))
+    eng = engine_mod.MultisliceEngine(n, n, S, 1, with_grad=True)
+    eng.set_physics(5000., 1e-7, fp)
+    eng.set_probe(pr, pi)
+    eng.set_object_batch(delta, beta)
+    wave = eng.forward(1)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, fp, delta.shape, return_probe_array=False)
+    assert rel(wave, ref) <= 5e-6
+    meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
+    loss = eng.loss_grad(1, meas)
+    gd, gb = eng.grad_batch_to_host(1)
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, fp)
+    assert abs(loss - rl) <= 1e-5 * abs(rl)
+    assert rel(gd, rgd) <= 2e-4 and rel(gb, rgb) <= 2e-4
