@@ -151,8 +151,10 @@ def main():
     solver.set_mask(np.ones((n, n, n), dtype=np.float32))
     del true_d, true_b, init_d, init_b
     hyper = dict(learning_rate=1e-7, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)     # params_cone, reconstruct_fullfield.py:50-56
+    n_slabs = solver.tune_allreduce()          # slab-pipelined vs whole-volume all-reduce tail: timed here, outside the run
     if rank == 0:
-        print('[bench] setup {:.1f} s'.format(time.time() - t_setup), file=sys.stderr)
+        print('[bench] setup {:.1f} s; all-reduce tail: {} slab(s) {}'.format(time.time() - t_setup, n_slabs, solver.tuned or ''),
+              file=sys.stderr)
 
     def run(i):
         solver.step(i % len(my_batches), my_batches[i % len(my_batches)], want_loss=False, **hyper)
@@ -216,7 +218,7 @@ def main():
                'adam_iters_per_s': args.steps / elapsed, 'final_loss': loss,
                'config': {'workload': 'cfg3: {0}^3 charcoal-like random (delta,beta) volume, {1} of {2} angles per GPU per '
                                       'Adam step, {0} slices, 5 keV, 1 nm, free_prop_cm=1e-4, plane probe'.format(n, mb, n_theta),
-                          'global_batch_angles': world * mb, 'parallelism': 'angle-sharded dp{}'.format(world),
+                          'global_batch_angles': world * mb, 'parallelism': 'angle-sharded dp{}'.format(world), 'allreduce_slabs': n_slabs,
                           'propagator': args.propagator},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:

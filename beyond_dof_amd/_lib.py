@@ -82,10 +82,6 @@ def load():
     # torch loads a SECOND runtime that cannot see the GPU.  Whenever the process is going to use torch.distributed
     # (multi-rank launch, or the switches below) torch is therefore imported before the library.
     global TORCH_FIRST
-    # more hardware queues than HIP's default of 4, so that the sub-batch streams (include/bdof.h, bdof_set_streams) are not
-    # folded onto a queue shared with torch's / RCCL's streams; only effective if the HIP runtime is not initialised yet
-    # (the library checks by measurement which of its streams really run concurrently).
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     if 'torch' in sys.modules:
         TORCH_FIRST = True
     elif (int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('BDOF_FORCE_TORCH_COMM')

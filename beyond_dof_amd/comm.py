@@ -24,6 +24,9 @@ class PseudoComm(object):
     def allreduce_sum_host(self, arr):
         return arr
 
+    def allreduce_max_host(self, arr):
+        return arr
+
     def pipelined_allreduce(self, buf, bounds, produce, consume, stream_ptr=0, lookahead=2):
         for c in range(len(bounds) - 1):
             produce(c)
@@ -122,6 +125,13 @@ class TorchComm(object):
         if self.backend == 'nccl':
             t = t.cuda()
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    def allreduce_max_host(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr))
+        if self.backend == 'nccl':
+            t = t.cuda()
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return t.cpu().numpy()
 
     def bcast_host(self, arr, root=0):

@@ -809,6 +809,9 @@ __device__ __forceinline__ void conv_window(const cf (&win)[R + 2 * H], const fl
     }
 }
 
+// workgroup barrier that orders LDS traffic only (see res_sync in bdof_resident.h)
+__device__ __forceinline__ void conv_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // H = (ks - 1) / 2 as a template parameter (2, 4, 8, 16 instantiated; H = 0 selects the generic runtime-ks loops)
 #define BDOF_CONV_THREADS 512
 template <bool BWD, int H>
@@ -825,19 +828,55 @@ __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
     cf* M = lds + TXH * SA;            // [TXH][SM]
     const int tiles_x = a.NX / TX, tiles_y = a.NY / TY;
     const int ntiles = a.B * tiles_x * tiles_y;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Software pipeline over the tiles of this workgroup: the halo tile of the NEXT tile is fetched into registers while
+    // the x pass of the current one runs (A is free once the y pass is done), and the loads the epilogue depends on
+    // (rotation-table row -> modulation row, tape) are issued at the top of the tile, two barriers before their use.
+    // Barriers order LDS only (conv_sync): __syncthreads() would also drain those loads.
+    constexpr int NLD = (BDOF_CONV_MAXK - 1 + BDOF_CONV_TX) * (BDOF_CONV_MAXK - 1 + BDOF_CONV_TY) / BDOF_CONV_THREADS + 1;
+    constexpr int NPF = H > 0 ? ((TX + 2 * H) * (TY + 2 * H) + BDOF_CONV_THREADS - 1) / BDOF_CONV_THREADS : NLD;
+    cf nx[NPF];
+    auto fetch = [&](int tile, cf (&v)[NPF]) {
         const int b = tile / (tiles_x * tiles_y);
         const int t2 = tile - b * tiles_x * tiles_y;
         const int x0 = (t2 / tiles_y) * TX, y0 = (t2 % tiles_y) * TY;
         const cf* src = a.in + (size_t)b * a.NX * a.NY;
-        for (int e = threadIdx.x; e < TXH * TYH; e += blockDim.x) {
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int e = min((int)threadIdx.x + q * BDOF_CONV_THREADS, TXH * TYH - 1);
             const int i = e / TYH, j = e - i * TYH;
             const int x = x0 - h + i, y = y0 - h + j;
             const bool in = x >= 0 && x < a.NX && y >= 0 && y < a.NY;
-            const cf v = src[(size_t)min(max(x, 0), a.NX - 1) * a.NY + min(max(y, 0), a.NY - 1)];
-            A[i * SA + j] = in ? v : a.pad;
+            const cf val = src[(size_t)min(max(x, 0), a.NX - 1) * a.NY + min(max(y, 0), a.NY - 1)];
+            v[q] = in ? val : a.pad;
         }
-        __syncthreads();
+    };
+    auto stash = [&](const cf (&v)[NPF]) {
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int e = (int)threadIdx.x + q * BDOF_CONV_THREADS;
+            if (e < TXH * TYH) {
+                const int i = e / TYH, j = e - i * TYH;
+                A[i * SA + j] = v[q];
+            }
+        }
+    };
+    if ((int)blockIdx.x < ntiles) {
+        fetch(blockIdx.x, nx);
+        stash(nx);
+    }
+    conv_sync();
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / (tiles_x * tiles_y);
+        const int t2 = tile - b * tiles_x * tiles_y;
+        const int x0 = (t2 / tiles_y) * TX, y0 = (t2 % tiles_y) * TY;
+        // this thread's x-pass item (one per thread: (TX / R2) * TY = 512) and the loads its epilogue needs
+        const int i0 = ((int)threadIdx.x / TY) * R2, j = (int)threadIdx.x % TY;
+        const int y = y0 + j;
+        const int yg = y + (a.obj.yoff ? a.obj.yoff[b] : 0);
+        const int yc = min(max(yg, 0), a.obj.volNY - 1);
+        long long srow[R2];
+#pragma unroll
+        for (int q = 0; q < R2; ++q) srow[q] = a.zmod >= 0 ? obj_src_row(a.obj, b, x0 + i0 + q, a.zmod, a.NX) : -1;
         // pass along y.  forward: o[y] = sum_d K[h+d] f[y-d] ; backward: o[y] = sum_d conj(K[h+d]) g[y+d]
         if constexpr (H > 0) {
             for (int t = threadIdx.x; t < TXH * (TY / R); t += blockDim.x) {
@@ -851,19 +890,27 @@ __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
             }
         } else {
             for (int e = threadIdx.x; e < TXH * TY; e += blockDim.x) {
-                const int i = e / TY, j = e - i * TY;
+                const int i = e / TY, jj = e - i * TY;
                 cf acc = make_float2(0.f, 0.f);
                 for (int d = -h; d <= h; ++d) {
-                    const cf f = A[i * SA + j + h + (BWD ? d : -d)];
+                    const cf f = A[i * SA + jj + h + (BWD ? d : -d)];
                     acc = cadd(acc, BWD ? cmulc(f, a.taps.ky[h + d]) : cmul(f, a.taps.ky[h + d]));
                 }
-                M[i * SM + j] = acc;
+                M[i * SM + jj] = acc;
             }
         }
-        __syncthreads();
-        // pass along x (window of R consecutive x for one y), then the pointwise physics
-        for (int t = threadIdx.x; t < (TX / R2) * TY; t += blockDim.x) {
-            const int i0 = (t / TY) * R2, j = t % TY;
+        float2 m1[R2];
+        cf tp[R2];
+#pragma unroll
+        for (int q = 0; q < R2; ++q) {
+            m1[q] = a.obj.vol[(size_t)(srow[q] >= 0 ? srow[q] : 0) * a.obj.volNY + yc];
+            if constexpr (BWD) tp[q] = a.tape[((size_t)b * a.NX + x0 + i0 + q) * a.NY + y];
+        }
+        conv_sync();
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next, nx);          // in flight during the x pass
+        // pass along x (window of R2 consecutive x for one y), then the pointwise physics
+        {
             cf o[R2];
             if constexpr (H > 0) {
                 cf win[R2 + 2 * H];
@@ -879,20 +926,6 @@ __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
                     }
                     o[q] = acc;
                 }
-            }
-            const int y = y0 + j;
-            const int yg = y + (a.obj.yoff ? a.obj.yoff[b] : 0);
-            const int yc = min(max(yg, 0), a.obj.volNY - 1);
-            // batch the dependent loads (row table -> modulation row, tape): issued as R independent requests each
-            long long srow[R2];
-            float2 m1[R2];
-            cf tp[R2];
-#pragma unroll
-            for (int q = 0; q < R2; ++q) srow[q] = a.zmod >= 0 ? obj_src_row(a.obj, b, x0 + i0 + q, a.zmod, a.NX) : -1;
-#pragma unroll
-            for (int q = 0; q < R2; ++q) {
-                m1[q] = a.obj.vol[(size_t)(srow[q] >= 0 ? srow[q] : 0) * a.obj.volNY + yc];
-                if constexpr (BWD) tp[q] = a.tape[((size_t)b * a.NX + x0 + i0 + q) * a.NY + y];
             }
 #pragma unroll
             for (int q = 0; q < R2; ++q) {
@@ -911,7 +944,8 @@ __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
                 }
             }
         }
-        __syncthreads();
+        if (next < ntiles) stash(nx);                // A was last read before the barrier above
+        conv_sync();
     }
 }
 

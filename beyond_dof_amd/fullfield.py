@@ -168,6 +168,7 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
         solver.set_volume(obj_delta, obj_beta)
         solver.set_mask(mask)
         solver.set_measurements(np.abs(prj))
+        solver.tune_allreduce()                  # N ranks: slab-pipelined or whole-volume all-reduce tail, by measurement
 
         print_flush('Optimizer started.', 0, rank)
         if rank == 0:

@@ -50,6 +50,8 @@ class FullfieldSolver(object):
                                        (self.mb, self.dim_x, self.dim_y))
         self.angle_buf = DeviceBuffer(self.ctx, self.mb * 4, np.int32, (self.mb,))
         self.nvox = nvox
+        self._n_slabs = None
+        self.tuned = None
         self._bind_volume()
         self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
 
@@ -125,24 +127,16 @@ class FullfieldSolver(object):
         edges = [(self.dim_x * i) // n_slabs for i in range(n_slabs + 1)]
         return [(edges[i], edges[i + 1] - edges[i]) for i in range(n_slabs)]
 
-    def step(self, i_batch, angle_idx, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, want_loss=False, n_slabs=None):
-        """grads = loss_grad(...); Allreduce; /size; Adam; mask; clip   (fullfield.py:345-362).
-
-        With more than one rank the tail of the step is pipelined over x-slabs of the volume: rotation adjoint of slab
-        c -> all-reduce of slab c (RCCL, asynchronous) -> regulariser + Adam of slab c, so that the 8 B/voxel collective
-        overlaps the kernels either side of it (the TV stencil reads the pre-update volume, which no slab overwrites).
-        Slab-wise and whole-volume execution give identical results."""
+    def _tail(self, i_batch, learning_rate, alpha_d, alpha_b, gamma, n_slabs, flip=True):
+        """Rotation adjoint -> all-reduce -> regulariser + Adam, whole volume (n_slabs <= 1) or pipelined over x-slabs."""
+        lib, h = self.ctx.lib, self.ctx.handle
         reduce = self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)
-        if n_slabs is None:
-            n_slabs = int(os.environ.get('BDOF_ALLREDUCE_SLABS', '8')) if reduce else 1
         if not reduce or n_slabs <= 1:
-            loss = self.loss_and_grad(angle_idx, want_loss=want_loss)
+            self.ctx.check(lib.bdof_rotation_adjoint(h, self.mb, self.angle_buf.ptr, self.g.ptr, 0, 1.0))
             if reduce:
                 self.comm.allreduce_sum_device(self.g, stream_sync=self.ctx.sync)
-            self.adam_update(i_batch, learning_rate, alpha_d, alpha_b, gamma)
-            return loss
-        lib, h = self.ctx.lib, self.ctx.handle
-        self._rot_loss_grad(angle_idx)
+            self.adam_update(i_batch, learning_rate, alpha_d, alpha_b, gamma, flip=flip)
+            return
         slabs = self.slab_bounds(n_slabs)
         per_x = self.dim_z * self.dim_y * 2               # floats per x-plane of the gradient
         bounds = [s[0] * per_x for s in slabs] + [self.dim_x * per_x]
@@ -156,8 +150,53 @@ class FullfieldSolver(object):
             self.adam_update(i_batch, learning_rate, alpha_d, alpha_b, gamma, slab=slabs[c], flip=False)
 
         self.comm.pipelined_allreduce(self.g, bounds, produce, consume, stream_ptr=self.eng.stream_ptr())
-        self.cur = 1 - self.cur
-        self._bind_volume()
+        if flip:
+            self.cur = 1 - self.cur
+            self._bind_volume()
+
+    def default_slabs(self):
+        if self._n_slabs is None:
+            reduce = self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)
+            self._n_slabs = int(os.environ.get('BDOF_ALLREDUCE_SLABS', '8')) if reduce else 1
+        return self._n_slabs
+
+    def tune_allreduce(self, candidates=(1, 8), reps=2):
+        """Pick the number of slabs of the pipelined tail by timing it on this machine and process layout (the collective,
+        the streams it runs on and the kernels either side interact in ways that differ between runtimes).  Dry run: the
+        gradient buffer and the Adam moments are scratch afterwards (the moments are zeroed again), the volume is not
+        touched.  Every rank takes the same decision (max of the timings over ranks).  Call before the epoch loop."""
+        import time
+        reduce = self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)
+        if not reduce or os.environ.get('BDOF_ALLREDUCE_SLABS'):
+            return self.default_slabs()
+        self.angle_buf.upload(np.arange(self.mb, dtype=np.int32) % self.n_theta)
+        times = []
+        for n in candidates:
+            self._tail(0, 0.0, 0.0, 0.0, 0.0, n, flip=False)             # first use: communicator / stream set-up
+            self.ctx.sync()
+            self.comm.Barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self._tail(0, 0.0, 0.0, 0.0, 0.0, n, flip=False)
+            self.ctx.sync()
+            times.append(time.perf_counter() - t0)
+        worst = self.comm.allreduce_max_host(np.array(times))
+        self._n_slabs = int(candidates[int(np.argmin(worst))])
+        self.tuned = dict(zip([int(c) for c in candidates], [float(t) / reps for t in worst]))
+        self.reset_moments()
+        return self._n_slabs
+
+    def step(self, i_batch, angle_idx, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, want_loss=False, n_slabs=None):
+        """grads = loss_grad(...); Allreduce; /size; Adam; mask; clip   (fullfield.py:345-362).
+
+        With more than one rank the tail of the step is pipelined over x-slabs of the volume: rotation adjoint of slab
+        c -> all-reduce of slab c (RCCL, asynchronous) -> regulariser + Adam of slab c, so that the 8 B/voxel collective
+        overlaps the kernels either side of it (the TV stencil reads the pre-update volume, which no slab overwrites).
+        Slab-wise and whole-volume execution give identical results."""
+        if n_slabs is None:
+            n_slabs = self.default_slabs()
+        self._rot_loss_grad(angle_idx)
+        self._tail(i_batch, learning_rate, alpha_d, alpha_b, gamma, n_slabs)
         return self._get_loss() if want_loss else None
 
     def shrink_wrap(self, thresh=1e-15):

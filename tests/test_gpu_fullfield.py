@@ -98,6 +98,17 @@ class _LoopbackComm(object):
         self._p = PseudoComm()
         self.calls = []
 
+    def Barrier(self):
+        pass
+
+    def allreduce_max_host(self, arr):
+        return arr
+
+    def allreduce_sum_device(self, buf, stream_sync=None):
+        if stream_sync is not None:
+            stream_sync()
+        return buf
+
     def pipelined_allreduce(self, buf, bounds, produce, consume, stream_ptr=0, lookahead=2):
         self.calls.append(list(bounds))
         return self._p.pipelined_allreduce(buf, bounds, produce, consume, stream_ptr, lookahead)
@@ -127,6 +138,14 @@ def _slab_case(comm, check_calls=False):
     for v in vols[1:]:
         assert np.array_equal(v[0], vols[0][0]) and np.array_equal(v[1], vols[0][1])
     assert not np.array_equal(vols[0][0], init_d)
+    # the tuner times both forms of the tail in a dry run: it must pick one of them and leave the volume alone
+    before = s.get_volume()
+    n_calls = len(getattr(comm, 'calls', []))
+    assert s.tune_allreduce(candidates=(1, 8)) in (1, 8) and set(s.tuned) == {1, 8}
+    after = s.get_volume()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    if hasattr(comm, 'calls'):
+        del comm.calls[n_calls:]
 
 
 def test_slab_pipelined_step_is_bit_identical():
