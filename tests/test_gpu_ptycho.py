@@ -15,9 +15,9 @@ def rel(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300)
 
 
-def _setup():
+def _setup(psz=(64, 64)):
     rng = np.random.default_rng(0)
-    n, n_theta, psz = 96, 5, (64, 64)
+    n, n_theta = 96, 5
     # positions include windows hanging over every edge (zero padding) and heavy overlap
     pos = np.array([(y, x) for y in (10, 48, 90) for x in (5, 40, 70, 95)])
     od = rng.uniform(0, 2e-5, size=(n, n, n))
@@ -27,11 +27,16 @@ def _setup():
     return rng, n, n_theta, psz, pos, od, ob, coords, prr, pii
 
 
-def test_ptycho_forward_and_gradient_vs_oracle():
+@pytest.mark.parametrize('psz,force_resident', [((64, 64), False), ((64, 64), True), ((72, 72), False), ((60, 60), False)],
+                         ids=['64-streaming', '64-resident', '72-resident', '60-rocfft'])
+def test_ptycho_forward_and_gradient_vs_oracle(psz, force_resident, monkeypatch):
+    """Rotation table + per-position windows (zero padding beyond the volume) through each of the three device engines."""
     import __graft_entry__ as entry
     entry.build()
     from beyond_dof_amd.solver import PtychoSolver
-    rng, n, n_theta, psz, pos, od, ob, coords, prr, pii = _setup()
+    if force_resident:
+        monkeypatch.setenv('BDOF_FORCE_RESIDENT', '1')
+    rng, n, n_theta, psz, pos, od, ob, coords, prr, pii = _setup(psz)
     mb = 6
     s = PtychoSolver((n, n, n), psz, pos, n_theta, mb, 5000., 1e-7, prr, pii, coord_ls=coords)
     s.set_volume(od, ob)
@@ -46,12 +51,16 @@ def test_ptycho_forward_and_gradient_vs_oracle():
     ref, _ = orc.multislice_propagate_batch_numpy(subs[..., 0], subs[..., 1], prr, pii, 5000., 1e-7, 'inf', subs[..., 0].shape,
                                                   return_probe_array=False)
     w = s.forward(i_theta, sel)
-    assert rel(np.abs(w) ** 2, np.abs(ref) ** 2) <= 1e-5
+    # 96 slices, localised probe (no carrier to split off): float32 round-off of the 192 transforms accumulates to
+    # 0.7e-5 (64^2) ... 1.7e-5 (96^2) in the intensities — the same level on the three engines, whose FFTs share no code
+    # (tools/gpu_check_pty_err.py: 72^2 resident 1.41e-5, rocFFT 1.33e-5) — so the bound here is 2e-5, not the 1e-5 of
+    # the short-stack comparisons in test_gpu_parity.py / test_gpu_resident.py.
+    assert rel(np.abs(w) ** 2, np.abs(ref) ** 2) <= 2e-5
     meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
     loss = s.loss_and_grad(i_theta, sel, meas)
     gd, gb = s.gradient_to_host()
     rl, rgd, rgb = orc.ptycho_loss_and_grad(od, ob, coords[i_theta], pos, pos[sel], meas, prr, pii, psz, 5000., 1e-7)
-    assert abs(loss - rl) <= 2e-5 * rl
+    assert abs(loss - rl) <= 5e-5 * rl
     # far field, 96 slices, localised probe (no carrier to split off): the |D| - |m| cancellation in float32 costs
     # ~3e-4 of the gradient (see tests/test_gpu_parity.py header); bound it at 1e-3
     assert rel(gd, rgd) <= 1e-3 and rel(gb, rgb) <= 1e-3
