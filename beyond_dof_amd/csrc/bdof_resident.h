@@ -20,7 +20,7 @@ template <> struct ResPlan<64> { static constexpr int n = 2, R0 = 8, R1 = 8, R2 
 // 72 (the reference drivers' probe): 648 / 576 butterflies per pass, one per thread; the epilogues of the fused form do not
 // fit the 80 registers that two 11-wave workgroups per CU leave (measured: fused, 576 threads 12.8 ms; this 11.9 ms)
 template <> struct ResPlan<72> { static constexpr int n = 2, R0 = 8, R1 = 9, R2 = 1, T = 704, WPE = 6; static constexpr bool FUSE = false; };
-template <> struct ResPlan<80> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 5, T = 512, WPE = 4; static constexpr bool FUSE = true; };
+template <> struct ResPlan<80> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 5, T = 512, WPE = 4; static constexpr bool FUSE = false; };
 template <> struct ResPlan<96> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 3, T = 768, WPE = 3; static constexpr bool FUSE = true; };
 template <> struct ResPlan<128> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 4, T = 1024, WPE = 4; static constexpr bool FUSE = true; };
 
@@ -283,7 +283,6 @@ template <int N, int T> struct ResPipe {
     }
 };
 
-// WPE = waves per SIMD the register allocation must leave room for (two workgroups per CU where the LDS image allows)
 // Modulation of the NEXT slice folded into the last pass of a propagation step: the element (x, y) leaves the inverse
 // transform as psi_{z+1}(x, y), is multiplied by that slice's factor and stored as phi_{z+1} (LDS + tape).
 template <int N, int T> struct EpiMod {
@@ -337,21 +336,65 @@ template <int N, int T> struct EpiBwd {
     }
 };
 
+// Stand-alone point-wise sweeps over the LDS image (element e = tid + i * T -> (x, y) = (e / N, e % N), coalesced globals).
+template <int N, int T> struct ResPoint {
+    typedef ResPipe<N, T> Pipe;
+    static constexpr int P = N | 1, EPT = Pipe::EPT;
+
+    // phi = c psi : modulation of the slice whose factors are in m; phi goes to the LDS image and to the tape
+    static __device__ __forceinline__ void modulate(cf* f, cf* tape, cf car, const float2 (&m)[EPT], int tid) {
+        asm volatile("" : "+v"(tid));
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + i * T;
+            if (EPT * T == N * N || e < N * N) {
+                const int x = e / N, y = e - x * N;
+                const cf phi = modulate_eps(f[x * P + y], car, m[i]);
+                f[x * P + y] = phi;
+                if (tape) tape[e] = phi;
+            }
+        }
+        res_sync();
+    }
+    // adjoint of the modulation: gradient rows out, G(psi) = conj(c) G(phi) left in the LDS image
+    static __device__ __forceinline__ void adjoint(cf* f, const cf (&t)[EPT], const float2 (&m)[EPT], cf car, float k, float2* gdst,
+                                                   int tid) {
+        asm volatile("" : "+v"(tid));
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+            const int e = tid + i * T;
+            if (EPT * T == N * N || e < N * N) {
+                const int x = e / N, y = e - x * N;
+                const cf G = f[x * P + y];
+                const cf phi = cadd(t[i], car);
+                const cf q = cmulc(G, phi);
+                gdst[e] = make_float2(k * q.y, -k * q.x);
+                f[x * P + y] = cmulc(G, make_float2(1.f + m[i].x, m[i].y));
+            }
+        }
+        res_sync();
+    }
+};
+
+// WPE = waves per SIMD the register allocation must leave room for (two workgroups per CU where the LDS image allows)
 template <int N, int T, int WPE>
 __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
     typedef ResPipe<N, T> Pipe;
+    typedef ResPoint<N, T> Point;
     constexpr int P = N | 1, EPT = Pipe::EPT;
     constexpr bool FUSE = ResPlan<N>::FUSE;      // point-wise steps folded into the neighbouring passes (EpiMod / EpiBwd)
     extern __shared__ __align__(16) unsigned char res_smem[];
     cf* f = reinterpret_cast<cf*>(res_smem);
     cf* tw = f + N * P;
-    long long* rowbuf = reinterpret_cast<long long*>(tw + N);      // [3][N]
+    long long* rowbuf = reinterpret_cast<long long*>(tw + N);      // [3][N] object rows of slices z, z+1, z+2 (ring)
     const int tid = threadIdx.x;
     for (int e = tid; e < N; e += T) tw[e] = a.twiddle[e];
     double acc = 0.0, acc2 = 0.0;
     const bool far = a.det_mode == BDOF_DET_FAR;
+    const size_t fsz = (size_t)N * N;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const int y0 = a.obj.yoff ? a.obj.yoff[b] : 0;
+        cf* tape0 = a.tape ? a.tape + b * fsz : nullptr;           // slice z of this wavefield: tape0 + z * tape_stride
         res_sync();
         for (int e = tid; e < N * N; e += T) {
             const int x = e / N, y = e - x * N;
@@ -362,162 +405,95 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
             rowbuf[N + tid] = Pipe::row_of(a, b, 1, tid);
         }
         res_sync();
+
         // ---- forward sweep --------------------------------------------------------------------
         float2 m[EPT];
-        if constexpr (FUSE) {
-        {   // slice 0 is modulated on its own; every later slice inside the propagation step that produces it (EpiMod)
-            Pipe::load_factors(a, rowbuf, y0, tid, m);
-            const cf car = a.carrier[0];
-            cf* tape = a.tape ? a.tape + (size_t)b * N * N : nullptr;
-            int tl = tid;
-            asm volatile("" : "+v"(tl));
-#pragma unroll
-            for (int i = 0; i < EPT; ++i) {
-                const int e = tl + i * T;
-                if (EPT * T == N * N || e < N * N) {
-                    const int x = e / N, y = e - x * N;
-                    const cf phi = modulate_eps(f[x * P + y], car, m[i]);
-                    f[x * P + y] = phi;
-                    if (tape) tape[e] = phi;
-                }
-            }
-            res_sync();
-        }
-        for (int z = 0; z < a.S; ++z) {
-            const long long r2 = Pipe::row_of(a, b, z + 2, tid);
-            if (z + 1 < a.S) {
-                EpiMod<N, T> em;
-                em.a = &a;
-                em.rows = rowbuf + ((z + 1) % 3) * N;
-                em.tape = a.tape ? a.tape + (size_t)(z + 1) * a.tape_stride + (size_t)b * N * N : nullptr;
-                em.car = a.carrier[z + 1];
-                em.y0 = y0;
-                res_prop<N, T, false>(f, a.hsT, tw, tid, em);
-            } else if (a.tf_all && !far) {
-                res_prop<N, T, false>(f, a.hsT, tw, tid);
-            }
-            if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;      // read two propagation steps from now
-        }
-        } else {
         Pipe::load_factors(a, rowbuf, y0, tid, m);
-        // ---- forward sweep --------------------------------------------------------------------
-        for (int z = 0; z < a.S; ++z) {
-            const long long r2 = Pipe::row_of(a, b, z + 2, tid);
-            const cf car = a.carrier[z];
-            cf* tape = a.tape ? a.tape + (size_t)z * a.tape_stride + (size_t)b * N * N : nullptr;
-            int tl = tid;
-            asm volatile("" : "+v"(tl));
-#pragma unroll
-            for (int i = 0; i < EPT; ++i) {
-                const int e = tl + i * T;
-                if (EPT * T == N * N || e < N * N) {
-                    const int x = e / N, y = e - x * N;
-                    const cf phi = modulate_eps(f[x * P + y], car, m[i]);
-                    f[x * P + y] = phi;
-                    if (tape) tape[e] = phi;
+        if constexpr (FUSE) {
+            // slice 0 is modulated on its own; every later slice inside the propagation step that produces it (EpiMod)
+            Point::modulate(f, tape0, a.carrier[0], m, tid);
+            for (int z = 0; z < a.S; ++z) {
+                const long long r2 = Pipe::row_of(a, b, z + 2, tid);
+                if (z + 1 < a.S) {
+                    EpiMod<N, T> em;
+                    em.a = &a;
+                    em.rows = rowbuf + ((z + 1) % 3) * N;
+                    em.tape = tape0 ? tape0 + (size_t)(z + 1) * a.tape_stride : nullptr;
+                    em.car = a.carrier[z + 1];
+                    em.y0 = y0;
+                    res_prop<N, T, false>(f, a.hsT, tw, tid, em);
+                } else if (a.tf_all && !far) {
+                    res_prop<N, T, false>(f, a.hsT, tw, tid);
                 }
+                if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;      // read two propagation steps from now
             }
-            res_sync();
-            if (z + 1 < a.S) Pipe::load_factors(a, rowbuf + ((z + 1) % 3) * N, y0, tid, m);
-            if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;
-            const bool last = z == a.S - 1;
-            if (!last || (a.tf_all && !far)) res_prop<N, T, false>(f, a.hsT, tw, tid);
-        }
+        } else {
+            for (int z = 0; z < a.S; ++z) {
+                const long long r2 = Pipe::row_of(a, b, z + 2, tid);
+                Point::modulate(f, tape0 ? tape0 + (size_t)z * a.tape_stride : nullptr, a.carrier[z], m, tid);
+                if (z + 1 < a.S) Pipe::load_factors(a, rowbuf + ((z + 1) % 3) * N, y0, tid, m);      // in flight during the step
+                if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;
+                if (z + 1 < a.S || (a.tf_all && !far)) res_prop<N, T, false>(f, a.hsT, tw, tid);
+            }
         }
         if (a.det_mode == BDOF_DET_NEAR) res_prop<N, T, false>(f, a.hdetT, tw, tid);
         else if (far) res_fft2<N, T, -1>(f, tw, tid);
+
         // ---- detector wave, loss, seed --------------------------------------------------------
         for (int e = tid; e < N * N; e += T) {
             const int x = e / N, y = e - x * N;
             cf d = f[x * P + y];
             if (!far || e == 0) d = cadd(d, a.carrier_det);
-            const size_t o = (size_t)b * N * N + (far ? y * N + x : e);
+            const size_t o = b * fsz + (far ? y * N + x : e);
             if (a.out_wave) a.out_wave[o] = d;
             if (a.meas) f[x * P + y] = loss_seed(d, a.meas[o], a.seed_scale, acc, acc2);
         }
         if (!a.do_grad || !a.meas) continue;
+
         // ---- adjoint sweep --------------------------------------------------------------------
         if (tid < N) {
             rowbuf[((a.S - 1) % 3) * N + tid] = Pipe::row_of(a, b, a.S - 1, tid);
             rowbuf[((a.S + 1) % 3) * N + tid] = Pipe::row_of(a, b, a.S - 2, tid);      // (S - 2) mod 3
         }
         res_sync();
-        if constexpr (FUSE) {
+        cf t[EPT];
+        if constexpr (!FUSE) {
+            Pipe::load_factors(a, rowbuf + ((a.S - 1) % 3) * N, y0, tid, m);
+            Pipe::load_field(tape0 + (size_t)(a.S - 1) * a.tape_stride, tid, t);
+        }
         if (a.det_mode == BDOF_DET_NEAR) res_prop<N, T, true>(f, a.hdetT, tw, tid);
         else if (far) res_fft2<N, T, +1>(f, tw, tid);                  // F^H = un-normalised inverse
         for (int z = a.S - 1; z >= 0; --z) {
             const long long r2 = Pipe::row_of(a, b, z - 2, tid);
             const bool prop_after = z < a.S - 1 || (a.tf_all && !far);
-            const cf* tape = a.tape + (size_t)z * a.tape_stride + (size_t)b * N * N;
-            float2* gdst = a.grot + ((size_t)b * a.S + z) * N * N;
-            if (prop_after) {
-                EpiBwd<N, T> eb;
-                eb.a = &a;
-                eb.rows = rowbuf + (z % 3) * N;
-                eb.tape = tape;
-                eb.gdst = gdst;
-                eb.car = a.carrier[z];
-                eb.y0 = y0;
-                res_prop<N, T, true>(f, a.hsT, tw, tid, eb);
-            } else {
-                // the slice the adjoint sweep starts from when no transfer-function step follows the last slice
-                float2 m[EPT];
-                cf t[EPT];
-                Pipe::load_factors(a, rowbuf + (z % 3) * N, y0, tid, m);
-                Pipe::load_field(tape, tid, t);
-                const cf car = a.carrier[z];
-                int tl = tid;
-                asm volatile("" : "+v"(tl));
-#pragma unroll
-                for (int i = 0; i < EPT; ++i) {
-                    const int e = tl + i * T;
-                    if (EPT * T == N * N || e < N * N) {
-                        const int x = e / N, y = e - x * N;
-                        const cf G = f[x * P + y];
-                        const cf phi = cadd(t[i], car);
-                        const cf q = cmulc(G, phi);
-                        gdst[e] = make_float2(a.k * q.y, -a.k * q.x);
-                        f[x * P + y] = cmulc(G, make_float2(1.f + m[i].x, m[i].y));
-                    }
+            const cf* tape = tape0 + (size_t)z * a.tape_stride;
+            float2* gdst = a.grot + ((size_t)b * a.S + z) * fsz;
+            if constexpr (FUSE) {
+                if (prop_after) {
+                    EpiBwd<N, T> eb;
+                    eb.a = &a;
+                    eb.rows = rowbuf + (z % 3) * N;
+                    eb.tape = tape;
+                    eb.gdst = gdst;
+                    eb.car = a.carrier[z];
+                    eb.y0 = y0;
+                    res_prop<N, T, true>(f, a.hsT, tw, tid, eb);
+                } else {
+                    // the slice the adjoint sweep starts from when no transfer-function step follows the last slice
+                    Pipe::load_factors(a, rowbuf + (z % 3) * N, y0, tid, m);
+                    Pipe::load_field(tape, tid, t);
+                    Point::adjoint(f, t, m, a.carrier[z], a.k, gdst, tid);
                 }
-                res_sync();
+            } else {
+                if (prop_after) res_prop<N, T, true>(f, a.hsT, tw, tid);
+                Point::adjoint(f, t, m, a.carrier[z], a.k, gdst, tid);
+                if (z > 0) {                                           // in flight during the next adjoint step
+                    Pipe::load_factors(a, rowbuf + ((z - 1) % 3) * N, y0, tid, m);
+                    Pipe::load_field(tape0 + (size_t)(z - 1) * a.tape_stride, tid, t);
+                }
             }
             if (tid < N) rowbuf[((z + 1) % 3) * N + tid] = r2;           // slot of slice z - 2
         }
-            } else {
-        cf t[EPT];
-        Pipe::load_factors(a, rowbuf + ((a.S - 1) % 3) * N, y0, tid, m);
-        Pipe::load_field(a.tape + (size_t)(a.S - 1) * a.tape_stride + (size_t)b * N * N, tid, t);
-        if (a.det_mode == BDOF_DET_NEAR) res_prop<N, T, true>(f, a.hdetT, tw, tid);
-        else if (far) res_fft2<N, T, +1>(f, tw, tid);                  // F^H = un-normalised inverse
-        for (int z = a.S - 1; z >= 0; --z) {
-            const long long r2 = Pipe::row_of(a, b, z - 2, tid);
-            const bool prop_after = z < a.S - 1 || (a.tf_all && !far);
-            if (prop_after) res_prop<N, T, true>(f, a.hsT, tw, tid);
-            const cf car = a.carrier[z];
-            float2* gdst = a.grot + ((size_t)b * a.S + z) * N * N;
-            int tl = tid;
-            asm volatile("" : "+v"(tl));
-#pragma unroll
-            for (int i = 0; i < EPT; ++i) {
-                const int e = tl + i * T;
-                if (EPT * T == N * N || e < N * N) {
-                    const int x = e / N, y = e - x * N;
-                    const cf G = f[x * P + y];
-                    const cf phi = cadd(t[i], car);
-                    const cf q = cmulc(G, phi);
-                    gdst[e] = make_float2(a.k * q.y, -a.k * q.x);
-                    f[x * P + y] = cmulc(G, make_float2(1.f + m[i].x, m[i].y));
-                }
-            }
-            res_sync();
-            if (z > 0) {
-                Pipe::load_factors(a, rowbuf + ((z - 1) % 3) * N, y0, tid, m);
-                Pipe::load_field(a.tape + (size_t)(z - 1) * a.tape_stride + (size_t)b * N * N, tid, t);
-            }
-            if (tid < N) rowbuf[((z + 1) % 3) * N + tid] = r2;           // (z - 2) mod 3
-        }
-            }
     }
     if (a.meas) {
         __shared__ double w1[16], w2[16];
