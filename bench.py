@@ -105,7 +105,7 @@ def main():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--propagator', default='fft', choices=['fft', 'conv'],
                     help="'conv': the reference entry points' truncated real-space kernel (17 taps), for comparison")
-    ap.add_argument('--profile-stride', type=int, default=16,
+    ap.add_argument('--profile-stride', type=int, default=64,
                     help='HIP-event time every n-th launch of the per-slice kernels (each timed launch costs ~9 us of stream time)')
     args = ap.parse_args()
 
