@@ -108,3 +108,26 @@ def test_resident_batch_larger_than_the_grid_and_auto_selection(engine_mod):
     small = _engine(engine_mod, n, 2, S, fp, 'numpy_skip_last', delta[:2], beta[:2], pr, pi, 'auto')
     assert rel(small.forward(2), wave[:2]) <= 2e-6
     assert np.isfinite(loss) and loss > 0
+
+
+@pytest.mark.parametrize('n', [64, 72])
+@pytest.mark.parametrize('S', [1, 2])
+@pytest.mark.parametrize('fp,variant', [(None, 'numpy_skip_last'), (1e-4, 'tf_all'), ('inf', 'tf_all')])
+def test_resident_one_and_two_slices(engine_mod, n, S, fp, variant):
+    """Fewer slices than the 3-slot row ring and the load pipeline look ahead (both the fused-epilogue and the plain form)."""
+    B = 2
+    rng, delta, beta, pr, pi = _inputs(n, B, S, fp, 7 * n + S)
+    eng = _engine(engine_mod, n, B, S, fp, variant, delta, beta, pr, pi, 'resident')
+    wave = eng.forward(B)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, fp, delta.shape, variant=variant,
+                                                  return_probe_array=False)
+    assert rel(wave, ref) <= 5e-6
+    meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
+    loss = eng.loss_grad(B, meas)
+    gd, gb = eng.grad_batch_to_host(B)
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, fp, variant)
+    assert abs(loss - rl) <= 1e-5 * abs(rl)
+    # one slice and no detector step: |d| does not depend on delta at all (pure phase), the exact delta-gradient is 0 —
+    # compare against the scale of the whole gradient
+    scale = np.sqrt(np.linalg.norm(rgd) ** 2 + np.linalg.norm(rgb) ** 2)
+    assert np.linalg.norm(gd - rgd) <= 2e-4 * scale and np.linalg.norm(gb - rgb) <= 2e-4 * scale
