@@ -170,7 +170,12 @@ def test_slab_pipelined_step_through_rccl():
             'from beyond_dof_amd.comm import TorchComm\n'
             'c = TorchComm("nccl"); assert c.always_reduce\n'
             't._slab_case(c); c.close(); print("SLAB_RCCL_OK")\n').format(root, os.path.join(root, 'tests'))
-    env = dict(os.environ, BDOF_FORCE_TORCH_COMM='1', MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', RANK='0', WORLD_SIZE='1',
+    import socket
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, BDOF_FORCE_TORCH_COMM='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
                LOCAL_RANK='0')
     r = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and b'SLAB_RCCL_OK' in r.stdout, r.stdout.decode()[-3000:]
