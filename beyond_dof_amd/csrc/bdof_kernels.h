@@ -699,31 +699,60 @@ struct WinAdjArgs {
 // Stage 1: overlap-add of the window-frame gradients into the rotated frame, pad[z][xg][y] = sum over the windows b that
 // cover (xg, y) of grot[b][z][xg - xoff[b]][y - yoff[b]]  (adjoint of the window cut + zero padding; pixels of a window
 // that lie outside the volume are dropped).  One workgroup per (xg, chunk of z): it first collects the windows covering
-// its xg in LDS (a scan over B offsets), then streams their rows.  Fixed summation order (by b) -> deterministic.
+// its xg in LDS (a scan over B offsets), then streams their rows.  Fixed summation order (by yoff, b) -> deterministic.
 // Stage 2 is the plain rotation adjoint (k_rot_adjoint) of `pad` as a one-element batch.
 #define BDOF_WIN_MAXLIST 1024
 __global__ __launch_bounds__(256) void k_window_overlap_add(WinAdjArgs a, float2* pad, int z_per_wg) {
-    __shared__ int lb[BDOF_WIN_MAXLIST], ly[BDOF_WIN_MAXLIST], lx[BDOF_WIN_MAXLIST];
+    __shared__ int ub[BDOF_WIN_MAXLIST], uy[BDOF_WIN_MAXLIST];                              // unsorted: window, yoff
+    __shared__ int lb[BDOF_WIN_MAXLIST], ly[BDOF_WIN_MAXLIST], lx[BDOF_WIN_MAXLIST];        // sorted by (yoff, window)
     __shared__ int nlist;
     const int xg = blockIdx.x;
     if (threadIdx.x == 0) {
         int n = 0;
         for (int b = 0; b < a.B; ++b) {
             const int xw = xg - a.xoff[b];
-            if (xw >= 0 && xw < a.NX && n < BDOF_WIN_MAXLIST) { lb[n] = b; lx[n] = xw; ly[n] = a.yoff[b]; ++n; }
+            if (xw >= 0 && xw < a.NX && n < BDOF_WIN_MAXLIST) { ub[n] = b; uy[n] = a.yoff[b]; ++n; }
         }
         nlist = n;
     }
     __syncthreads();
     const int n = nlist;
+    // rank sort by (yoff, window index): the windows that cover a given y are then one contiguous run of the list, so the
+    // inner loop below has no per-element test and its loads can be issued back to back
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int ye = uy[e], be = ub[e];
+        int rank = 0;
+        for (int o = 0; o < n; ++o) rank += (uy[o] < ye) || (uy[o] == ye && ub[o] < be);
+        lb[rank] = be;
+        ly[rank] = ye;
+        lx[rank] = xg - a.xoff[be];
+    }
+    __syncthreads();
     const int z0 = blockIdx.y * z_per_wg, z1 = min(a.S, z0 + z_per_wg);
-    for (int z = z0; z < z1; ++z) {
-        for (int y = threadIdx.x; y < a.volNY; y += blockDim.x) {
+    for (int y = threadIdx.x; y < a.volNY; y += blockDim.x) {
+        // windows with yoff in (y - NY, y]: first index with yoff > y - NY, first index with yoff > y
+        int lo, hi;
+        {
+            int l = 0, h = n;
+            while (l < h) { const int mid = (l + h) >> 1; if (ly[mid] > y - a.NY) h = mid; else l = mid + 1; }
+            lo = l;
+            l = 0; h = n;
+            while (l < h) { const int mid = (l + h) >> 1; if (ly[mid] > y) h = mid; else l = mid + 1; }
+            hi = l;
+        }
+        for (int z = z0; z < z1; ++z) {
             float2 acc = make_float2(0.f, 0.f);
-            for (int e = 0; e < n; ++e) {
-                const int yw = y - ly[e];
-                if (yw < 0 || yw >= a.NY) continue;
-                const float2 g = a.grot[(((size_t)lb[e] * a.S + z) * a.NX + lx[e]) * a.NY + yw];
+            int e = lo;
+            for (; e + 4 <= hi; e += 4) {
+                float2 g[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    g[q] = a.grot[(((size_t)lb[e + q] * a.S + z) * a.NX + lx[e + q]) * a.NY + (y - ly[e + q])];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc.x += g[q].x; acc.y += g[q].y; }
+            }
+            for (; e < hi; ++e) {
+                const float2 g = a.grot[(((size_t)lb[e] * a.S + z) * a.NX + lx[e]) * a.NY + (y - ly[e])];
                 acc.x += g.x;
                 acc.y += g.y;
             }
