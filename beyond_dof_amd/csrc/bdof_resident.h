@@ -17,12 +17,20 @@ template <> struct ResPlan<32> { static constexpr int n = 2, R0 = 8, R1 = 4, R2 
 template <> struct ResPlan<36> { static constexpr int n = 2, R0 = 4, R1 = 9, R2 = 1, T = 128, WPE = 2; static constexpr bool FUSE = true; };
 template <> struct ResPlan<48> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 3, T = 192, WPE = 3; static constexpr bool FUSE = true; };
 template <> struct ResPlan<64> { static constexpr int n = 2, R0 = 8, R1 = 8, R2 = 1, T = 512, WPE = 4; static constexpr bool FUSE = true; };
-// 72 (the reference drivers' probe): 648 / 576 butterflies per pass, one per thread; the epilogues of the fused form do not
-// fit the 80 registers that two 11-wave workgroups per CU leave (measured: fused, 576 threads 12.8 ms; this 11.9 ms)
-template <> struct ResPlan<72> { static constexpr int n = 2, R0 = 8, R1 = 9, R2 = 1, T = 704, WPE = 6; static constexpr bool FUSE = false; };
+// 72 (the reference drivers' probe): wave-local lines (ResWave<72>), radix 9 first — the stride-8 writes of an (8, 9) plan are
+// 4-way bank conflicts in that lane mapping; the point-wise epilogues of the fused form do not fit the 80 registers that
+// two 11-wave workgroups per CU leave
+template <> struct ResPlan<72> { static constexpr int n = 2, R0 = 9, R1 = 8, R2 = 1, T = 704, WPE = 6; static constexpr bool FUSE = false; };
 template <> struct ResPlan<80> { static constexpr int n = 3, R0 = 8, R1 = 2, R2 = 5, T = 512, WPE = 4; static constexpr bool FUSE = false; };
 template <> struct ResPlan<96> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 3, T = 768, WPE = 3; static constexpr bool FUSE = true; };
 template <> struct ResPlan<128> { static constexpr int n = 3, R0 = 8, R1 = 4, R2 = 4, T = 1024, WPE = 4; static constexpr bool FUSE = true; };
+
+// Wave-local lines: L lanes of one wave own one line (L >= butterflies per line in every pass), LPW lines per wave.  Both
+// passes of a line then run in the same wave with no workgroup barrier in between (a wave's LDS accesses execute in
+// program order), and the x-lines of a propagation step go through forward pass 0, 1 (x h), inverse pass 0, 1 without one:
+// 4 barriers per step instead of 17.  L = 0: workgroup-wide passes (res_pass).
+template <int N> struct ResWave { static constexpr int L = 0, LPW = 0; };
+template <> struct ResWave<72> { static constexpr int L = 9, LPW = 7; };       // 7 x 9 = 63 lanes; 11 waves cover 77 >= 72 lines
 
 static inline bool resident_supported(int n) {
     return n == 32 || n == 36 || n == 48 || n == 64 || n == 72 || n == 80 || n == 96 || n == 128;
@@ -153,6 +161,61 @@ __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid, Epi& epi)
     res_sync();
 }
 
+// Wave-local Stockham pass: lane (li, j) of wave w holds butterfly j of line w * LPW + li.  In place without a barrier: every
+// lane of the wave has issued its reads before any lane's write (one instruction stream), and only this wave touches
+// these lines while the line direction does not change.
+template <int N, int R, int NS, int SIGN, bool ALONG_Y, int L, int LPW, class Epi>
+__device__ __forceinline__ void res_wpass(cf* f, const cf* tw, int tid, Epi& epi) {
+    asm volatile("" : "+v"(tid));
+    constexpr int P = N | 1, ES = ALONG_Y ? 1 : P, NBL = N / R;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int li = lane / L, j = lane - li * L;
+    const int line = wave * LPW + li;
+    const bool act = li < LPW && line < N && j < NBL;
+    cf u[R];
+    cf* base = f + (ALONG_Y ? line * P : line);
+    const int k = j % NS;
+    const int j0 = (j / NS) * NS * R + k;
+    if (act) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) u[m] = base[(j + m * NBL) * ES];
+        if constexpr (Epi::active) {
+#pragma unroll
+            for (int m = 0; m < R; ++m) epi.pre(0, m, line, j0 + m * NS);
+        }
+        if constexpr (NS > 1) {
+#pragma unroll
+            for (int m = 1; m < R; ++m) {
+                cf w = tw[k * m * (N / (NS * R))];
+                if constexpr (SIGN > 0) w.y = -w.y;
+                u[m] = cmul(u[m], w);
+            }
+        }
+        res_dft<R, SIGN>(u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (act) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) base[(j0 + m * NS) * ES] = epi.post(0, m, line, j0 + m * NS, u[m]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// both passes of every line of one direction (two-pass plans only); no workgroup barrier inside
+template <int N, int SIGN, bool ALONG_Y, class Epi> __device__ __forceinline__ void res_wlines(cf* f, const cf* tw, int tid, Epi& epi) {
+    typedef ResPlan<N> Pl;
+    static_assert(Pl::n == 2, "wave-local lines are written for two-pass plans");
+    constexpr int L = ResWave<N>::L, LPW = ResWave<N>::LPW;
+    static_assert(L >= N / Pl::R0 && L >= N / Pl::R1 && L * LPW <= 64, "lanes per line");
+    EpiNone none;
+    res_wpass<N, Pl::R0, 1, SIGN, ALONG_Y, L, LPW>(f, tw, tid, none);
+    res_wpass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, L, LPW>(f, tw, tid, epi);
+}
+
 // radix and butterflies per thread of the LAST pass of a line (the one that carries an epilogue)
 template <int N, int T> struct ResLast {
     typedef ResPlan<N> Pl;
@@ -176,8 +239,16 @@ __device__ __forceinline__ void res_lines(cf* f, const cf* tw, int tid, Epi& epi
 // un-normalised 2-D DFT of the field image f[x * P + y], SIGN = -1 forward, +1 inverse; `epi` rides on the last pass
 template <int N, int T, int SIGN, class Epi> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid, Epi& epi) {
     EpiNone none;
-    res_lines<N, T, SIGN, true>(f, tw, tid, none);
-    res_lines<N, T, SIGN, false>(f, tw, tid, epi);
+    if constexpr (ResWave<N>::L > 0) {
+        static_assert(T >= 64 * ((N + ResWave<N>::LPW - 1) / ResWave<N>::LPW), "not enough waves for the lines");
+        res_wlines<N, SIGN, true>(f, tw, tid, none);
+        res_sync();
+        res_wlines<N, SIGN, false>(f, tw, tid, epi);
+        res_sync();
+    } else {
+        res_lines<N, T, SIGN, true>(f, tw, tid, none);
+        res_lines<N, T, SIGN, false>(f, tw, tid, epi);
+    }
 }
 template <int N, int T, int SIGN> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid) {
     EpiNone none;
@@ -240,9 +311,22 @@ template <int N, int T, bool CONJ, class Epi>
 __device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid, Epi& epi) {
     EpiH<N, T, CONJ> eh;
     eh.hT = hT;
-    res_fft2<N, T, -1>(f, tw, tid, eh);
-    res_epi_prefetch<N, T>(tid, epi);
-    res_fft2<N, T, +1>(f, tw, tid, epi);
+    if constexpr (ResWave<N>::L > 0) {
+        // wave-local lines: the inverse transform runs x first, so that a column goes forward, x h, and back in one wave
+        static_assert(!Epi::active, "the wave-local form carries no point-wise epilogue");
+        EpiNone none;
+        res_wlines<N, -1, true>(f, tw, tid, none);
+        res_sync();
+        res_wlines<N, -1, false>(f, tw, tid, eh);
+        res_wlines<N, +1, false>(f, tw, tid, none);
+        res_sync();
+        res_wlines<N, +1, true>(f, tw, tid, none);
+        res_sync();
+    } else {
+        res_fft2<N, T, -1>(f, tw, tid, eh);
+        res_epi_prefetch<N, T>(tid, epi);
+        res_fft2<N, T, +1>(f, tw, tid, epi);
+    }
 }
 template <int N, int T, bool CONJ> __device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid) {
     EpiNone none;

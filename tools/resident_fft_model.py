@@ -2,7 +2,7 @@
 with pitch P, butterflies of radix 2/3/4/5/8/9 written exactly as in the kernel.  Checks against numpy.fft."""
 import numpy as np
 
-PLANS = {32: (8, 4), 36: (4, 9), 48: (8, 2, 3), 64: (8, 8), 72: (8, 9), 80: (8, 2, 5), 96: (8, 4, 3), 128: (8, 4, 4)}
+PLANS = {32: (8, 4), 36: (4, 9), 48: (8, 2, 3), 64: (8, 8), 72: (9, 8), 80: (8, 2, 5), 96: (8, 4, 3), 128: (8, 4, 4)}
 
 
 def dft3(a, s):
