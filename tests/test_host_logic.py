@@ -115,3 +115,23 @@ def test_conv_kernel_separable_matches_reference_recipe():
         ky, kx, e = util.conv_kernel_separable(1.0, 0.248, np.array([1., 1., 1.]), shape, ks)
         k2 = orc.conv_kernel_2d(1.0, 0.248, np.array([1., 1., 1.]), np.array(shape), ks)
         np.testing.assert_allclose(e * np.outer(ky, kx), k2, rtol=0, atol=1e-13 * np.abs(k2).max())
+
+
+def test_ptychography_epoch_schedule():
+    """cnn_propagator/ptychography.py:269-282: every angle once, in shuffled order; each angle's position list padded to a
+    multiple of the minibatch with positions drawn from its own head, so that minibatches never mix angles."""
+    from beyond_dof_amd.ptychography import epoch_schedule
+    n_theta, n_pos, mb = 5, 23, 4
+    sched = epoch_schedule(n_theta, n_pos, mb, np.random.RandomState(3))
+    per_theta = 24
+    assert sched.shape == (n_theta * per_theta, 2)
+    assert sorted(set(sched[:, 0].tolist())) == list(range(n_theta))
+    for i in range(n_theta):
+        blk = sched[i * per_theta:(i + 1) * per_theta]
+        assert len(set(blk[:, 0].tolist())) == 1                       # one angle per block -> per minibatch
+        assert np.array_equal(blk[:n_pos, 1], np.arange(n_pos))
+        assert np.all(blk[n_pos:, 1] < n_pos - n_pos % mb)             # padding drawn from spots[:-(n_pos % mb)]
+    again = epoch_schedule(n_theta, n_pos, mb, np.random.RandomState(3))
+    assert np.array_equal(sched, again)                                # every rank derives the same schedule from the seed
+    exact = epoch_schedule(2, 8, 4, np.random.RandomState(0))
+    assert exact.shape == (16, 2)
