@@ -832,8 +832,13 @@ __device__ __forceinline__ void conv_window(const cf (&win)[R + 2 * H], const fl
         const cf w = taps[H + d];
 #pragma unroll
         for (int o = 0; o < R; ++o) {
+            // complex multiply-accumulate as four FMAs (cadd(out, cmul(f, w)) compiles to mul + fma + add per component)
             const cf f = win[o + H + (BWD ? d : -d)];
-            out[o] = cadd(out[o], BWD ? cmulc(f, w) : cmul(f, w));
+            const float wy = BWD ? -w.y : w.y;                   // backward: multiply by conj(w)
+            out[o].x = fmaf(f.x, w.x, out[o].x);
+            out[o].x = fmaf(-f.y, wy, out[o].x);
+            out[o].y = fmaf(f.x, wy, out[o].y);
+            out[o].y = fmaf(f.y, w.x, out[o].y);
         }
     }
 }
