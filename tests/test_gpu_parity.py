@@ -185,6 +185,22 @@ def test_error_behaviour(engine_mod):
         eng.forward(3)                                            # B > Bmax
     with pytest.raises(ValueError):
         eng.set_physics(5000., 1e-7, 'far')
+    with pytest.raises(ValueError):
+        engine_mod.MultisliceEngine(64, 64, 4, 1, engine='fastest')
+    with pytest.raises(_lib.BdofError):
+        eng.set_streams(0)                                         # -1 (automatic) or 1..4
+    with pytest.raises(_lib.BdofError):
+        eng.set_streams(5)
+    lib, h = eng.lib, eng.h
+    one = _lib.DeviceBuffer.zeros(eng.ctx, (16,), np.float32)
+    # row / slab ranges outside the volume are refused before anything is launched
+    assert lib.bdof_rotation_adjoint_rows(h, 1, one.ptr, one.ptr, 0, 10, 0, 1.0) != 0        # no gradient workspace either
+    rc = lib.bdof_adam_step_slab(h, one.ptr, one.ptr + 64, one.ptr, one.ptr, one.ptr, None, 2, 2, 2, 1.0, 0.0, 0.0, 0.0,
+                                 1e-3, 0.9, 0.999, 1e-8, 0, 1, 1, 2)
+    assert rc != 0 and b'slab' in lib.bdof_last_error(h)
+    rc = lib.bdof_adam_step(h, one.ptr, one.ptr, one.ptr, one.ptr, one.ptr, None, 2, 2, 2, 1.0, 0.0, 0.0, 0.0,
+                            1e-3, 0.9, 0.999, 1e-8, 0, 1)
+    assert rc != 0 and b'alias' in lib.bdof_last_error(h)
 
 
 def test_fullfield_fused_rotation_and_adjoint(engine_mod):
