@@ -38,6 +38,20 @@ def pmc_traffic(kernel_class, n, mb):
     return k['total_bytes_per_launch'] if k else None
 
 
+def rocprof_avg_ms(kernel_class, n, mb):
+    """Average dispatch duration of the class's kernel in the committed rocprofv3 --kernel-trace --stats summary of this
+    same command (profiles/r01_kernel_stats.csv; 512^3, 25 angles only), or None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_kernel_stats.csv')
+    if (n, mb) != (512, 25) or not os.path.exists(path):
+        return None
+    import csv
+    want = PMC_KERNEL[kernel_class]
+    for row in csv.DictReader(open(path)):
+        if row['Name'].replace('void ', '').startswith(want):
+            return float(row['AverageNs']) * 1e-6
+    return None
+
+
 def make_phantom(n, seed=3):
     """'charcoal-like': U(0, 2e-6) box-smoothed over 3 voxels, beta = 0.1 delta."""
     from scipy.ndimage import uniform_filter
@@ -204,7 +218,12 @@ def main():
                     'frac': ach * 1e9 / HBM_PEAK,
                     'traffic': None if tb is None else g * tb / (per_class[dom]['avg_ms'] * 1e-3) / 1e9,
                     'concurrent_launches': g,
-                    'note': 'achieved = concurrent_launches x algorithmic bytes of one launch / its average duration'
+                    'avg_launch_ms_events': per_class[dom]['avg_ms'],
+                    'avg_launch_ms_rocprof': rocprof_avg_ms(dom, n, mb),
+                    'note': ('achieved = concurrent_launches x algorithmic bytes of one launch / its event interval; with two '
+                             'sub-batch streams the event interval on a stream (end of its previous kernel -> end of this one) '
+                             'includes the wait for CU slots the other stream holds, rocprofv3 reports the dispatch alone '
+                             '(avg_launch_ms_rocprof, from the committed profiles/r01_kernel_stats.csv)')
                             if g > 1 else 'achieved = algorithmic bytes of one launch / its average duration',
                     'traffic_bytes_per_launch': tb, 'algorithmic_bytes_per_launch': per_class[dom]['bytes_per_launch'],
                     'traffic_source': 'profiles/r01_pmc_traffic_bench.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE x1)' if tb else None,
