@@ -131,3 +131,29 @@ def test_resident_one_and_two_slices(engine_mod, n, S, fp, variant):
     # compare against the scale of the whole gradient
     scale = np.sqrt(np.linalg.norm(rgd) ** 2 + np.linalg.norm(rgb) ** 2)
     assert np.linalg.norm(gd - rgd) <= 2e-4 * scale and np.linalg.norm(gb - rgb) <= 2e-4 * scale
+
+
+@pytest.mark.parametrize('n', [64, 72, 96])
+def test_resident_is_deterministic(engine_mod, n):
+    """Same inputs, three runs on a chip-filling batch: identical bits (no atomics; the wave-local passes of the 72^2
+    instance rely on LDS ordering inside a wave, the others on workgroup barriers — a race would show up here)."""
+    B, S = 300, 6
+    rng = np.random.default_rng(n)
+    delta = rng.uniform(0, 2e-5, size=(B, n, n, S)).astype(np.float32)
+    beta = 0.1 * delta
+    pr, pi = orc.gaussian_probe((n, n), n / 8., n / 8., 0.5)
+    eng = _engine(engine_mod, n, B, S, 'inf', 'numpy_skip_last', delta, beta, pr, pi, 'resident')
+    meas = rng.uniform(0.5, 1.5, size=(B, n, n)).astype(np.float32) * n
+    runs = []
+    for _ in range(3):
+        wave = eng.forward(B)
+        loss = eng.loss_grad(B, meas)
+        gd, gb = eng.grad_batch_to_host(B)
+        runs.append((wave, loss, gd, gb))
+    for r in runs[1:]:
+        assert np.array_equal(r[0], runs[0][0]) and r[1] == runs[0][1]
+        assert np.array_equal(r[2], runs[0][2]) and np.array_equal(r[3], runs[0][3])
+    pick = [0, 150, 299]
+    ref, _ = orc.multislice_propagate_batch_numpy(delta[pick], beta[pick], pr, pi, 5000., 1e-7, 'inf', delta[pick].shape,
+                                                  return_probe_array=False)
+    assert rel(runs[0][0][pick], ref) <= 5e-6
