@@ -48,3 +48,17 @@ def test_product_does_not_import_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'oracle' not in src.replace('no CPU fallback', ''), os.path.join(dirpath, f)
+
+
+def test_c_example_compiles_and_links(tmp_path):
+    """examples/cabi_forward.c is plain C against include/bdof.h: it must build with gcc alone and link to libbdof.so."""
+    import subprocess
+    import __graft_entry__ as entry
+    entry.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'cabi_forward')
+    subprocess.check_call(['gcc', '-O2', '-Wall', '-Werror', '-std=c99', '-I', os.path.join(root, 'include'),
+                           os.path.join(root, 'examples', 'cabi_forward.c'), '-o', exe,
+                           '-L', os.path.join(root, 'beyond_dof_amd'), '-lbdof', '-Wl,-rpath,' + os.path.join(root, 'beyond_dof_amd')])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 1 and b'usage' in r.stderr
