@@ -26,7 +26,7 @@ HBM_PEAK = 8.0e12
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_summary.py applies the gfx950
 # corrections); a process cannot collect them on itself, so the committed summary is read back here
 PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_bench.json')
-PMC_KERNEL = {'row_fwd': 'k_row_fwd<512, false, true>', 'col_prop': 'k_row_prop<512>', 'row_bwd': 'k_row_bwd<512>',
+PMC_KERNEL = {'row_fwd': 'k_row_fwd<512, false, true>', 'col_prop': 'k_row_prop<512>', 'row_bwd': 'k_row_bwd<512, 1>',
               'rot_adjoint': 'k_rot_adjoint'}
 
 
@@ -214,6 +214,12 @@ def main():
             ach = per_class[dom]['GBps']
             tb = pmc_traffic(dom, n, mb)
             g = per_class[dom]['concurrent_launches']
+            if tb is not None:
+                # the PMC passes serialise kernels, so the library may have run them un-split (one launch per batch) while
+                # the timed run splits the batch in g sub-batches: bring the measured bytes to the timed run's launch size
+                full = BYTES_PER_PX[dom] * px * (S if dom == 'rot_adjoint' else 1)
+                g_pmc = 1 if tb > 0.75 * full else g
+                tb = tb * g_pmc / g
             roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': ach * 1e9 / HBM_PEAK,
                     'traffic': None if tb is None else g * tb / (per_class[dom]['avg_ms'] * 1e-3) / 1e9,

@@ -312,12 +312,17 @@ static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf*
 }
 
 // A'_z: L1 (g) + phi tape -> L2 (g)
-static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout) {
+// hist: 0 = `tape` is the phi tape of slice z; 1 = `tape` is psi_hat_z of the history tape; 2 = slice 0 of the history mode
+static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout, int hist = 0) {
     ProfScope ps(c, BDOF_K_ROW_BWD);
-    RowBwdArgs a{sub_field(c, gin), sub_field(c, tape), sub_field(c, gout), c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY, sub_obj(c),
-                 B, c->NX, z, c->k, carrier_at(c, z), c->twY};
+    RowBwdArgs a{sub_field(c, gin), hist == 2 ? c->probe : sub_field(c, tape), sub_field(c, gout),
+                 c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY};
     DISPATCH_N(c->NY, {
-        hipLaunchKernelGGL((k_row_bwd<N_>), dim3(rows_grid<N_>(c, B, c->NX)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
+        const dim3 grid(rows_grid<N_>(c, B, c->NX));
+        const dim3 blk(BDOF_THREADS);
+        if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0>), grid, blk, 0, c->sub_stream, a);
+        else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1>), grid, blk, 0, c->sub_stream, a);
+        else hipLaunchKernelGGL((k_row_bwd<N_, 2>), grid, blk, 0, c->sub_stream, a);
     });
 }
 
@@ -930,8 +935,12 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     Group groups[BDOF_MAX_GROUPS];
     const int ng = batch_groups(c, B, c->NX, 16, groups);
     if ((r = fork_streams(c, ng))) return r;
-    forward_sweep(c, groups, ng, TAPE_PHI);
-    c->tape_valid = false;      // the tape now holds phi_z, not the per-slice history
+    // The tape is the per-slice history psi_hat_z that the transfer-function kernel writes anyway; A'_z recomputes phi_z from
+    // it (one more transform per launch, no tape write in A_z: 104 instead of 112 B per pixel per slice-step, 67.6 -> 65.3 ms
+    // per step at 512^3 x 25).  BDOF_TAPE_PHI=1 selects the older form (A_z stores phi_z) for comparison; same bits.
+    static const bool hist_tape = std::getenv("BDOF_TAPE_PHI") == nullptr;
+    forward_sweep(c, groups, ng, hist_tape ? TAPE_HISTORY : TAPE_PHI);
+    c->tape_valid = false;      // the tape holds phi_z (or an incomplete history), not what bdof_tape_to_real expects
     c->last_valid = false;
     const float seed_scale = 2.f / ((float)B * (float)c->NX * (float)c->NY);
     int npart = 0;
@@ -954,7 +963,11 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     for (int z = c->S - 1; z >= 0; --z) {
         for (int gi = 0; gi < ng; ++gi) {
             use_group(c, groups[gi]);
-            launch_row_bwd(c, groups[gi].B, z, c->bufB, c->tape + (size_t)z * fld, z > 0 ? c->bufA : nullptr);
+            if (hist_tape)
+                launch_row_bwd(c, groups[gi].B, z, c->bufB, z > 0 ? c->tape + (size_t)(z - 1) * fld : nullptr, z > 0 ? c->bufA : nullptr,
+                               z > 0 ? 1 : 2);
+            else
+                launch_row_bwd(c, groups[gi].B, z, c->bufB, c->tape + (size_t)z * fld, z > 0 ? c->bufA : nullptr);
             if (z > 0) launch_row_prop(c, groups[gi].B, c->bufA, c->bufB, c->hs, 1.f, 1);
         }
     }

@@ -420,7 +420,11 @@ struct RowBwdArgs {
     const cf* twiddle;
 };
 
-template <int NY>
+// HIST = 0: phi_z (scattered part) is read from the tape A_z wrote.  HIST = 1: the tape holds the per-slice history
+// psi_hat_z (the INPUT of A_z, written by the transfer-function kernel anyway) and phi_z is recomputed here with A_z's own
+// operations (inverse transform, modulation) — one more transform per launch, 8 B per pixel less traffic in A.
+// HIST = 2: slice 0 of that mode, phi_0 from the probe (no transform).
+template <int NY, int HIST>
 __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd(RowBwdArgs a) {
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
@@ -444,9 +448,15 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
             float2 db[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) g[m] = a.gin[off + tid + m * C::T];
+            const cf* psrc = HIST == 2 ? a.tape + (size_t)x * NY : a.tape + off;      // HIST 2: `tape` is the probe [NX][NY]
 #pragma unroll
-            for (int m = 0; m < 8; ++m) p[m] = a.tape[off + tid + m * C::T];
+            for (int m = 0; m < 8; ++m) p[m] = psrc[tid + m * C::T];
             load_obj_row(a.obj, obj_src_row(a.obj, b, x, a.z, a.NX), y0, tid, C::T, db);
+            if constexpr (HIST == 1) line_fft<NY, +1>(p, tw, tid, lds);                // psi_hat_z -> psi_z (scattered part)
+            if constexpr (HIST != 0) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) p[m] = modulate_eps(p[m], a.carrier, db[m]);
+            }
             line_fft<NY, +1>(g, tw, tid, lds);
             float2* gdst = a.grot + (((size_t)b * a.obj.S + a.z) * a.NX + x) * NY;
 #pragma unroll
