@@ -142,7 +142,7 @@ def main():
     if world > 1 or os.environ.get('BDOF_FORCE_TORCH_COMM'):      # the env switch exercises the RCCL path on one GPU
         import torch
         torch.cuda.set_device(local_rank)
-        comm = TorchComm('nccl')
+        comm = TorchComm(os.environ.get('BDOF_COMM_BACKEND', 'nccl'))      # gloo: rehearsal with several ranks on one GPU
 
     n, mb, n_theta = args.size, args.angles_per_gpu, args.n_theta
     sched = minibatch_schedule(n_theta, world, mb, rng=np.random.default_rng(1234))

@@ -53,7 +53,8 @@ class TorchComm(object):
         self.dist = dist
         if not dist.is_initialized():
             if backend is None:
-                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+                # BDOF_COMM_BACKEND=gloo: rehearse an N-rank run with several ranks on one GPU (RCCL wants one device per rank)
+                backend = os.environ.get('BDOF_COMM_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             if backend == 'nccl':
                 dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))

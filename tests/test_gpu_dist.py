@@ -72,3 +72,20 @@ def test_two_ranks_on_one_gpu_match_the_union_minibatch(tmp_path):
     diff = np.abs(d - r0['d'])
     assert np.mean(diff > 0.05 * lr) < 2e-3          # Adam's first steps are sign-like: see test_gpu_fullfield.py
     assert rel(r0['d'], d) <= 2e-3
+
+
+def test_bench_py_two_rank_rehearsal(tmp_path):
+    """bench.py's own N-rank path (sharded schedule, tune_allreduce on two ranks, max-over-ranks timing, one JSON line from
+    rank 0) with two ranks sharing the GPU and gloo as the collective backend (tools/rehearse_2ranks.sh)."""
+    import json
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    r = subprocess.run([os.path.join(ROOT, 'tools', 'rehearse_2ranks.sh'), '--size', '64', '--angles-per-gpu', '4', '--n-theta', '16',
+                        '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1                                           # exactly one JSON line on stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['value'] > 0 and d['scaling'] == 'weak'
+    assert d['config']['global_batch_angles'] == 8 and d['config']['allreduce_slabs'] in (1, 8)
+    assert np.isfinite(d['final_loss'])
