@@ -1274,6 +1274,7 @@ int bdof_adam_step_slab(bdof_ctx* c, const void* x_old, void* x_new, const void*
     const size_t n = (size_t)nx * NZv * NYv;
     size_t need = (n + 255) / 256;
     int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
+    grid = (grid + 7) / 8 * 8;                       // k_adam deals the range to the 8 XCDs by blockIdx % 8
     hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;

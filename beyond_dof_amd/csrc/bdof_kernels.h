@@ -648,8 +648,15 @@ __device__ __forceinline__ float sgn(float v) { return (v > 0.f) - (v < 0.f); }
 
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     const size_t slab = (size_t)a.NZv * a.NYv;
-    const size_t n = (size_t)a.x1 * slab;
-    for (size_t idx = (size_t)a.x0 * slab + (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin, so workgroup b works in the (b % 8)-th eighth of the
+    // range and walks it linearly with its XCD's other workgroups — the z+-1 / x+-1 neighbours of the TV stencil (4 KB and
+    // NZ*NY*8 B away) are then lines the same XCD's L2 has just seen, instead of another XCD's.
+    const size_t first = (size_t)a.x0 * slab, total = (size_t)(a.x1 - a.x0) * slab;
+    const size_t per_xcd = (total + 7) / 8;
+    const size_t lane0 = (size_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x, stride = (size_t)(gridDim.x >> 3) * blockDim.x;
+    const size_t c0 = (size_t)(blockIdx.x & 7) * per_xcd, c1 = c0 + per_xcd < total ? c0 + per_xcd : total;
+    for (size_t loc = c0 + lane0; loc < c1; loc += stride) {
+        const size_t idx = first + loc;
         const int y = idx % a.NYv;
         const size_t r = idx / a.NYv;
         const int z = r % a.NZv;
