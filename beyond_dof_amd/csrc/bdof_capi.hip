@@ -695,11 +695,31 @@ int bdof_sync(bdof_ctx* c) {
     return 0;
 }
 
+// exp(-2 pi i j / N) in float32, rounded so that the MODULUS is as close to one as float32 allows: among the roundings
+// of (cos, sin) up or down (each candidate within one ulp of the true value) the pair with the smallest | |w|^2 - 1 |.
+// Plain round-to-nearest leaves every twiddle with a modulus error of +-3e-8; the factors do not average out along the
+// paths of a transform, a chain of hundreds of transforms then drifts in energy.
+static cf unit_twiddle(double c, double s) {
+    const float c0 = (float)c, s0 = (float)s;
+    const float cc[3] = {c0, std::nextafterf(c0, 2.f), std::nextafterf(c0, -2.f)};
+    const float ss[3] = {s0, std::nextafterf(s0, 2.f), std::nextafterf(s0, -2.f)};
+    float bc = c0, bs = s0;
+    double best = std::fabs((double)c0 * c0 + (double)s0 * s0 - 1.0);
+    for (float x : cc)
+        for (float y : ss) {
+            if (std::fabs((double)x - c) > std::fabs((double)std::nextafterf(c0, 2.f) - (double)c0)) continue;      // > 1 ulp away
+            if (std::fabs((double)y - s) > std::fabs((double)std::nextafterf(s0, 2.f) - (double)s0)) continue;
+            const double e = std::fabs((double)x * x + (double)y * y - 1.0);
+            if (e < best) { best = e; bc = x; bs = y; }
+        }
+    return make_float2(bc, bs);
+}
+
 static int upload_twiddle(bdof_ctx* c, int N, cf** dst) {
     std::vector<cf> t(N);
     for (int j = 0; j < N; ++j) {
         double ang = -2.0 * M_PI * (double)j / (double)N;
-        t[j] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+        t[j] = unit_twiddle(std::cos(ang), std::sin(ang));
     }
     HIPC(c, hipMalloc((void**)dst, sizeof(cf) * N));
     HIPC(c, hipMemcpyAsync(*dst, t.data(), sizeof(cf) * N, hipMemcpyHostToDevice, c->stream));

@@ -39,15 +39,29 @@ template <int SIGN> __device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2,
     a3 = csub(s1, s3);
 }
 
-template <int SIGN> __device__ __forceinline__ void dft8(cf& a0, cf& a1, cf& a2, cf& a3, cf& a4, cf& a5, cf& a6, cf& a7) {
+// Irrational butterfly constants.  float32(sqrt(1/2)) is 1.7e-8 short (float32(sqrt(3)/2) 1.8e-8): every product with it
+// shrinks the amplitude by that much, the defects add up along a chain of transforms and a multislice stack drifts in
+// energy (-1.25e-7 per slice at 72^2).  ROUND selects the remedy:
+//   0  hi + lo pair, one more FMA per product — the constant is exact to 1e-15 (+1.5 % on the streaming step: not used);
+//   1  the nearest float32 (rounds DOWN for both constants); 2  its upper neighbour.  A kernel whose propagation step runs
+//      four line transforms uses 2 in one of them and 1 in the other three: (3 x -1.71 + 6.72)e-8 — the defects cancel to
+//      a quarter at no cost in instructions.  The streaming engine rounds up in the inverse transform of the
+//      transfer-function kernel, the LDS-resident kernel in its inverse passes along x.
+template <int ROUND> __device__ __forceinline__ float mul_sqrt_half(float t) {
+    if constexpr (ROUND == 0) return fmaf(t, 0.70710678118654752f, t * 1.2101617e-8f);
+    else if constexpr (ROUND == 1) return t * 0.70710678118654752f;
+    else return t * 0.70710682868957520f;
+}
+
+template <int SIGN, int ROUND = 1>
+__device__ __forceinline__ void dft8(cf& a0, cf& a1, cf& a2, cf& a3, cf& a4, cf& a5, cf& a6, cf& a7) {
     dft4<SIGN>(a0, a2, a4, a6);   // E0..E3 -> a0,a2,a4,a6
     dft4<SIGN>(a1, a3, a5, a7);   // O0..O3 -> a1,a3,a5,a7
-    const float h = 0.70710678118654752f;
     const float s = (float)SIGN;
     cf o0 = a1;
-    cf o1 = make_float2(h * (a3.x - s * a3.y), h * (a3.y + s * a3.x));      // * (1 + s i)/sqrt2
-    cf o2 = mul_si<SIGN>(a5);                                              // * s i
-    cf o3 = make_float2(h * (-a7.x - s * a7.y), h * (-a7.y + s * a7.x));    // * (-1 + s i)/sqrt2
+    cf o1 = make_float2(mul_sqrt_half<ROUND>(a3.x - s * a3.y), mul_sqrt_half<ROUND>(a3.y + s * a3.x));       // * (1 + s i)/sqrt2
+    cf o2 = mul_si<SIGN>(a5);                                                                                // * s i
+    cf o3 = make_float2(mul_sqrt_half<ROUND>(-a7.x - s * a7.y), mul_sqrt_half<ROUND>(-a7.y + s * a7.x));     // * (-1 + s i)/sqrt2
     cf e0 = a0, e1 = a2, e2 = a4, e3 = a6;
     a0 = cadd(e0, o0); a4 = csub(e0, o0);
     a1 = cadd(e1, o1); a5 = csub(e1, o1);
@@ -105,8 +119,8 @@ template <int N> struct FftTw {
     }
 };
 
-template <int R, int SIGN> __device__ __forceinline__ void dftR(cf (&u)[8], int j) {
-    if constexpr (R == 8) dft8<SIGN>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+template <int R, int SIGN, int ROUND = 1> __device__ __forceinline__ void dftR(cf (&u)[8], int j) {
+    if constexpr (R == 8) dft8<SIGN, ROUND>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
     else if constexpr (R == 4) {
         if (j == 0) dft4<SIGN>(u[0], u[1], u[2], u[3]); else dft4<SIGN>(u[4], u[5], u[6], u[7]);
     } else {
@@ -130,7 +144,7 @@ template <int N, int R, class L> __device__ __forceinline__ void stage_read(cf (
 }
 
 // WHICH: 0 = first stage (no twiddles), 1 / 2 = middle stage (LDS table), 3 = last stage (registers)
-template <int N, int SIGN, int R, int PP, int WHICH>
+template <int N, int SIGN, int R, int PP, int WHICH, int ROUND = 1>
 __device__ __forceinline__ void stage_compute(cf (&u)[8], const FftTw<N>& tw, int tid) {
     constexpr int T = N / 8, NB = 8 / R;
     typedef FftTw<N> TW;
@@ -153,7 +167,7 @@ __device__ __forceinline__ void stage_compute(cf (&u)[8], const FftTw<N>& tw, in
                 u[j * R + m] = cmul(u[j * R + m], w);
             }
         }
-        dftR<R, SIGN>(u, j);
+        dftR<R, SIGN, ROUND>(u, j);
     }
 }
 
@@ -172,50 +186,50 @@ template <int N, int R, int PP, class L> __device__ __forceinline__ void stage_w
 // Full transform of one line.  u[m] <-> position tid + m*T on entry and on exit.
 // Unnormalised; SIGN = -1 forward DFT, +1 inverse.  lds.sync_w2r() orders a stage's stores
 // before the next stage's loads; lds.sync_r2w() orders loads before the stores that reuse the image.
-template <int N, int SIGN, class L>
+template <int N, int SIGN, int ROUND = 1, class L>
 __device__ __forceinline__ void line_fft(cf (&u)[8], const FftTw<N>& tw, int tid, L& lds) {
     typedef FftPlan<N> P;
-    stage_compute<N, SIGN, P::R0, 1, 0>(u, tw, tid);
+    stage_compute<N, SIGN, P::R0, 1, 0, ROUND>(u, tw, tid);
     lds.sync_r2w();
     stage_write<N, P::R0, 1>(u, tid, lds);
     lds.sync_w2r();
     stage_read<N, P::R1>(u, tid, lds);
-    stage_compute<N, SIGN, P::R1, P::R0, (P::NS == 2 ? 3 : 1)>(u, tw, tid);
+    stage_compute<N, SIGN, P::R1, P::R0, (P::NS == 2 ? 3 : 1), ROUND>(u, tw, tid);
     if constexpr (P::NS > 2) {
         lds.sync_r2w();
         stage_write<N, P::R1, P::R0>(u, tid, lds);
         lds.sync_w2r();
         stage_read<N, P::R2>(u, tid, lds);
-        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, (P::NS == 3 ? 3 : 2)>(u, tw, tid);
+        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, (P::NS == 3 ? 3 : 2), ROUND>(u, tw, tid);
     }
     if constexpr (P::NS > 3) {
         lds.sync_r2w();
         stage_write<N, P::R2, P::R0 * P::R1>(u, tid, lds);
         lds.sync_w2r();
         stage_read<N, P::R3>(u, tid, lds);
-        stage_compute<N, SIGN, P::R3, P::R0 * P::R1 * P::R2, 3>(u, tw, tid);
+        stage_compute<N, SIGN, P::R3, P::R0 * P::R1 * P::R2, 3, ROUND>(u, tw, tid);
     }
 }
 
 // All stages but the last; the last stage's inputs are left in the line's LDS image (no sync after the
 // final store: the caller's workgroup barrier orders it before the transposed readers).
-template <int N, int SIGN, class L>
+template <int N, int SIGN, int ROUND = 1, class L>
 __device__ __forceinline__ void line_fft_partial(cf (&u)[8], const FftTw<N>& tw, int tid, L& lds) {
     typedef FftPlan<N> P;
-    stage_compute<N, SIGN, P::R0, 1, 0>(u, tw, tid);
+    stage_compute<N, SIGN, P::R0, 1, 0, ROUND>(u, tw, tid);
     lds.sync_r2w();
     stage_write<N, P::R0, 1>(u, tid, lds);
     if constexpr (P::NS > 2) {
         lds.sync_w2r();
         stage_read<N, P::R1>(u, tid, lds);
-        stage_compute<N, SIGN, P::R1, P::R0, 1>(u, tw, tid);
+        stage_compute<N, SIGN, P::R1, P::R0, 1, ROUND>(u, tw, tid);
         lds.sync_r2w();
         stage_write<N, P::R1, P::R0>(u, tid, lds);
     }
     if constexpr (P::NS > 3) {
         lds.sync_w2r();
         stage_read<N, P::R2>(u, tid, lds);
-        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, 2>(u, tw, tid);
+        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, 2, ROUND>(u, tw, tid);
         lds.sync_r2w();
         stage_write<N, P::R2, P::R0 * P::R1>(u, tid, lds);
     }
@@ -223,7 +237,7 @@ __device__ __forceinline__ void line_fft_partial(cf (&u)[8], const FftTw<N>& tw,
 
 // The last stage (radix 8, p = N/8) for butterfly j of a line whose image is `lds`; `tail` is the LDS copy
 // [m-1][j] of the twiddles exp(-2 pi i m j / N) (fill_tail_table).  On exit u[q] is the output at position j + q*N/8.
-template <int N, int SIGN, class L>
+template <int N, int SIGN, int ROUND = 1, class L>
 __device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* tail) {
     constexpr int T = N / 8;
     cf w[7];
@@ -236,5 +250,5 @@ __device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* 
         if (SIGN > 0) t.y = -t.y;
         u[m] = cmul(u[m], t);
     }
-    dft8<SIGN>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+    dft8<SIGN, ROUND>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
 }

@@ -54,7 +54,7 @@ template <int T> struct RowLds {
 //   dst[(pos) * ld + r] = scale * out(row r, position pos),  pos = j + q*T
 // Called by all threads between two workgroup barriers.
 // ---------------------------------------------------------------------------------------------
-template <int N, int SIGN>
+template <int N, int SIGN, int ROUND = 1>
 __device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, size_t ld, float scale, const cf* tail) {
     typedef RowCfg<N> C;
 #pragma nounroll
@@ -63,7 +63,7 @@ __device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, 
         const int r = q % C::TILE, j = q / C::TILE;
         RowLds<C::T> lds{smem + r * C::RS};
         cf u[8];
-        last_stage<N, SIGN>(u, j, lds, tail);
+        last_stage<N, SIGN, ROUND>(u, j, lds, tail);
 #pragma unroll
         for (int m = 0; m < 8; ++m) dst[(size_t)(j + m * C::T) * ld + r] = cscale(u[m], scale);
     }
@@ -265,10 +265,10 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_pro
                 if (a.conj_h) t.y = -t.y;
                 u[m] = cmul(u[m], cscale(t, a.scale));
             }
-            line_fft_partial<NX, +1>(u, tw, tid, lds);
+            line_fft_partial<NX, +1, 2>(u, tw, tid, lds);      // constants rounded up here, down elsewhere (bdof_fft.h)
         }
         __syncthreads();
-        transposed_tail<NX, +1>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, smem_tail);
+        transposed_tail<NX, +1, 2>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, smem_tail);
         __syncthreads();
     }
 }

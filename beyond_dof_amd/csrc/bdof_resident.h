@@ -42,12 +42,20 @@ static inline bool resident_supported(int n) {
 // elements it wrote itself), so waiting for the LDS counter is sufficient.
 __device__ __forceinline__ void res_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int SIGN> __device__ __forceinline__ void dft3(cf& a0, cf& a1, cf& a2) {
+// ROUND: how sqrt(3)/2 is represented (see mul_sqrt_half in bdof_fft.h): 0 hi + lo pair, 1 nearest float32 (1.8e-8 short),
+// 2 its upper neighbour (5.1e-8 long)
+template <int ROUND> __device__ __forceinline__ float mul_sqrt3_half(float t) {
+    if constexpr (ROUND == 0) return fmaf(t, 0.86602540378443865f, t * 1.5543624e-8f);
+    else if constexpr (ROUND == 1) return t * 0.86602540378443865f;
+    else return t * 0.86602544784545898f;
+}
+
+template <int SIGN, int ROUND = 0> __device__ __forceinline__ void dft3(cf& a0, cf& a1, cf& a2) {
     const cf t1 = cadd(a1, a2);
     const cf t2 = make_float2(a0.x - 0.5f * t1.x, a0.y - 0.5f * t1.y);
     const cf d = csub(a1, a2);
-    const float h = 0.86602540378443865f * (float)SIGN;
-    const cf t3 = make_float2(-h * d.y, h * d.x);                    // SIGN * i * sqrt(3)/2 * (a1 - a2)
+    const float s = (float)SIGN;
+    const cf t3 = make_float2(-s * mul_sqrt3_half<ROUND>(d.y), s * mul_sqrt3_half<ROUND>(d.x));      // SIGN * i * sqrt(3)/2 * (a1 - a2)
     a0 = cadd(a0, t1);
     a1 = cadd(t2, t3);
     a2 = csub(t2, t3);
@@ -69,10 +77,10 @@ template <int SIGN> __device__ __forceinline__ void dft5(cf& a0, cf& a1, cf& a2,
     a3 = csub(m2, n2);
 }
 
-template <int SIGN> __device__ __forceinline__ void dft9(cf (&u)[9]) {
-    dft3<SIGN>(u[0], u[3], u[6]);
-    dft3<SIGN>(u[1], u[4], u[7]);
-    dft3<SIGN>(u[2], u[5], u[8]);
+template <int SIGN, int ROUND = 0> __device__ __forceinline__ void dft9(cf (&u)[9]) {
+    dft3<SIGN, ROUND>(u[0], u[3], u[6]);
+    dft3<SIGN, ROUND>(u[1], u[4], u[7]);
+    dft3<SIGN, ROUND>(u[2], u[5], u[8]);
     const float s = (float)SIGN;
     const cf w1 = make_float2(0.76604444311897804f, s * 0.64278760968653933f);
     const cf w2 = make_float2(0.17364817766693035f, s * 0.98480775301220806f);
@@ -81,9 +89,9 @@ template <int SIGN> __device__ __forceinline__ void dft9(cf (&u)[9]) {
     u[7] = cmul(u[7], w2);
     u[5] = cmul(u[5], w2);
     u[8] = cmul(u[8], w4);
-    dft3<SIGN>(u[0], u[1], u[2]);
-    dft3<SIGN>(u[3], u[4], u[5]);
-    dft3<SIGN>(u[6], u[7], u[8]);
+    dft3<SIGN, ROUND>(u[0], u[1], u[2]);
+    dft3<SIGN, ROUND>(u[3], u[4], u[5]);
+    dft3<SIGN, ROUND>(u[6], u[7], u[8]);
     // u[3 k1 + k2] holds X[k1 + 3 k2]: transpose
     cf t;
     t = u[1]; u[1] = u[3]; u[3] = t;
@@ -91,13 +99,15 @@ template <int SIGN> __device__ __forceinline__ void dft9(cf (&u)[9]) {
     t = u[5]; u[5] = u[7]; u[7] = t;
 }
 
-template <int R, int SIGN> __device__ __forceinline__ void res_dft(cf (&u)[R]) {
+// ROUND: 1 / 2 = irrational constants rounded down / up (bdof_fft.h).  The passes along x of an inverse transform use 2, all
+// others 1: over the four line transforms of a propagation step the modulus defects of the constants nearly cancel.
+template <int R, int SIGN, int ROUND> __device__ __forceinline__ void res_dft(cf (&u)[R]) {
     if constexpr (R == 2) dft2<SIGN>(u[0], u[1]);
-    else if constexpr (R == 3) dft3<SIGN>(u[0], u[1], u[2]);
+    else if constexpr (R == 3) dft3<SIGN, ROUND>(u[0], u[1], u[2]);
     else if constexpr (R == 4) dft4<SIGN>(u[0], u[1], u[2], u[3]);
     else if constexpr (R == 5) dft5<SIGN>(u[0], u[1], u[2], u[3], u[4]);
-    else if constexpr (R == 8) dft8<SIGN>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
-    else if constexpr (R == 9) dft9<SIGN>(u);
+    else if constexpr (R == 8) dft8<SIGN, ROUND>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+    else if constexpr (R == 9) dft9<SIGN, ROUND>(u);
 }
 
 // One Stockham pass (radix R, NS = product of the earlier radices) over the N lines of the field, in place.
@@ -143,7 +153,7 @@ __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid, Epi& epi)
                     u[c][m] = cmul(u[c][m], w);
                 }
             }
-            res_dft<R, SIGN>(u[c]);
+            res_dft<R, SIGN, (SIGN > 0 && !ALONG_Y) ? 2 : 1>(u[c]);
         }
     }
     res_sync();
@@ -191,7 +201,7 @@ __device__ __forceinline__ void res_wpass(cf* f, const cf* tw, int tid, Epi& epi
                 u[m] = cmul(u[m], w);
             }
         }
-        res_dft<R, SIGN>(u);
+        res_dft<R, SIGN, (SIGN > 0 && !ALONG_Y) ? 2 : 1>(u);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -37,6 +37,9 @@ class MultisliceEngine(object):
         self.ctx.check(self.lib.bdof_configure(self.h, self.ny, self.nx, self.n_slice, self.batch_max,
                                                int(bool(with_grad)) | (2 if (force_generic or os.environ.get('BDOF_FORCE_GENERIC')) else 0)
                                                | (4 if engine == 'streaming' else 0) | (8 if engine == 'resident' else 0)))
+        self._engine_arg = 'generic' if force_generic else engine
+        self._device = device
+        self.calibrate_energy = True      # see set_probe
         self.det_mode = _lib.DET_NONE
         self._keep = {}          # device buffers that must outlive the calls that registered them
         self._tables = None
@@ -64,6 +67,7 @@ class MultisliceEngine(object):
         self.det_mode = det
         self.variant = variant
         self.k = k
+        self._physics_args = (energy_ev, psize_cm, free_prop_cm, variant, pi)
         # tf_all + far field: the last transfer-function step only multiplies the far field by the
         # unit-modulus H (F P phi = H . F phi); libbdof skips it and the host applies it to returned waves
         self._far_phase = None
@@ -73,13 +77,40 @@ class MultisliceEngine(object):
                                                  h00.ctypes.data, hdet00.ctypes.data if hdet00 is not None else None,
                                                  det, _VARIANT[variant]))
 
+    def _free_space_gain(self, probe_c64):
+        """Amplitude factor that undoes the energy drift of THIS probe through THIS stack in free space.  |H| = 1, so in
+        exact arithmetic propagation through an empty object conserves energy; in float32 it does not — sqrt(1/2) and
+        sqrt(3)/2 have no exact float32 value, the transfer-function entries around DC are nearly one number and share its
+        rounding error — and the defect is systematic: the same sign at every step (-1.2e-7 per slice at 72^2 with any plain
+        float32 FFT, rocFFT included).  It is measured once on a scratch context (the probe through S empty
+        slices, same engine, same variant) and divided out of the probe: the model is linear in the probe, so this
+        rescales every wave by one constant within 1e-4 of 1 and changes nothing else."""
+        scratch = MultisliceEngine(self.ny, self.nx, self.n_slice, 1, with_grad=False, device=self._device, engine=self._engine_arg)
+        scratch.calibrate_energy = False
+        energy_ev, psize_cm, free_prop_cm, variant, pi = self._physics_args
+        scratch.set_physics(energy_ev, psize_cm, None if isinstance(free_prop_cm, str) else free_prop_cm, variant=variant, pi=pi)
+        scratch.set_probe(probe_c64.real, probe_c64.imag)
+        zero = np.zeros((1, self.ny, self.nx, self.n_slice), dtype=np.float32)
+        scratch.set_object_batch(zero, zero)
+        out = scratch.forward(1)[0].astype(np.complex128)
+        e_in = float(np.sum(np.abs(probe_c64.astype(np.complex128)) ** 2))
+        e_out = float(np.sum(np.abs(out) ** 2))
+        if not (e_in > 0 and np.isfinite(e_out) and abs(e_out / e_in - 1) < 1e-3):
+            return 1.0                                             # nothing sensible to correct (empty probe, ...)
+        return float(np.sqrt(e_in / e_out))
+
     def set_probe(self, probe_real, probe_imag):
         probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.ny, self.nx))
         probe = probe.astype(np.complex64)                         # the reference rounds to complex64 too (np_funcs.py:20)
         # carrier splitting: probe = a0 + eps.  A (nearly) uniform probe rides on its mean; a localised one has a0 = 0.
         mean = complex(probe.astype(np.complex128).mean())
         a0 = mean if np.abs(probe - mean).max() <= 0.25 * abs(mean) else 0j
-        eps = np.ascontiguousarray((probe.astype(np.complex128) - a0).T.astype(np.complex64))
+        gain = 1.0
+        if a0 == 0 and self.calibrate_energy and self.n_slice > 1 and hasattr(self, '_physics_args') \
+                and not os.environ.get('BDOF_NO_ENERGY_CALIBRATION'):
+            gain = self._free_space_gain(probe)
+        self.probe_gain = gain
+        eps = np.ascontiguousarray(((probe.astype(np.complex128) - a0) * gain).T.astype(np.complex64))
         self.ctx.check(self.lib.bdof_set_probe(self.h, eps.ctypes.data, a0.real, a0.imag))
 
     def set_conv(self, energy_ev, psize_cm, kernel_size=17):
