@@ -18,6 +18,9 @@ def _idx_buf(ctx, values):
     return DeviceBuffer.from_host(ctx, np.asarray(values, dtype=np.int32))
 
 
+_GAIN_CACHE = {}      # free-space energy calibration per (geometry, physics, probe): see MultisliceEngine._free_space_gain
+
+
 class MultisliceEngine(object):
     """One wavefield geometry (NY x NX x S) on one GPU."""
 
@@ -85,14 +88,25 @@ class MultisliceEngine(object):
         float32 FFT, rocFFT included).  It is measured once on a scratch context (the probe through S empty
         slices, same engine, same variant) and divided out of the probe: the model is linear in the probe, so this
         rescales every wave by one constant within 1e-4 of 1 and changes nothing else."""
+        import hashlib
+        key = (self.ny, self.nx, self.n_slice, self._engine_arg, repr(self._physics_args),
+               hashlib.sha1(np.ascontiguousarray(probe_c64).tobytes()).hexdigest())
+        if key in _GAIN_CACHE:
+            return _GAIN_CACHE[key]
+        _GAIN_CACHE[key] = gain = self._measure_free_space_gain(probe_c64)
+        return gain
+
+    def _measure_free_space_gain(self, probe_c64):
         scratch = MultisliceEngine(self.ny, self.nx, self.n_slice, 1, with_grad=False, device=self._device, engine=self._engine_arg)
         scratch.calibrate_energy = False
         energy_ev, psize_cm, free_prop_cm, variant, pi = self._physics_args
         scratch.set_physics(energy_ev, psize_cm, None if isinstance(free_prop_cm, str) else free_prop_cm, variant=variant, pi=pi)
         scratch.set_probe(probe_c64.real, probe_c64.imag)
-        zero = np.zeros((1, self.ny, self.nx, self.n_slice), dtype=np.float32)
-        scratch.set_object_batch(zero, zero)
-        out = scratch.forward(1)[0].astype(np.complex128)
+        # empty object: one row of zeros and a rotation table that maps every (slice, x) to it
+        vol = DeviceBuffer.zeros(scratch.ctx, (1, self.ny, 2), np.float32)
+        tab = DeviceBuffer.zeros(scratch.ctx, (1, self.n_slice, self.nx), np.int32)
+        scratch.set_volume(vol, 1, self.ny, tab, self.nx, 1)
+        out = scratch.forward(1, angle_idx=[0])[0].astype(np.complex128)
         e_in = float(np.sum(np.abs(probe_c64.astype(np.complex128)) ** 2))
         e_out = float(np.sum(np.abs(out) ** 2))
         if not (e_in > 0 and np.isfinite(e_out) and abs(e_out / e_in - 1) < 1e-3):
