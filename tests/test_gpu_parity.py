@@ -333,3 +333,30 @@ def test_full_size_properties_512(engine_mod):
     eng.set_object_batch(delta - step * gd, beta - step * gb)
     l1 = eng.loss_grad(B, meas)
     assert abs((l0 - l1) - step * gnorm2) <= 0.05 * step * gnorm2
+
+
+def test_cfg3_full_depth_vs_oracle(engine_mod):
+    """BASELINE's headline wavefield at its full size: one 512 x 512 wavefield through all 512 slices (plane probe,
+    charcoal-like object of bench.py, near-field detector) against the float64 oracle — the oracle needs ~20 s for it.
+    Carrier splitting keeps the float32 forward within 1.2e-7 of the reference in intensity (north star: 1e-5), the
+    gradient within 2e-5 (tools/gpu_check_cfg3_depth.py)."""
+    from scipy.ndimage import uniform_filter
+    n = S = 512
+    rng = np.random.default_rng(3)
+    delta = uniform_filter(rng.random((1, n, n, S)) * 2e-6, size=(1, 3, 3, 3), mode='wrap')
+    beta = 0.1 * delta
+    pr, pi = np.ones((n, n)), np.zeros((n, n))
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, 1e-4, delta.shape, return_probe_array=False)
+    meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, 1e-4)
+    eng = engine_mod.MultisliceEngine(n, n, S, 1, with_grad=True)
+    eng.set_physics(5000., 1e-7, 1e-4)
+    eng.set_probe(pr, pi)
+    eng.set_object_batch(delta, beta)
+    wave = eng.forward(1)
+    assert rel(np.abs(wave) ** 2, np.abs(ref) ** 2) <= 1e-6
+    assert rel(wave, ref) <= 5e-7
+    loss = eng.loss_grad(1, meas)
+    gd, gb = eng.grad_batch_to_host(1)
+    assert abs(loss - rl) <= 1e-6 * abs(rl)
+    assert rel(gd, rgd) <= 1e-4 and rel(gb, rgb) <= 1e-4
