@@ -360,3 +360,32 @@ def test_cfg3_full_depth_vs_oracle(engine_mod):
     gd, gb = eng.grad_batch_to_host(1)
     assert abs(loss - rl) <= 1e-6 * abs(rl)
     assert rel(gd, rgd) <= 1e-4 and rel(gb, rgb) <= 1e-4
+
+
+def test_cfg2_full_size_fullfield_step_vs_oracle(engine_mod):
+    """cfg2 at its full size (256^3 volume, 256 slices, 50-angle rotation tables): rotation gather, forward, loss, adjoint
+    and rotation adjoint of a two-angle minibatch against the oracle (the oracle needs ~20 s per angle pair)."""
+    from beyond_dof_amd.solver import FullfieldSolver
+    n, n_theta, fp = 256, 50, 1e-4
+    rng = np.random.default_rng(2)
+    od = rng.uniform(0, 1e-6, size=(n, n, n))
+    ob = 0.1 * od
+    coords = orc.rotation_lookup([n, n, n], n_theta)
+    idx = np.array([7, 31])
+    one, zero = np.ones((n, n)), np.zeros((n, n))
+    rot = np.stack([orc.apply_rotation(np.stack([od, ob], axis=3), coords[j]) for j in idx])
+    ref_wave, _ = orc.multislice_propagate_batch_numpy(rot[..., 0], rot[..., 1], one, zero, 5000., 1e-7, fp, rot[..., 0].shape,
+                                                       return_probe_array=False)
+    del rot
+    prj = np.zeros((n_theta, n, n))
+    prj[idx] = np.abs(ref_wave) * (1 + 0.05 * rng.normal(size=ref_wave.shape))
+    s = FullfieldSolver(n, n, n, n_theta, len(idx), 5000., 1e-7, free_prop_cm=fp, coord_ls=coords)
+    s.set_volume(od, ob)
+    s.set_measurements(prj)
+    assert rel(np.abs(s.forward_angles(idx)) ** 2, np.abs(ref_wave) ** 2) <= 1e-6
+    loss = s.loss_and_grad(idx)
+    gd, gb = s.gradient_to_host()
+    rl, rgd, rgb = orc.fullfield_loss_and_grad(od, ob, coords, idx, prj[idx], one, zero, 5000., 1e-7, free_prop_cm=fp,
+                                               with_reg=False)
+    assert abs(loss - rl) <= 1e-6 * rl
+    assert rel(gd, rgd) <= 1e-4 and rel(gb, rgb) <= 1e-4
