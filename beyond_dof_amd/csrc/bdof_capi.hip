@@ -53,6 +53,7 @@ struct bdof_ctx {
     // LDS-resident engine (small square fields, bdof_resident.h)
     bool resident = false, res_dirty = true, res_always = false;
     cf *hsT = nullptr, *hdetT = nullptr, *twR = nullptr, *res_carrier = nullptr;
+    cf *pstack = nullptr, *pdet = nullptr;      // carrier field of a localised probe (bdof_set_probe_stack)
     // generic-size engine (rocFFT): one plan pair per batch size
     bool generic = false;
     std::map<int, std::pair<rocfft_plan, rocfft_plan>> gplans;
@@ -567,7 +568,7 @@ template <int N> static int resident_launch(bdof_ctx* c, const ResArgs& a, int g
 // sizes without a fused plan always take it (the alternative is the unfused rocFFT engine).
 static bool use_resident(const bdof_ctx* c, int B) {
     if (!c->resident) return false;
-    return c->generic || c->res_always || B * 4 >= c->ncu;
+    return c->pstack || c->generic || c->res_always || B * 4 >= c->ncu;      // a carrier field exists in this engine only
 }
 
 static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, bool do_grad) {
@@ -581,7 +582,7 @@ static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, b
     ProfScope ps(c, BDOF_K_ROW_FWD);
     const bool grad = do_grad && meas;
     ResArgs a{c->probe, c->hsT, c->hdetT, grad ? c->tape : nullptr, (size_t)c->Bmax * c->NX * c->NY, c->grot, c->obj, c->res_carrier,
-              carrier_det(c), meas, (cf*)out_wave, c->partial, c->twR, B, c->S, c->det_mode,
+              carrier_det(c), c->pstack, c->pdet, meas, (cf*)out_wave, c->partial, c->twR, B, c->S, c->det_mode,
               c->variant == BDOF_VARIANT_TF_ALL ? 1 : 0, grad ? 1 : 0, c->k, 2.f / ((float)B * (float)c->NX * (float)c->NY)};
     const int grid = B < c->npartial ? B : c->npartial;
     int r = 0;
@@ -658,9 +659,10 @@ static void free_generic(bdof_ctx* c) {
 
 static void free_workspace(bdof_ctx* c) {
     free_generic(c);
-    void* ptrs[] = {c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
+    void* ptrs[] = {c->pstack, c->pdet, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
+    c->pstack = c->pdet = nullptr;
     c->resident = false;
     c->bufC = c->conv_scal = nullptr;
     c->have_conv = false;
@@ -825,6 +827,29 @@ int bdof_set_probe(bdof_ctx* c, const float* probe, double a0_re, double a0_im) 
     c->a0 = std::complex<double>(a0_re, a0_im);
     c->res_dirty = true;
     c->have_probe = true;
+    return 0;
+}
+
+int bdof_probe_stack_supported(bdof_ctx* c) {
+    // the carrier field lives in the LDS-resident kernel; it can be used when that engine serves every batch size
+    return c && c->resident && (c->generic || c->res_always) ? 1 : 0;
+}
+
+int bdof_set_probe_stack(bdof_ctx* c, const float* stack, const float* det) {
+    if (!c) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->pstack) { (void)hipFree(c->pstack); c->pstack = nullptr; }
+    if (c->pdet) { (void)hipFree(c->pdet); c->pdet = nullptr; }
+    if (!stack && !det) return 0;
+    if (!stack || !det) return fail(c, BDOF_ERR_ARG, "bdof_set_probe_stack: both arrays or neither");
+    if (!bdof_probe_stack_supported(c)) return fail(c, BDOF_ERR_STATE, "a probe stack needs the LDS-resident engine for every batch size");
+    const size_t fld = sizeof(cf) * (size_t)c->NX * c->NY;
+    HIPC(c, hipMalloc((void**)&c->pstack, fld * (size_t)c->S));
+    HIPC(c, hipMalloc((void**)&c->pdet, fld));
+    HIPC(c, hipMemcpy(c->pstack, stack, fld * (size_t)c->S, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->pdet, det, fld, hipMemcpyHostToDevice));
     return 0;
 }
 

@@ -277,6 +277,12 @@ struct ResArgs {
     ObjView obj;
     const cf* carrier;     // device [S]: a_z
     cf carrier_det;        // constant part of the detector wave (far field: DC bin value)
+    // Carrier FIELD (bdof_set_probe_stack): the probe propagated through free space, p_z [S][N][N] at the entrance of every
+    // slice and pdet [N][N] at the detector (far field: its un-normalised fft2, [kx][ky]), computed by the host in
+    // float64.  The wave is then held as psi_z = p_z + eps_z and only the SCATTERED part eps goes through the float32
+    // transforms — the generalisation of the scalar carrier to a localised probe.  nullptr: scalar carrier above.
+    const cf* pstack;
+    const cf* pdet;
     const float* meas;     // nullable; real detectors [b][x][y], far field [b][ky][kx]
     cf* out_wave;          // nullable; same order as meas
     double* partial;       // [2 * gridDim.x]
@@ -387,6 +393,7 @@ template <int N, int T> struct EpiMod {
     const long long* rows;     // object rows of slice z+1
     cf* tape;                  // nullable: tape of slice z+1 for this wavefield
     cf car;
+    const cf* pz;              // nullable: carrier field of slice z+1
     int y0;
     float2 fac[ResLast<N, T>::CNT][ResLast<N, T>::R];
     __device__ __forceinline__ void pre(int c, int m, int line, int pos) {
@@ -398,8 +405,9 @@ template <int N, int T> struct EpiMod {
         fac[c][m] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
     }
     __device__ __forceinline__ cf post(int c, int m, int line, int pos, cf v) {
-        const cf phi = modulate_eps(v, car, fac[c][m]);
-        if (tape) tape[pos * N + line] = phi;
+        const cf pc = pz ? pz[pos * N + line] : car;
+        const cf phi = modulate_eps(v, pc, fac[c][m]);
+        if (tape) tape[pos * N + line] = pz ? cadd(phi, pc) : phi;      // carrier field: the tape holds the FULL phi (see adjoint)
         return phi;
     }
 };
@@ -412,6 +420,7 @@ template <int N, int T> struct EpiBwd {
     const cf* tape;
     float2* gdst;
     cf car;
+    const cf* pz;              // nullable: carrier field of slice z
     int y0;
     float2 fac[ResLast<N, T>::CNT][ResLast<N, T>::R];
     cf tp[ResLast<N, T>::CNT][ResLast<N, T>::R];
@@ -425,7 +434,7 @@ template <int N, int T> struct EpiBwd {
         tp[c][m] = tape[pos * N + line];
     }
     __device__ __forceinline__ cf post(int c, int m, int line, int pos, cf G) {
-        const cf phi = cadd(tp[c][m], car);
+        const cf phi = pz ? tp[c][m] : cadd(tp[c][m], car);            // with a carrier field the tape already holds p + eps
         const cf q = cmulc(G, phi);
         gdst[pos * N + line] = make_float2(a->k * q.y, -a->k * q.x);
         return cmulc(G, make_float2(1.f + fac[c][m].x, fac[c][m].y));
@@ -438,23 +447,26 @@ template <int N, int T> struct ResPoint {
     static constexpr int P = N | 1, EPT = Pipe::EPT;
 
     // phi = c psi : modulation of the slice whose factors are in m; phi goes to the LDS image and to the tape
-    static __device__ __forceinline__ void modulate(cf* f, cf* tape, cf car, const float2 (&m)[EPT], int tid) {
+    // pz: nullable carrier field of the slice ([x][y], read where it is used: an L2-resident table shared by all wavefields)
+    static __device__ __forceinline__ void modulate(cf* f, cf* tape, cf car, const cf* pz, const float2 (&m)[EPT], int tid) {
         asm volatile("" : "+v"(tid));
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
             const int e = tid + i * T;
             if (EPT * T == N * N || e < N * N) {
                 const int x = e / N, y = e - x * N;
-                const cf phi = modulate_eps(f[x * P + y], car, m[i]);
+                const cf pc = pz ? pz[e] : car;
+                const cf phi = modulate_eps(f[x * P + y], pc, m[i]);
                 f[x * P + y] = phi;
-                if (tape) tape[e] = phi;
+                if (tape) tape[e] = pz ? cadd(phi, pc) : phi;      // carrier field: the tape holds the FULL phi, so that the
+                                                                    // adjoint sweep does not have to read p_z again
             }
         }
         res_sync();
     }
     // adjoint of the modulation: gradient rows out, G(psi) = conj(c) G(phi) left in the LDS image
-    static __device__ __forceinline__ void adjoint(cf* f, const cf (&t)[EPT], const float2 (&m)[EPT], cf car, float k, float2* gdst,
-                                                   int tid) {
+    static __device__ __forceinline__ void adjoint(cf* f, const cf (&t)[EPT], const float2 (&m)[EPT], cf car, const cf* pz, float k,
+                                                   float2* gdst, int tid) {
         asm volatile("" : "+v"(tid));
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
@@ -462,7 +474,7 @@ template <int N, int T> struct ResPoint {
             if (EPT * T == N * N || e < N * N) {
                 const int x = e / N, y = e - x * N;
                 const cf G = f[x * P + y];
-                const cf phi = cadd(t[i], car);
+                const cf phi = pz ? t[i] : cadd(t[i], car);
                 const cf q = cmulc(G, phi);
                 gdst[e] = make_float2(k * q.y, -k * q.x);
                 f[x * P + y] = cmulc(G, make_float2(1.f + m[i].x, m[i].y));
@@ -507,7 +519,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
         Pipe::load_factors(a, rowbuf, y0, tid, m);
         if constexpr (FUSE) {
             // slice 0 is modulated on its own; every later slice inside the propagation step that produces it (EpiMod)
-            Point::modulate(f, tape0, a.carrier[0], m, tid);
+            Point::modulate(f, tape0, a.carrier[0], a.pstack, m, tid);
             for (int z = 0; z < a.S; ++z) {
                 const long long r2 = Pipe::row_of(a, b, z + 2, tid);
                 if (z + 1 < a.S) {
@@ -516,6 +528,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     em.rows = rowbuf + ((z + 1) % 3) * N;
                     em.tape = tape0 ? tape0 + (size_t)(z + 1) * a.tape_stride : nullptr;
                     em.car = a.carrier[z + 1];
+                    em.pz = a.pstack ? a.pstack + (size_t)(z + 1) * fsz : nullptr;
                     em.y0 = y0;
                     res_prop<N, T, false>(f, a.hsT, tw, tid, em);
                 } else if (a.tf_all && !far) {
@@ -526,7 +539,8 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
         } else {
             for (int z = 0; z < a.S; ++z) {
                 const long long r2 = Pipe::row_of(a, b, z + 2, tid);
-                Point::modulate(f, tape0 ? tape0 + (size_t)z * a.tape_stride : nullptr, a.carrier[z], m, tid);
+                Point::modulate(f, tape0 ? tape0 + (size_t)z * a.tape_stride : nullptr, a.carrier[z],
+                                a.pstack ? a.pstack + (size_t)z * fsz : nullptr, m, tid);
                 if (z + 1 < a.S) Pipe::load_factors(a, rowbuf + ((z + 1) % 3) * N, y0, tid, m);      // in flight during the step
                 if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;
                 if (z + 1 < a.S || (a.tf_all && !far)) res_prop<N, T, false>(f, a.hsT, tw, tid);
@@ -539,7 +553,8 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
         for (int e = tid; e < N * N; e += T) {
             const int x = e / N, y = e - x * N;
             cf d = f[x * P + y];
-            if (!far || e == 0) d = cadd(d, a.carrier_det);
+            if (a.pdet) d = cadd(d, a.pdet[e]);
+            else if (!far || e == 0) d = cadd(d, a.carrier_det);
             const size_t o = b * fsz + (far ? y * N + x : e);
             if (a.out_wave) a.out_wave[o] = d;
             if (a.meas) f[x * P + y] = loss_seed(d, a.meas[o], a.seed_scale, acc, acc2);
@@ -572,17 +587,18 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     eb.tape = tape;
                     eb.gdst = gdst;
                     eb.car = a.carrier[z];
+                    eb.pz = a.pstack ? a.pstack + (size_t)z * fsz : nullptr;
                     eb.y0 = y0;
                     res_prop<N, T, true>(f, a.hsT, tw, tid, eb);
                 } else {
                     // the slice the adjoint sweep starts from when no transfer-function step follows the last slice
                     Pipe::load_factors(a, rowbuf + (z % 3) * N, y0, tid, m);
                     Pipe::load_field(tape, tid, t);
-                    Point::adjoint(f, t, m, a.carrier[z], a.k, gdst, tid);
+                    Point::adjoint(f, t, m, a.carrier[z], a.pstack ? a.pstack + (size_t)z * fsz : nullptr, a.k, gdst, tid);
                 }
             } else {
                 if (prop_after) res_prop<N, T, true>(f, a.hsT, tw, tid);
-                Point::adjoint(f, t, m, a.carrier[z], a.k, gdst, tid);
+                Point::adjoint(f, t, m, a.carrier[z], a.pstack ? a.pstack + (size_t)z * fsz : nullptr, a.k, gdst, tid);
                 if (z > 0) {                                           // in flight during the next adjoint step
                     Pipe::load_factors(a, rowbuf + ((z - 1) % 3) * N, y0, tid, m);
                     Pipe::load_field(tape0 + (size_t)(z - 1) * a.tape_stride, tid, t);

@@ -113,13 +113,53 @@ class MultisliceEngine(object):
             return 1.0                                             # nothing sensible to correct (empty probe, ...)
         return float(np.sqrt(e_in / e_out))
 
+    def _probe_stack(self, probe_c64):
+        """The probe propagated through free space to the entrance of every slice and to the detector, in float64 on the
+        host (np_funcs.py:42-61 without an object) — the carrier field of bdof_set_probe_stack (include/bdof.h)."""
+        energy_ev, psize_cm, free_prop_cm, variant, pi = self._physics_args
+        voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
+        lmbda_nm = 1240. / energy_ev
+        h = np.fft.ifftshift(util.get_kernel(voxel_nm[-1], lmbda_nm, voxel_nm, (self.ny, self.nx), pi=pi))
+        p = probe_c64.astype(np.complex128)
+        stack = np.empty((self.n_slice, self.nx, self.ny), dtype=np.complex64)
+        for z in range(self.n_slice):
+            stack[z] = p.T
+            if z < self.n_slice - 1:
+                p = np.fft.ifft2(np.fft.fft2(p) * h)
+        if self.det_mode == _lib.DET_FAR:
+            det = np.fft.fft2(p)                      # un-shifted, un-normalised; a tf_all step before it is applied on the host
+        else:
+            if variant == 'tf_all':
+                p = np.fft.ifft2(np.fft.fft2(p) * h)
+            if self.det_mode == _lib.DET_NEAR:
+                hd = np.fft.ifftshift(util.get_kernel(free_prop_cm * 1e7, lmbda_nm, voxel_nm, (self.ny, self.nx), pi=pi))
+                p = np.fft.ifft2(np.fft.fft2(p) * hd)
+            det = p
+        return np.ascontiguousarray(stack), np.ascontiguousarray(det.T.astype(np.complex64))
+
     def set_probe(self, probe_real, probe_imag):
         probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.ny, self.nx))
         probe = probe.astype(np.complex64)                         # the reference rounds to complex64 too (np_funcs.py:20)
-        # carrier splitting: probe = a0 + eps.  A (nearly) uniform probe rides on its mean; a localised one has a0 = 0.
+        # Carrier splitting: the wave is held as carrier + eps and only eps runs through the float32 transforms.
+        #  - a (nearly) uniform probe rides on its mean a0, propagated exactly as a scalar inside the library;
+        #  - a localised probe on the LDS-resident engine rides on its own free-space propagation, a carrier FIELD per slice
+        #    computed here in float64 (bdof_set_probe_stack): eps is the scattered wave alone;
+        #  - otherwise a0 = 0, and the systematic energy drift of the float32 chain is measured and divided out.
         mean = complex(probe.astype(np.complex128).mean())
         a0 = mean if np.abs(probe - mean).max() <= 0.25 * abs(mean) else 0j
         gain = 1.0
+        self.probe_stack = False
+        use_stack = (a0 == 0 and hasattr(self, '_physics_args') and not os.environ.get('BDOF_NO_PROBE_STACK')
+                     and self.lib.bdof_probe_stack_supported(self.h) == 1)
+        if use_stack:
+            stack, det = self._probe_stack(probe)
+            zero = np.zeros((self.nx, self.ny), dtype=np.complex64)
+            self.ctx.check(self.lib.bdof_set_probe(self.h, zero.ctypes.data, 0.0, 0.0))
+            self.ctx.check(self.lib.bdof_set_probe_stack(self.h, stack.ctypes.data, det.ctypes.data))
+            self.probe_stack, self.probe_gain = True, 1.0
+            return
+        if self.lib.bdof_probe_stack_supported(self.h) == 1:
+            self.ctx.check(self.lib.bdof_set_probe_stack(self.h, None, None))
         if a0 == 0 and self.calibrate_energy and self.n_slice > 1 and hasattr(self, '_physics_args') \
                 and not os.environ.get('BDOF_NO_ENERGY_CALIBRATION'):
             gain = self._free_space_gain(probe)
