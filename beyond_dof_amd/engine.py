@@ -18,6 +18,7 @@ def _idx_buf(ctx, values):
     return DeviceBuffer.from_host(ctx, np.asarray(values, dtype=np.int32))
 
 
+RESIDENT_SIZES = (32, 36, 48, 64, 72, 80, 96, 128)      # square fields with an LDS-resident plan (csrc/bdof_resident.h)
 _GAIN_CACHE = {}      # free-space energy calibration per (geometry, physics, probe): see MultisliceEngine._free_space_gain
 
 

@@ -231,7 +231,13 @@ class PtychoSolver(object):
         self.comm = comm or PseudoComm()
         self.probe_pos = np.asarray(probe_pos).astype(int)
         self.half = (np.array(probe_size) / 2).astype('int')            # ptychography.py:138
-        self.eng = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream)
+        # a localised probe rides on its float64 free-space propagation (carrier field, engine.set_probe) on the LDS-resident
+        # engine: whenever the probe size has a resident plan that engine is pinned for every batch size, also where the
+        # streaming kernels would be faster for a small batch (64^2 / 128^2) — 1e-7 instead of 1e-5 against the reference
+        from .engine import RESIDENT_SIZES
+        pin = 'resident' if (self.py == self.px and self.py in RESIDENT_SIZES and not self.conv
+                             and not os.environ.get('BDOF_NO_RESIDENT_PIN')) else 'auto'
+        self.eng = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream, engine=pin)
         self.ctx = self.eng.ctx
         self.eng.set_physics(energy_ev, psize_cm, 'inf', variant=variant)   # free_prop_cm='inf', ptychography.py:76
         if self.conv:

@@ -36,6 +36,8 @@ def test_ptycho_forward_and_gradient_vs_oracle(psz, force_resident, monkeypatch)
     from beyond_dof_amd.solver import PtychoSolver
     if force_resident:
         monkeypatch.setenv('BDOF_FORCE_RESIDENT', '1')
+    elif psz == (64, 64):
+        monkeypatch.setenv('BDOF_NO_RESIDENT_PIN', '1')      # PtychoSolver pins the resident engine where it exists: not here
     rng, n, n_theta, psz, pos, od, ob, coords, prr, pii = _setup(psz)
     mb = 6
     s = PtychoSolver((n, n, n), psz, pos, n_theta, mb, 5000., 1e-7, prr, pii, coord_ls=coords)
@@ -55,15 +57,19 @@ def test_ptycho_forward_and_gradient_vs_oracle(psz, force_resident, monkeypatch)
     # 4e-6 (60^2) ... 1.0e-5 (72^2 on the rocFFT engine) in the intensities (tools/gpu_check_pty_err.py) — it was 1.4e-5
     # before the systematic energy drift of float32 transform chains was taken out; the bound stays at 1.2e-5,
     # above the 1e-5 of the short-stack comparisons in test_gpu_parity.py / test_gpu_resident.py.
-    assert rel(np.abs(w) ** 2, np.abs(ref) ** 2) <= 1.2e-5
+    on_resident = s.eng.probe_stack
+    assert on_resident == (force_resident or psz == (72, 72))
+    assert rel(np.abs(w) ** 2, np.abs(ref) ** 2) <= (5e-7 if on_resident else 1.2e-5)
     meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
     loss = s.loss_and_grad(i_theta, sel, meas)
     gd, gb = s.gradient_to_host()
     rl, rgd, rgb = orc.ptycho_loss_and_grad(od, ob, coords[i_theta], pos, pos[sel], meas, prr, pii, psz, 5000., 1e-7)
-    assert abs(loss - rl) <= 5e-5 * rl
-    # far field, 96 slices, localised probe (no carrier to split off): the |D| - |m| cancellation in float32 costs
-    # ~3e-4 of the gradient (see tests/test_gpu_parity.py header); bound it at 1e-3
-    assert rel(gd, rgd) <= 1e-3 and rel(gb, rgb) <= 1e-3
+    assert abs(loss - rl) <= (2e-6 if on_resident else 5e-5) * rl
+    # far field, 96 slices, localised probe: without a carrier to split off the |D| - |m| cancellation in float32 costs
+    # ~3e-4 of the gradient (see tests/test_gpu_parity.py header), bound 1e-3; on the resident engine the probe's free-space
+    # propagation is the carrier (bdof_set_probe_stack) and the whole comparison tightens by two orders of magnitude
+    gtol = 1e-4 if on_resident else 1e-3
+    assert rel(gd, rgd) <= gtol and rel(gb, rgb) <= gtol
 
 
 def test_reconstruct_ptychography_end_to_end(tmp_path, monkeypatch):
