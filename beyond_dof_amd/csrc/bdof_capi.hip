@@ -478,7 +478,7 @@ static int generic_forward_sweep(bdof_ctx* c, int B, bool tape, rocfft_plan pf, 
         {
             ProfScope ps(c, BDOF_K_ROW_FWD);
             GModArgs m{c->bufA, z == 0 ? c->probe : nullptr, tape ? c->tape + (size_t)z * fld : nullptr, c->obj, B, c->NX, c->NY, z,
-                       make_float2((float)a.real(), (float)a.imag())};
+                       make_float2((float)a.real(), (float)a.imag()), c->pstack ? c->pstack + (size_t)z * c->NX * c->NY : nullptr};
             hipLaunchKernelGGL(k_g_modulate, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, m);
         }
         const bool last = z == c->S - 1;
@@ -508,7 +508,7 @@ static int generic_forward(bdof_ctx* c, int B, void* out_wave, bool keep_tape) {
     if (out_wave) {
         const size_t n = (size_t)B * c->NX * c->NY;
         GLossArgs la{c->bufA, (cf*)out_wave, nullptr, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
-                     make_float2((float)a.real(), (float)a.imag()), 0.f};
+                     make_float2((float)a.real(), (float)a.imag()), 0.f, c->pdet};
         hipLaunchKernelGGL(k_g_loss, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, la);
     }
     return 0;
@@ -527,7 +527,7 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
     {
         ProfScope ps(c, BDOF_K_LOSS);
         GLossArgs la{c->bufA, (cf*)out_wave, meas, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
-                     make_float2((float)a.real(), (float)a.imag()), 2.f / ((float)B * (float)c->NX * (float)c->NY)};
+                     make_float2((float)a.real(), (float)a.imag()), 2.f / ((float)B * (float)c->NX * (float)c->NY), c->pdet};
         hipLaunchKernelGGL(k_g_loss, dim3(egrid), dim3(256), 0, c->stream, la);
     }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, egrid, 1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
@@ -542,7 +542,7 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
         const bool prop_after = z < c->S - 1 || (tf_all && c->det_mode != BDOF_DET_FAR);
         if (prop_after && (r = generic_prop(c, B, pf, pi, c->bufA, c->hs, 1))) return r;
         ProfScope ps(c, BDOF_K_ROW_BWD);
-        GBwdArgs ba{c->bufA, c->tape + (size_t)z * fld, c->grot, c->obj, B, c->NX, c->NY, z, c->k, carrier_at(c, z)};
+        GBwdArgs ba{c->bufA, c->tape + (size_t)z * fld, c->grot, c->obj, B, c->NX, c->NY, z, c->k, carrier_at(c, z), c->pstack ? 1 : 0};
         hipLaunchKernelGGL(k_g_bwd, dim3(egrid), dim3(256), 0, c->stream, ba);
     }
     return 0;
@@ -568,7 +568,7 @@ template <int N> static int resident_launch(bdof_ctx* c, const ResArgs& a, int g
 // sizes without a fused plan always take it (the alternative is the unfused rocFFT engine).
 static bool use_resident(const bdof_ctx* c, int B) {
     if (!c->resident) return false;
-    return c->pstack || c->generic || c->res_always || B * 4 >= c->ncu;      // a carrier field exists in this engine only
+    return c->pstack || c->generic || c->res_always || B * 4 >= c->ncu;      // (a carrier field is never set where the streaming engine could run)
 }
 
 static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, bool do_grad) {
@@ -831,8 +831,9 @@ int bdof_set_probe(bdof_ctx* c, const float* probe, double a0_re, double a0_im) 
 }
 
 int bdof_probe_stack_supported(bdof_ctx* c) {
-    // the carrier field lives in the LDS-resident kernel; it can be used when that engine serves every batch size
-    return c && c->resident && (c->generic || c->res_always) ? 1 : 0;
+    // the carrier field is implemented by the LDS-resident kernel and by the rocFFT engine: usable when one of the two serves
+    // every batch size (the streaming kernels carry a scalar only)
+    return c && ((c->resident && (c->generic || c->res_always)) || (c->generic && !c->resident)) ? 1 : 0;
 }
 
 int bdof_set_probe_stack(bdof_ctx* c, const float* stack, const float* det) {
@@ -844,7 +845,7 @@ int bdof_set_probe_stack(bdof_ctx* c, const float* stack, const float* det) {
     if (c->pdet) { (void)hipFree(c->pdet); c->pdet = nullptr; }
     if (!stack && !det) return 0;
     if (!stack || !det) return fail(c, BDOF_ERR_ARG, "bdof_set_probe_stack: both arrays or neither");
-    if (!bdof_probe_stack_supported(c)) return fail(c, BDOF_ERR_STATE, "a probe stack needs the LDS-resident engine for every batch size");
+    if (!bdof_probe_stack_supported(c)) return fail(c, BDOF_ERR_STATE, "a probe stack needs the LDS-resident or the generic-size engine for every batch size");
     const size_t fld = sizeof(cf) * (size_t)c->NX * c->NY;
     HIPC(c, hipMalloc((void**)&c->pstack, fld * (size_t)c->S));
     HIPC(c, hipMalloc((void**)&c->pdet, fld));

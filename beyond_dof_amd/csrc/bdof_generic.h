@@ -12,6 +12,7 @@ struct GModArgs {
     ObjView obj;
     int B, NX, NY, z;
     cf carrier;
+    const cf* pz;        // nullable: carrier field of the slice, [x][y] (bdof_set_probe_stack); the tape then holds the full phi
 };
 
 __device__ __forceinline__ float2 g_mod_value(const ObjView& o, int b, int x, int y, int z, int NX) {
@@ -30,9 +31,10 @@ __global__ __launch_bounds__(256) void k_g_modulate(GModArgs a) {
         const size_t r = idx / a.NY;
         const int x = r % a.NX, b = r / a.NX;
         const cf e = a.probe ? a.probe[(size_t)x * a.NY + y] : a.field[idx];
-        const cf phi = modulate_eps(e, a.carrier, g_mod_value(a.obj, b, x, y, a.z, a.NX));
+        const cf pc = a.pz ? a.pz[(size_t)x * a.NY + y] : a.carrier;
+        const cf phi = modulate_eps(e, pc, g_mod_value(a.obj, b, x, y, a.z, a.NX));
         a.field[idx] = phi;
-        if (a.tape) a.tape[idx] = phi;
+        if (a.tape) a.tape[idx] = a.pz ? cadd(phi, pc) : phi;
     }
 }
 
@@ -56,6 +58,7 @@ struct GLossArgs {
     int B, NX, NY, far;
     cf carrier;          // real detectors: added everywhere; far: added to the DC bin of every batch element
     float seed_scale;
+    const cf* pdet;      // nullable: carrier field at the detector, [x][y] / far field [kx][ky] (replaces `carrier`)
 };
 
 __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
@@ -66,7 +69,8 @@ __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
         const size_t r = idx / a.NY;
         const int x = r % a.NX, b = r / a.NX;
         cf d = a.field[idx];
-        if (!a.far || (x == 0 && y == 0)) d = cadd(d, a.carrier);
+        if (a.pdet) d = cadd(d, a.pdet[(size_t)x * a.NY + y]);
+        else if (!a.far || (x == 0 && y == 0)) d = cadd(d, a.carrier);
         const size_t oidx = a.far ? ((size_t)b * a.NY + y) * a.NX + x : idx;
         if (a.out_wave) a.out_wave[oidx] = d;
         if (a.meas) a.field[idx] = loss_seed(d, a.meas[oidx], a.seed_scale, acc, acc2);
@@ -92,6 +96,7 @@ struct GBwdArgs {
     int B, NX, NY, z;
     float k;
     cf carrier;
+    int full_tape;       // the tape holds the full phi (carrier field), not its scattered part
 };
 
 __global__ __launch_bounds__(256) void k_g_bwd(GBwdArgs a) {
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void k_g_bwd(GBwdArgs a) {
         const size_t r = idx / a.NY;
         const int x = r % a.NX, b = r / a.NX;
         const cf G = a.g[idx];
-        const cf phi = cadd(a.tape[idx], a.carrier);
+        const cf phi = a.full_tape ? a.tape[idx] : cadd(a.tape[idx], a.carrier);
         const cf t = cmulc(G, phi);
         a.grot[(((size_t)b * a.obj.S + a.z) * a.NX + x) * a.NY + y] = make_float2(a.k * t.y, -a.k * t.x);
         const float2 m1 = g_mod_value(a.obj, b, x, y, a.z, a.NX);

@@ -191,7 +191,7 @@ def test_cfg5_full_size_properties(engine_mod):
     assert np.array_equal(eng2.forward(B), 2 * exit_wave)
     sub = slice(0, 8)
     gen = _engine(engine_mod, n, 8, S, None, 'numpy_skip_last', delta[sub], beta[sub], pr, pi, 'generic')
-    assert rel(gen.forward(8), exit_wave[sub]) <= 2e-5            # the rocFFT engine carries the larger drift
+    assert rel(gen.forward(8), exit_wave[sub]) <= 1e-6            # both ride on the carrier field of the probe
 
 
 @pytest.mark.parametrize('engine', ['resident', 'generic'])
@@ -199,18 +199,18 @@ def test_cfg5_full_depth_vs_oracle(engine_mod, engine):
     """cfg5's probe size and FULL depth (72 x 72, 256 slices, gaussian probe, far field) against the float64 oracle on a few
     wavefields.  A float32 transform chain on the whole wave is limited by its own arithmetic at this depth: 2.6e-5 in
     intensity on rocFFT even with the energy drift calibrated out (3.5e-5 without; numpy's float32 FFT with an exact
-    transfer function: 1.7e-5; tools/gpu_check_depth.py).  The resident engine carries the probe's free-space propagation
-    as a float64-computed carrier FIELD (bdof_set_probe_stack) and runs only the scattered wave through float32: 1.4e-7
-    in intensity, gradients to 2e-5 — the localised-probe analogue of the plane-wave carrier."""
+    transfer function: 1.7e-5; BDOF_NO_PROBE_STACK=1 python tools/gpu_check_depth.py).  The resident and the rocFFT engine
+    carry the probe's free-space propagation as a float64-computed carrier FIELD (bdof_set_probe_stack) and run only the
+    scattered wave through float32: 1.4e-7 in intensity, gradients to 2e-5 — the localised-probe analogue of the
+    plane-wave carrier."""
     n, S, B = 72, 256, 3
     rng = np.random.default_rng(55)
     delta = rng.uniform(0, 2e-6, size=(B, n, n, S))
     beta = 0.1 * delta
     pr, pi = orc.gaussian_probe((n, n), 6., 6., 0.5)
     eng = _engine(engine_mod, n, B, S, 'inf', 'numpy_skip_last', delta, beta, pr, pi, engine)
-    assert eng.probe_stack if engine == 'resident' else (abs(eng.probe_gain - 1) < 1e-4 and eng.probe_gain != 1.0)
-    tol = dict(intensity=1e-6, energy=2e-7, loss=5e-6, grad=1e-4) if engine == 'resident' else \
-        dict(intensity=3e-5, energy=2e-6, loss=3e-4, grad=2e-3)
+    assert eng.probe_stack
+    tol = dict(intensity=1e-6, energy=2e-7, loss=5e-6, grad=1e-4)
     wave = eng.forward(B)
     ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, 'inf', delta.shape, return_probe_array=False)
     assert rel(np.abs(wave) ** 2, np.abs(ref) ** 2) <= tol['intensity']
