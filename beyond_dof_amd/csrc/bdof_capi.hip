@@ -53,7 +53,7 @@ struct bdof_ctx {
     // LDS-resident engine (small square fields, bdof_resident.h)
     bool resident = false, res_dirty = true, res_always = false;
     cf *hsT = nullptr, *hdetT = nullptr, *twR = nullptr, *res_carrier = nullptr;
-    cf *pstack = nullptr, *pdet = nullptr;      // carrier field of a localised probe (bdof_set_probe_stack)
+    cf *pstack = nullptr, *pdet = nullptr, *pdetT = nullptr;      // carrier field of a localised probe (bdof_set_probe_stack); pdetT = det transposed
     // generic-size engine (rocFFT): one plan pair per batch size
     bool generic = false;
     std::map<int, std::pair<rocfft_plan, rocfft_plan>> gplans;
@@ -287,15 +287,27 @@ static ObjView sub_obj(const bdof_ctx* c) {
 template <class T> static T* sub_field(const bdof_ctx* c, T* p) { return p ? p + (size_t)c->sub_b0 * c->NX * c->NY : p; }
 
 // A_z: L1 (or the probe) -> L2 (tstore) or L1 (plain)
+static const cf* slice_carrier_field(const bdof_ctx* c, int z) { return c->pstack ? c->pstack + (size_t)z * c->NX * c->NY : nullptr; }
+
 static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore, cf* phi_out = nullptr) {
     ProfScope ps(c, BDOF_K_ROW_FWD);
-    RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), sub_field(c, phi_out), sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY};
+    RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), sub_field(c, phi_out), sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
+                 slice_carrier_field(c, z)};
+    const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
         if (z == 0) {
-            if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, true, true>), grid, blk, 0, c->sub_stream, a);
-            else hipLaunchKernelGGL((k_row_fwd<N_, true, false>), grid, blk, 0, c->sub_stream, a);
+            if (pf) {
+                if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, true, true, true>), grid, blk, 0, c->sub_stream, a);
+                else hipLaunchKernelGGL((k_row_fwd<N_, true, false, true>), grid, blk, 0, c->sub_stream, a);
+            } else {
+                if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, true, true>), grid, blk, 0, c->sub_stream, a);
+                else hipLaunchKernelGGL((k_row_fwd<N_, true, false>), grid, blk, 0, c->sub_stream, a);
+            }
+        } else if (pf) {
+            if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, false, true, true>), grid, blk, 0, c->sub_stream, a);
+            else hipLaunchKernelGGL((k_row_fwd<N_, false, false, true>), grid, blk, 0, c->sub_stream, a);
         } else {
             if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, false, true>), grid, blk, 0, c->sub_stream, a);
             else hipLaunchKernelGGL((k_row_fwd<N_, false, false>), grid, blk, 0, c->sub_stream, a);
@@ -317,22 +329,30 @@ static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf*
 static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout, int hist = 0) {
     ProfScope ps(c, BDOF_K_ROW_BWD);
     RowBwdArgs a{sub_field(c, gin), hist == 2 ? c->probe : sub_field(c, tape), sub_field(c, gout),
-                 c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY};
+                 c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
+                 slice_carrier_field(c, z)};
+    const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
-        if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0>), grid, blk, 0, c->sub_stream, a);
-        else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1>), grid, blk, 0, c->sub_stream, a);
-        else hipLaunchKernelGGL((k_row_bwd<N_, 2>), grid, blk, 0, c->sub_stream, a);
+        if (pf) {
+            if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0, true>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1, true>), grid, blk, 0, c->sub_stream, a);
+            else hipLaunchKernelGGL((k_row_bwd<N_, 2, true>), grid, blk, 0, c->sub_stream, a);
+        } else {
+            if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1>), grid, blk, 0, c->sub_stream, a);
+            else hipLaunchKernelGGL((k_row_bwd<N_, 2>), grid, blk, 0, c->sub_stream, a);
+        }
     });
 }
 
 // Real-space detector on L1 rows.  Returns the grid (= number of partial sums when meas != null).
 static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool tstore, cf* out_wave, const float* meas,
-                            float in_scale, float out_scale, float seed_scale, cf carrier) {
+                            float in_scale, float out_scale, float seed_scale, cf carrier, const cf* pfield = nullptr) {
     ProfScope ps(c, BDOF_K_LOSS);
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NX,
-               in_scale, out_scale, seed_scale, carrier, c->twY};
+               in_scale, out_scale, seed_scale, carrier, c->twY, pfield};
     int grid = 0;
     DISPATCH_N(c->NY, {
         grid = rows_grid<N_>(c, B, c->NX);
@@ -344,10 +364,10 @@ static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool 
 
 // Far-field detector on L2 rows; the seed goes back transposed into L1.
 static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* out_wave, const float* meas, float in_scale,
-                           float out_scale, float seed_scale) {
+                           float out_scale, float seed_scale, const cf* pfield = nullptr) {
     ProfScope ps(c, BDOF_K_LOSS);
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NY,
-               in_scale, out_scale, seed_scale, carrier_det(c), c->twX};
+               in_scale, out_scale, seed_scale, carrier_det(c), c->twX, pfield};
     int grid = 0;
     DISPATCH_N(c->NX, {
         grid = rows_grid<N_>(c, B, c->NY);
@@ -568,7 +588,7 @@ template <int N> static int resident_launch(bdof_ctx* c, const ResArgs& a, int g
 // sizes without a fused plan always take it (the alternative is the unfused rocFFT engine).
 static bool use_resident(const bdof_ctx* c, int B) {
     if (!c->resident) return false;
-    return c->pstack || c->generic || c->res_always || B * 4 >= c->ncu;      // (a carrier field is never set where the streaming engine could run)
+    return c->generic || c->res_always || B * 4 >= c->ncu;
 }
 
 static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, bool do_grad) {
@@ -659,10 +679,10 @@ static void free_generic(bdof_ctx* c) {
 
 static void free_workspace(bdof_ctx* c) {
     free_generic(c);
-    void* ptrs[] = {c->pstack, c->pdet, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
+    void* ptrs[] = {c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
-    c->pstack = c->pdet = nullptr;
+    c->pstack = c->pdet = c->pdetT = nullptr;
     c->resident = false;
     c->bufC = c->conv_scal = nullptr;
     c->have_conv = false;
@@ -831,9 +851,8 @@ int bdof_set_probe(bdof_ctx* c, const float* probe, double a0_re, double a0_im) 
 }
 
 int bdof_probe_stack_supported(bdof_ctx* c) {
-    // the carrier field is implemented by the LDS-resident kernel and by the rocFFT engine: usable when one of the two serves
-    // every batch size (the streaming kernels carry a scalar only)
-    return c && ((c->resident && (c->generic || c->res_always)) || (c->generic && !c->resident)) ? 1 : 0;
+    // every engine of the transfer-function path carries it (the real-space propagator of bdof_set_conv does not)
+    return c && c->NY > 0 ? 1 : 0;
 }
 
 int bdof_set_probe_stack(bdof_ctx* c, const float* stack, const float* det) {
@@ -843,14 +862,23 @@ int bdof_set_probe_stack(bdof_ctx* c, const float* stack, const float* det) {
     HIPC(c, hipStreamSynchronize(c->stream));
     if (c->pstack) { (void)hipFree(c->pstack); c->pstack = nullptr; }
     if (c->pdet) { (void)hipFree(c->pdet); c->pdet = nullptr; }
+    if (c->pdetT) { (void)hipFree(c->pdetT); c->pdetT = nullptr; }
     if (!stack && !det) return 0;
     if (!stack || !det) return fail(c, BDOF_ERR_ARG, "bdof_set_probe_stack: both arrays or neither");
-    if (!bdof_probe_stack_supported(c)) return fail(c, BDOF_ERR_STATE, "a probe stack needs the LDS-resident or the generic-size engine for every batch size");
     const size_t fld = sizeof(cf) * (size_t)c->NX * c->NY;
     HIPC(c, hipMalloc((void**)&c->pstack, fld * (size_t)c->S));
     HIPC(c, hipMalloc((void**)&c->pdet, fld));
     HIPC(c, hipMemcpy(c->pstack, stack, fld * (size_t)c->S, hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(c->pdet, det, fld, hipMemcpyHostToDevice));
+    // the streaming far-field detector works on rows [ky][kx]: the same field transposed
+    std::vector<float> t((size_t)2 * c->NX * c->NY);
+    for (int i = 0; i < c->NX; ++i)
+        for (int j = 0; j < c->NY; ++j) {
+            t[2 * ((size_t)j * c->NX + i)] = det[2 * ((size_t)i * c->NY + j)];
+            t[2 * ((size_t)j * c->NX + i) + 1] = det[2 * ((size_t)i * c->NY + j) + 1];
+        }
+    HIPC(c, hipMalloc((void**)&c->pdetT, fld));
+    HIPC(c, hipMemcpy(c->pdetT, t.data(), fld, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -918,11 +946,11 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
     c->last_valid = false;
     if (out_wave) {
         if (c->det_mode == BDOF_DET_FAR)
-            launch_loss_far(c, B, c->bufA, nullptr, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f);
+            launch_loss_far(c, B, c->bufA, nullptr, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f, c->pdetT);
         else if (c->det_mode == BDOF_DET_NONE && !tf_all)
-            launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out_wave, nullptr, 1.f / c->NY, 1.f, 0.f, carrier_det(c));
+            launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out_wave, nullptr, 1.f / c->NY, 1.f, 0.f, carrier_det(c), c->pdet);
         else
-            launch_loss_real(c, B, c->bufB, nullptr, false, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f, carrier_det(c));
+            launch_loss_real(c, B, c->bufB, nullptr, false, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f, carrier_det(c), c->pdet);
     }
     if (keep_tape && !tf_all) {
         // probe_array[S-1] = phi_{S-1} (np_funcs.py:41-43): keep R phi_{S-1} in L1 order in bufA
@@ -945,11 +973,13 @@ int bdof_tape_to_real(bdof_ctx* c, int i, int B, void* out) {
     if (i < 0 || i >= c->S) return fail(c, BDOF_ERR_ARG, "slice index outside [0, S)");
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     if (i < c->S - 1) {
-        launch_loss_real(c, B, c->tape + (size_t)i * fld, nullptr, false, (cf*)out, nullptr, 1.f, 1.f, 0.f, carrier_at(c, i + 1));
+        launch_loss_real(c, B, c->tape + (size_t)i * fld, nullptr, false, (cf*)out, nullptr, 1.f, 1.f, 0.f, carrier_at(c, i + 1),
+                         slice_carrier_field(c, i + 1));
     } else {
         if (!c->last_valid)
             return fail(c, BDOF_ERR_STATE, "the last slice's wave is only kept after bdof_forward(keep_tape=1) with the numpy_skip_last variant");
-        launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out, nullptr, 1.f / c->NY, 1.f, 0.f, carrier_at(c, c->S - 1));
+        launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out, nullptr, 1.f / c->NY, 1.f, 0.f, carrier_at(c, c->S - 1),
+                         slice_carrier_field(c, c->S - 1));
     }
     HIPC(c, hipGetLastError());
     return 0;
@@ -995,13 +1025,13 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
         const int Bg = groups[gi].B;
         use_group(c, groups[gi], npart);
         if (c->det_mode == BDOF_DET_FAR) {
-            npart += launch_loss_far(c, Bg, c->bufA, c->bufB, (cf*)out_wave, meas, 1.f, 1.f, seed_scale);
+            npart += launch_loss_far(c, Bg, c->bufA, c->bufB, (cf*)out_wave, meas, 1.f, 1.f, seed_scale, c->pdetT);
         } else if (c->det_mode == BDOF_DET_NONE && !tf_all) {
-            npart += launch_loss_real(c, Bg, c->bufA, c->bufB, false, (cf*)out_wave, meas, 1.f / NYf, 1.f / NYf, seed_scale, carrier_det(c));
+            npart += launch_loss_real(c, Bg, c->bufA, c->bufB, false, (cf*)out_wave, meas, 1.f / NYf, 1.f / NYf, seed_scale, carrier_det(c), c->pdet);
         } else {
             // the detector wave came out of a transfer-function step: seed -> R (transposed) -> adjoint step
             const cf* h = c->det_mode == BDOF_DET_NONE ? c->hs : (tf_all ? c->hcomb : c->hdet);
-            npart += launch_loss_real(c, Bg, c->bufB, c->bufA, true, (cf*)out_wave, meas, 1.f, 1.f, seed_scale, carrier_det(c));
+            npart += launch_loss_real(c, Bg, c->bufB, c->bufA, true, (cf*)out_wave, meas, 1.f, 1.f, seed_scale, carrier_det(c), c->pdet);
             launch_row_prop(c, Bg, c->bufA, c->bufB, h, 1.f, 1);
         }
     }

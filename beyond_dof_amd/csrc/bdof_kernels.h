@@ -169,9 +169,11 @@ struct RowFwdArgs {
     float k;
     cf carrier;        // a_z: constant part of the wave entering slice z
     const cf* twiddle;
+    const cf* pz;      // PF kernels: carrier FIELD of slice z, [NX][NY] (bdof_set_probe_stack); replaces `carrier`
 };
 
-template <int NY, bool FIRST, bool TSTORE>
+// PF: the carrier is a field (localised probe), one more coalesced 8-B read per pixel; the plane-wave instances are untouched
+template <int NY, bool FIRST, bool TSTORE, bool PF = false>
 __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd(RowFwdArgs a) {
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
@@ -196,9 +198,18 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
 #pragma unroll
             for (int m = 0; m < 8; ++m) u[m] = src[tid + m * C::T];
             load_obj_row(a.obj, obj_src_row(a.obj, b, x, a.z, a.NX), y0, tid, C::T, db);
-            if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
+            if constexpr (PF) {
+                cf pc[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], a.carrier, db[m]);
+                for (int m = 0; m < 8; ++m) pc[m] = a.pz[(size_t)x * NY + tid + m * C::T];
+                if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], pc[m], db[m]);
+            } else {
+                if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], a.carrier, db[m]);
+            }
             if (a.phi_out) {
                 cf* pdst = a.phi_out + (size_t)(row0 + r) * NY;
 #pragma unroll
@@ -315,6 +326,8 @@ struct LossArgs {
     float in_scale, out_scale, seed_scale;
     cf carrier;          // constant part of the detector wave (far field: its DC bin value a*NX*NY)
     const cf* twiddle;
+    const cf* pfield;    // nullable: carrier field at this plane in the row layout of `in` ([R][N], the same for every batch
+                         // element); replaces `carrier`
 };
 
 __device__ __forceinline__ cf loss_seed(cf d, float m, float seed_scale, double& acc, double& acc2) {
@@ -358,7 +371,11 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
             line_fft<N, S1>(u, tw, tid, lds);
 #pragma unroll
             for (int m = 0; m < 8; ++m) u[m] = cscale(u[m], a.in_scale);
-            if constexpr (FAR) {
+            if (a.pfield) {
+                const cf* pf = a.pfield + (size_t)(r0 + r) * N;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) u[m] = cadd(u[m], pf[tid + m * C::T]);
+            } else if constexpr (FAR) {
                 if (r0 + r == 0 && tid == 0) u[0] = cadd(u[0], a.carrier);       // DC bin of the un-shifted fft2
             } else {
 #pragma unroll
@@ -418,13 +435,14 @@ struct RowBwdArgs {
     float k;
     cf carrier;        // constant part of phi_z (= a_z: the modulation moves no weight into it)
     const cf* twiddle;
+    const cf* pz;      // PF kernels: carrier field of slice z, [NX][NY]
 };
 
 // HIST = 0: phi_z (scattered part) is read from the tape A_z wrote.  HIST = 1: the tape holds the per-slice history
 // psi_hat_z (the INPUT of A_z, written by the transfer-function kernel anyway) and phi_z is recomputed here with A_z's own
 // operations (inverse transform, modulation) — one more transform per launch, 8 B per pixel less traffic in A.
 // HIST = 2: slice 0 of that mode, phi_0 from the probe (no transform).
-template <int NY, int HIST>
+template <int NY, int HIST, bool PF = false>
 __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd(RowBwdArgs a) {
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
@@ -452,16 +470,21 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
 #pragma unroll
             for (int m = 0; m < 8; ++m) p[m] = psrc[tid + m * C::T];
             load_obj_row(a.obj, obj_src_row(a.obj, b, x, a.z, a.NX), y0, tid, C::T, db);
+            cf pc[PF ? 8 : 1];
+            if constexpr (PF) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) pc[m] = a.pz[(size_t)x * NY + tid + m * C::T];
+            }
             if constexpr (HIST == 1) line_fft<NY, +1>(p, tw, tid, lds);                // psi_hat_z -> psi_z (scattered part)
             if constexpr (HIST != 0) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) p[m] = modulate_eps(p[m], a.carrier, db[m]);
+                for (int m = 0; m < 8; ++m) p[m] = modulate_eps(p[m], PF ? pc[m] : a.carrier, db[m]);
             }
             line_fft<NY, +1>(g, tw, tid, lds);
             float2* gdst = a.grot + (((size_t)b * a.obj.S + a.z) * a.NX + x) * NY;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const cf phi = cadd(p[m], a.carrier);
+                const cf phi = cadd(p[m], PF ? pc[m] : a.carrier);
                 const cf t = cmulc(g[m], phi);                       // G * conj(phi)
                 gdst[tid + m * C::T] = make_float2(a.k * t.y, -a.k * t.x);
                 g[m] = cmulc(g[m], make_float2(1.f + db[m].x, db[m].y));    // conj(c) G,  c = 1 + (c - 1)

@@ -151,6 +151,8 @@ class MultisliceEngine(object):
         gain = 1.0
         self.probe_stack = False
         use_stack = (a0 == 0 and hasattr(self, '_physics_args') and not os.environ.get('BDOF_NO_PROBE_STACK')
+                     and not getattr(self, '_conv_set', False)              # the real-space propagator has its own carrier
+                     and self.n_slice * self.nx * self.ny <= (1 << 28)      # 2 GiB of stack at most
                      and self.lib.bdof_probe_stack_supported(self.h) == 1)
         if use_stack:
             stack, det = self._probe_stack(probe)
@@ -176,6 +178,7 @@ class MultisliceEngine(object):
         delta_nm = voxel_nm[-1]
         ky, kx, e = util.conv_kernel_separable(delta_nm, lmbda_nm, voxel_nm, (self.ny, self.nx), kernel_size)
         ksum = e * ky.sum() * kx.sum()
+        self._conv_set = True
         k = 2. * np.pi * delta_nm / lmbda_nm
         kyf = np.ascontiguousarray(ky.astype(np.complex64))
         kxf = np.ascontiguousarray(kx.astype(np.complex64))

@@ -65,15 +65,15 @@ int bdof_set_physics(bdof_ctx* ctx, double k, const float* hs, const float* hs_d
  * only eps through the float32 FFTs, so round-off scales with the scattered field, not with the full wave. */
 int bdof_set_probe(bdof_ctx* ctx, const float* probe_eps, double a0_re, double a0_im);
 
-/* Carrier FIELD for a localised probe (LDS-resident and generic-size engines).  stack: HOST array [S][NX][NY] complex, the probe propagated
+/* Carrier FIELD for a localised probe (all three engines of the transfer-function path).  stack: HOST array [S][NX][NY] complex, the probe propagated
  * through free space to the entrance of every slice, p_0 = probe, p_{z+1} = ifft2(ifftshift(fftshift(fft2 p_z) H))
  * (np_funcs.py:42 without an object), computed by the host in float64; det: HOST [NX][NY], the same wave at the detector
  * (no detector: p_{S-1}, or p_S with the tf_all variant; near field: one more step with the detector kernel; far field:
  * the un-shifted, un-normalised fft2 of it, indexed [kx][ky]).  The wave is then carried as psi_z = p_z + eps_z and only
  * the scattered part eps runs through the float32 transforms, whose round-off therefore scales with the scattered field —
  * what the scalar a0 of bdof_set_probe does for a plane wave.  Call bdof_set_probe with a zero array (eps_0 = 0, a0 = 0).
- * NULL, NULL removes the stack.  bdof_probe_stack_supported: 1 when the configured size runs on one of those two engines for
- * every batch size (any size without a streaming plan, or a resident size with with_grad bit 3). */
+ * NULL, NULL removes the stack.  bdof_probe_stack_supported: 1 once bdof_configure has run (the real-space propagator of
+ * bdof_set_conv does not use the stack). */
 int bdof_probe_stack_supported(bdof_ctx* ctx);
 int bdof_set_probe_stack(bdof_ctx* ctx, const float* stack, const float* det);
 

@@ -20,7 +20,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize('fp', [None, 1e-4])
-def test_c_host_drives_the_library(tmp_path, fp):
+def test_c_host_drives_the_library(tmp_path, fp, monkeypatch):
     import __graft_entry__ as entry
     entry.build()
     from beyond_dof_amd import util
@@ -73,8 +73,10 @@ def test_c_host_drives_the_library(tmp_path, fp):
     grad_c = util.rows_to_batch(np.frombuffer(raw[8 + nw:], dtype=np.float32).reshape(B, S, X, Y, 2))
 
     # the Python host on the same library
+    # the C driver hands the probe over as it is: no carrier field, no energy calibration (engine.py: set_probe)
+    monkeypatch.setenv('BDOF_NO_PROBE_STACK', '1')
     eng = MultisliceEngine(Y, X, S, B, with_grad=True)
-    eng.calibrate_energy = False            # the C driver hands the probe over as it is (engine.py: _free_space_gain)
+    eng.calibrate_energy = False
     eng.set_physics(5000., 1e-7, fp)
     eng.set_probe(pr, pi)
     eng.set_object_batch(delta, beta)

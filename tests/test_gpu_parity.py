@@ -389,3 +389,38 @@ def test_cfg2_full_size_fullfield_step_vs_oracle(engine_mod):
                                                with_reg=False)
     assert abs(loss - rl) <= 1e-6 * rl
     assert rel(gd, rgd) <= 1e-4 and rel(gb, rgb) <= 1e-4
+
+
+@pytest.mark.parametrize('fp,variant', [(None, 'numpy_skip_last'), (1e-4, 'tf_all'), ('inf', 'numpy_skip_last'), ('inf', 'tf_all')])
+def test_streaming_carrier_field(engine_mod, fp, variant, monkeypatch):
+    """A localised probe on the streaming kernels rides on its float64 free-space propagation (bdof_set_probe_stack): waves,
+    loss, gradient and the per-slice history against the oracle, non-square field, 40 slices — and the same run without
+    the carrier field, which must be at least ten times further away."""
+    B, Y, X, S = 2, 64, 128, 40
+    rng = np.random.default_rng(4)
+    delta = rng.uniform(0, 2e-6, size=(B, Y, X, S))
+    beta = 0.1 * delta
+    pr, pi = orc.gaussian_probe((Y, X), Y / 10., X / 10., 0.5)
+    ref, pa = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, fp, delta.shape, variant=variant)
+    meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, fp, variant)
+    err = {}
+    for stack in (True, False):
+        if not stack:
+            monkeypatch.setenv('BDOF_NO_PROBE_STACK', '1')
+        eng = engine_mod.MultisliceEngine(Y, X, S, B, with_grad=True, engine='streaming')
+        eng.set_physics(5000., 1e-7, fp, variant=variant)
+        eng.set_probe(pr, pi)
+        eng.set_object_batch(delta, beta)
+        assert eng.probe_stack == stack
+        wave = eng.forward(B)
+        loss = eng.loss_grad(B, meas)
+        gd, gb = eng.grad_batch_to_host(B)
+        err[stack] = rel(wave, ref)
+        if stack:
+            assert err[True] <= 1.5e-7 and abs(loss - rl) <= 1e-6 * abs(rl)
+            assert rel(gd, rgd) <= 1e-5 and rel(gb, rgb) <= 1e-5
+            if variant == 'numpy_skip_last':
+                eng.forward(B, keep_tape=True)
+                assert rel(eng.probe_array(B), pa) <= 1.5e-7
+    assert err[False] <= 1e-5 and err[True] * 10 <= err[False]
