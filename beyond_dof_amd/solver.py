@@ -231,9 +231,8 @@ class PtychoSolver(object):
         self.comm = comm or PseudoComm()
         self.probe_pos = np.asarray(probe_pos).astype(int)
         self.half = (np.array(probe_size) / 2).astype('int')            # ptychography.py:138
-        # a localised probe rides on its float64 free-space propagation (carrier field, engine.set_probe) on the LDS-resident
-        # engine: whenever the probe size has a resident plan that engine is pinned for every batch size, also where the
-        # streaming kernels would be faster for a small batch (64^2 / 128^2) — 1e-7 instead of 1e-5 against the reference
+        # small square probes: the LDS-resident engine (one launch per minibatch) also for the minibatches of ~20 positions the
+        # drivers use, where the automatic choice would take the launch-bound streaming kernels for 64^2 / 128^2
         from .engine import RESIDENT_SIZES
         pin = 'resident' if (self.py == self.px and self.py in RESIDENT_SIZES and not self.conv
                              and not os.environ.get('BDOF_NO_RESIDENT_PIN')) else 'auto'
