@@ -80,6 +80,8 @@ class MultisliceEngine(object):
         self.ctx.check(self.lib.bdof_set_physics(self.h, k, hs.ctypes.data, hdet.ctypes.data if hdet is not None else None,
                                                  h00.ctypes.data, hdet00.ctypes.data if hdet00 is not None else None,
                                                  det, _VARIANT[variant]))
+        if getattr(self, '_probe_args', None) is not None:
+            self.set_probe(*self._probe_args)      # the carrier (field, calibration) of the probe depends on the physics
 
     def _free_space_gain(self, probe_c64):
         """Amplitude factor that undoes the energy drift of THIS probe through THIS stack in free space.  |H| = 1, so in
@@ -139,6 +141,7 @@ class MultisliceEngine(object):
         return np.ascontiguousarray(stack), np.ascontiguousarray(det.T.astype(np.complex64))
 
     def set_probe(self, probe_real, probe_imag):
+        self._probe_args = (np.array(probe_real, copy=True), np.array(probe_imag, copy=True))
         probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.ny, self.nx))
         probe = probe.astype(np.complex64)                         # the reference rounds to complex64 too (np_funcs.py:20)
         # Carrier splitting: the wave is held as carrier + eps and only eps runs through the float32 transforms.

@@ -253,3 +253,17 @@ def test_probe_stack_all_detectors(engine_mod, fp, variant):
     assert errs[True][0] <= 2e-7 and errs[True][1] <= 2e-6 and errs[True][2] <= 5e-5 and errs[True][3] <= 5e-5
     assert errs[False][0] <= 1e-5
     assert errs[True][0] * 10 <= errs[False][0]
+
+
+def test_physics_change_refreshes_the_probe_carrier(engine_mod):
+    """The carrier field belongs to (probe, physics): changing the detector after set_probe must rebuild it."""
+    n, S, B = 72, 24, 2
+    rng, delta, beta, pr, pi = _inputs(n, B, S, 'inf', 3)
+    eng = engine_mod.MultisliceEngine(n, n, S, B, with_grad=False)
+    eng.set_physics(5000., 1e-7, None)
+    eng.set_probe(pr, pi)
+    eng.set_object_batch(delta, beta)
+    for fp in (1e-4, 'inf', None):
+        eng.set_physics(5000., 1e-7, fp)
+        ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, fp, delta.shape, return_probe_array=False)
+        assert eng.probe_stack and rel(eng.forward(B), ref) <= 2e-7
