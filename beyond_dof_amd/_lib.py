@@ -29,6 +29,7 @@ _SIGNATURES = {
     'bdof_configure': (ctypes.c_int, [_vp] + [ctypes.c_int] * 5),
     'bdof_set_physics': (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     'bdof_set_probe': (ctypes.c_int, [_vp, _vp, ctypes.c_double, ctypes.c_double]),
+    'bdof_set_meas_mode': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_probe_stack_supported': (ctypes.c_int, [_vp]),
     'bdof_set_probe_stack': (ctypes.c_int, [_vp, _vp, _vp]),
     'bdof_set_object': (ctypes.c_int, [_vp, _vp, ctypes.c_longlong, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int]),

@@ -53,6 +53,7 @@ struct bdof_ctx {
     // LDS-resident engine (small square fields, bdof_resident.h)
     bool resident = false, res_dirty = true, res_always = false;
     cf *hsT = nullptr, *hdetT = nullptr, *twR = nullptr, *res_carrier = nullptr;
+    int meas_dev = 0;                           // bdof_set_meas_mode
     cf *pstack = nullptr, *pdet = nullptr, *pdetT = nullptr;      // carrier field of a localised probe (bdof_set_probe_stack); pdetT = det transposed
     // generic-size engine (rocFFT): one plan pair per batch size
     bool generic = false;
@@ -352,7 +353,7 @@ static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool 
                             float in_scale, float out_scale, float seed_scale, cf carrier, const cf* pfield = nullptr) {
     ProfScope ps(c, BDOF_K_LOSS);
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NX,
-               in_scale, out_scale, seed_scale, carrier, c->twY, pfield};
+               in_scale, out_scale, seed_scale, carrier, c->twY, pfield, c->meas_dev};
     int grid = 0;
     DISPATCH_N(c->NY, {
         grid = rows_grid<N_>(c, B, c->NX);
@@ -367,7 +368,7 @@ static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* ou
                            float out_scale, float seed_scale, const cf* pfield = nullptr) {
     ProfScope ps(c, BDOF_K_LOSS);
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NY,
-               in_scale, out_scale, seed_scale, carrier_det(c), c->twX, pfield};
+               in_scale, out_scale, seed_scale, carrier_det(c), c->twX, pfield, 0};
     int grid = 0;
     DISPATCH_N(c->NX, {
         grid = rows_grid<N_>(c, B, c->NY);
@@ -528,7 +529,7 @@ static int generic_forward(bdof_ctx* c, int B, void* out_wave, bool keep_tape) {
     if (out_wave) {
         const size_t n = (size_t)B * c->NX * c->NY;
         GLossArgs la{c->bufA, (cf*)out_wave, nullptr, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
-                     make_float2((float)a.real(), (float)a.imag()), 0.f, c->pdet};
+                     make_float2((float)a.real(), (float)a.imag()), 0.f, c->pdet, 0};
         hipLaunchKernelGGL(k_g_loss, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, la);
     }
     return 0;
@@ -547,7 +548,7 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
     {
         ProfScope ps(c, BDOF_K_LOSS);
         GLossArgs la{c->bufA, (cf*)out_wave, meas, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
-                     make_float2((float)a.real(), (float)a.imag()), 2.f / ((float)B * (float)c->NX * (float)c->NY), c->pdet};
+                     make_float2((float)a.real(), (float)a.imag()), 2.f / ((float)B * (float)c->NX * (float)c->NY), c->pdet, c->meas_dev};
         hipLaunchKernelGGL(k_g_loss, dim3(egrid), dim3(256), 0, c->stream, la);
     }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, egrid, 1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
@@ -603,7 +604,7 @@ static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, b
     const bool grad = do_grad && meas;
     ResArgs a{c->probe, c->hsT, c->hdetT, grad ? c->tape : nullptr, (size_t)c->Bmax * c->NX * c->NY, c->grot, c->obj, c->res_carrier,
               carrier_det(c), c->pstack, c->pdet, meas, (cf*)out_wave, c->partial, c->twR, B, c->S, c->det_mode,
-              c->variant == BDOF_VARIANT_TF_ALL ? 1 : 0, grad ? 1 : 0, c->k, 2.f / ((float)B * (float)c->NX * (float)c->NY)};
+              c->variant == BDOF_VARIANT_TF_ALL ? 1 : 0, grad ? 1 : 0, c->k, 2.f / ((float)B * (float)c->NX * (float)c->NY), c->meas_dev};
     const int grid = B < c->npartial ? B : c->npartial;
     int r = 0;
     switch (c->NX) {
@@ -850,6 +851,13 @@ int bdof_set_probe(bdof_ctx* c, const float* probe, double a0_re, double a0_im) 
     return 0;
 }
 
+int bdof_set_meas_mode(bdof_ctx* c, int mode) {
+    if (!c) return BDOF_ERR_ARG;
+    if (mode != 0 && mode != 1) return fail(c, BDOF_ERR_ARG, "bdof_set_meas_mode: mode must be 0 or 1");
+    c->meas_dev = mode;
+    return 0;
+}
+
 int bdof_probe_stack_supported(bdof_ctx* c) {
     // every engine of the transfer-function path carries it (the real-space propagator of bdof_set_conv does not)
     return c && c->NY > 0 ? 1 : 0;
@@ -989,6 +997,8 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     int r = check_ready(c, B);
     if (r) return r;
     if (!meas) return BDOF_ERR_ARG;
+    if (c->meas_dev && (c->det_mode == BDOF_DET_FAR || c->pstack))
+        return fail(c, BDOF_ERR_STATE, "bdof_set_meas_mode(1) needs a real-space detector and a scalar carrier");
     if (!c->with_grad) return fail(c, BDOF_ERR_STATE, "bdof_loss_grad needs bdof_configure(with_grad=1)");
     if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
     HIPC(c, hipSetDevice(c->device));
@@ -1200,6 +1210,7 @@ int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xo
     int r = conv_check(c, B, angle_of_b);
     if (r) return r;
     if (!meas) return BDOF_ERR_ARG;
+    if (c->meas_dev) return fail(c, BDOF_ERR_STATE, "bdof_set_meas_mode(1) applies to the transfer-function path only");
     if (!c->with_grad) return fail(c, BDOF_ERR_STATE, "bdof_loss_grad_conv needs bdof_configure(with_grad=1)");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);

@@ -59,6 +59,7 @@ struct GLossArgs {
     cf carrier;          // real detectors: added everywhere; far: added to the DC bin of every batch element
     float seed_scale;
     const cf* pdet;      // nullable: carrier field at the detector, [x][y] / far field [kx][ky] (replaces `carrier`)
+    int meas_dev;        // `meas` holds m - |carrier| (loss_seed_dev, bdof_kernels.h)
 };
 
 __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
@@ -69,6 +70,13 @@ __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
         const size_t r = idx / a.NY;
         const int x = r % a.NX, b = r / a.NX;
         cf d = a.field[idx];
+        if (a.meas_dev && a.meas && !a.far && !a.pdet) {
+            const size_t oidx = idx;
+            if (a.out_wave) a.out_wave[oidx] = cadd(d, a.carrier);
+            a.field[idx] = loss_seed_dev(d, a.carrier, sqrtf(a.carrier.x * a.carrier.x + a.carrier.y * a.carrier.y), a.meas[oidx],
+                                         a.seed_scale, acc, acc2);
+            continue;
+        }
         if (a.pdet) d = cadd(d, a.pdet[(size_t)x * a.NY + y]);
         else if (!a.far || (x == 0 && y == 0)) d = cadd(d, a.carrier);
         const size_t oidx = a.far ? ((size_t)b * a.NY + y) * a.NX + x : idx;

@@ -328,6 +328,7 @@ struct LossArgs {
     const cf* twiddle;
     const cf* pfield;    // nullable: carrier field at this plane in the row layout of `in` ([R][N], the same for every batch
                          // element); replaces `carrier`
+    int meas_dev;        // `meas` holds m - |carrier| (loss_seed_dev); real-space detectors with a scalar carrier only
 };
 
 __device__ __forceinline__ cf loss_seed(cf d, float m, float seed_scale, double& acc, double& acc2) {
@@ -336,6 +337,22 @@ __device__ __forceinline__ cf loss_seed(cf d, float m, float seed_scale, double&
     acc += (double)r * (double)r;
     acc2 += (double)r * (double)a;
     const float f = a > 0.f ? seed_scale * r / a : 0.f;
+    return make_float2(d.x * f, d.y * f);
+}
+
+// Residual splitting at the detector (bdof_set_meas_mode 1): with the wave held as d = a + e (a the plane-wave part, known
+// exactly) the residual |d| - m is the difference of two float32 numbers of size one and carries 7e-8 of absolute error,
+// i.e. 3e-6 of a 2 % residual.  |a + e| - |a| = (2 Re(conj(a) e) + |e|^2) / (|a + e| + |a|) has no cancellation, and the host
+// hands the measurement over as mdev = m - |a| (float64 subtraction, then float32): r = (|d| - |a|) - mdev is as accurate
+// as the scattered wave e itself.
+__device__ __forceinline__ cf loss_seed_dev(cf e, cf a, float abs_a, float mdev, float seed_scale, double& acc, double& acc2) {
+    const cf d = cadd(a, e);
+    const float ab = sqrtf(d.x * d.x + d.y * d.y);
+    const float q = fmaf(2.f * a.x, e.x, fmaf(2.f * a.y, e.y, fmaf(e.x, e.x, e.y * e.y)));
+    const float r = q / (ab + abs_a) - mdev;
+    acc += (double)r * (double)r;
+    acc2 += (double)r * (double)ab;
+    const float f = ab > 0.f ? seed_scale * r / ab : 0.f;
     return make_float2(d.x * f, d.y * f);
 }
 
@@ -371,23 +388,35 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
             line_fft<N, S1>(u, tw, tid, lds);
 #pragma unroll
             for (int m = 0; m < 8; ++m) u[m] = cscale(u[m], a.in_scale);
-            if (a.pfield) {
-                const cf* pf = a.pfield + (size_t)(r0 + r) * N;
+            const bool dev = !FAR && a.meas_dev && a.meas && !a.pfield;
+            if (dev) {
+                // u is still the scattered part: the seed comes from (e, a) directly, the detector wave is a + e
+                const float abs_a = sqrtf(a.carrier.x * a.carrier.x + a.carrier.y * a.carrier.y);
+                if (a.out_wave) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) u[m] = cadd(u[m], pf[tid + m * C::T]);
-            } else if constexpr (FAR) {
-                if (r0 + r == 0 && tid == 0) u[0] = cadd(u[0], a.carrier);       // DC bin of the un-shifted fft2
+                    for (int m = 0; m < 8; ++m) a.out_wave[off + tid + m * C::T] = cadd(u[m], a.carrier);
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) u[m] = loss_seed_dev(u[m], a.carrier, abs_a, mm[m], a.seed_scale, acc, acc2);
             } else {
+                if (a.pfield) {
+                    const cf* pf = a.pfield + (size_t)(r0 + r) * N;
 #pragma unroll
-                for (int m = 0; m < 8; ++m) u[m] = cadd(u[m], a.carrier);
-            }
-            if (a.out_wave) {
+                    for (int m = 0; m < 8; ++m) u[m] = cadd(u[m], pf[tid + m * C::T]);
+                } else if constexpr (FAR) {
+                    if (r0 + r == 0 && tid == 0) u[0] = cadd(u[0], a.carrier);       // DC bin of the un-shifted fft2
+                } else {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) a.out_wave[off + tid + m * C::T] = u[m];
-            }
-            if (a.meas) {
+                    for (int m = 0; m < 8; ++m) u[m] = cadd(u[m], a.carrier);
+                }
+                if (a.out_wave) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) u[m] = loss_seed(u[m], mm[m], a.seed_scale, acc, acc2);
+                    for (int m = 0; m < 8; ++m) a.out_wave[off + tid + m * C::T] = u[m];
+                }
+                if (a.meas) {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) u[m] = loss_seed(u[m], mm[m], a.seed_scale, acc, acc2);
+                }
             }
             if (a.out_hyb) {
                 if constexpr (TSTORE) {

@@ -289,6 +289,7 @@ struct ResArgs {
     const cf* twiddle;     // [N] exp(-2 pi i k / N)
     int B, S, det_mode, tf_all, do_grad;
     float k, seed_scale;
+    int meas_dev;          // `meas` holds m - |carrier_det| (loss_seed_dev, bdof_kernels.h)
 };
 
 // transfer-function multiply folded into the last pass of the forward transform: the thread writing element (kx, ky)
@@ -553,6 +554,13 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
         for (int e = tid; e < N * N; e += T) {
             const int x = e / N, y = e - x * N;
             cf d = f[x * P + y];
+            if (a.meas_dev && a.meas && !far && !a.pdet) {
+                const size_t o = b * fsz + e;
+                if (a.out_wave) a.out_wave[o] = cadd(d, a.carrier_det);
+                f[x * P + y] = loss_seed_dev(d, a.carrier_det, sqrtf(a.carrier_det.x * a.carrier_det.x + a.carrier_det.y * a.carrier_det.y),
+                                             a.meas[o], a.seed_scale, acc, acc2);
+                continue;
+            }
             if (a.pdet) d = cadd(d, a.pdet[e]);
             else if (!far || e == 0) d = cadd(d, a.carrier_det);
             const size_t o = b * fsz + (far ? y * N + x : e);

@@ -163,6 +163,7 @@ class MultisliceEngine(object):
             self.ctx.check(self.lib.bdof_set_probe(self.h, zero.ctypes.data, 0.0, 0.0))
             self.ctx.check(self.lib.bdof_set_probe_stack(self.h, stack.ctypes.data, det.ctypes.data))
             self.probe_stack, self.probe_gain = True, 1.0
+            self._set_meas_mode(0j)
             return
         if self.lib.bdof_probe_stack_supported(self.h) == 1:
             self.ctx.check(self.lib.bdof_set_probe_stack(self.h, None, None))
@@ -172,6 +173,16 @@ class MultisliceEngine(object):
         self.probe_gain = gain
         eps = np.ascontiguousarray(((probe.astype(np.complex128) - a0) * gain).T.astype(np.complex64))
         self.ctx.check(self.lib.bdof_set_probe(self.h, eps.ctypes.data, a0.real, a0.imag))
+        self._set_meas_mode(a0)
+
+    def _set_meas_mode(self, a0):
+        """Residual splitting at the detector (include/bdof.h, bdof_set_meas_mode): with a plane-wave carrier and a real-space
+        detector the measured amplitudes go to the device as m - |a0|."""
+        self.meas_ref = 0.0
+        if (a0 != 0 and self.det_mode != _lib.DET_FAR and not getattr(self, '_conv_set', False)
+                and not os.environ.get('BDOF_NO_RESIDUAL_SPLIT')):
+            self.meas_ref = abs(a0)
+        self.ctx.check(self.lib.bdof_set_meas_mode(self.h, 1 if self.meas_ref else 0))
 
     def set_conv(self, energy_ev, psize_cm, kernel_size=17):
         """Switch the slice-to-slice step to the truncated real-space kernel of multislice_propagate_cnn
@@ -220,7 +231,11 @@ class MultisliceEngine(object):
 
     def meas_layout(self, meas_abs):
         """|measured| (n, Y, X) in the index order libbdof's loss kernels read it."""
-        m = np.asarray(meas_abs, dtype=np.float32)
+        ref = getattr(self, 'meas_ref', 0.0)
+        if ref:
+            m = (np.asarray(meas_abs, dtype=np.float64) - ref).astype(np.float32)      # subtract in float64, round once
+        else:
+            m = np.asarray(meas_abs, dtype=np.float32)
         if self.det_mode == _lib.DET_FAR:
             return np.ascontiguousarray(np.fft.ifftshift(m, axes=(1, 2)))
         return np.ascontiguousarray(m.transpose(0, 2, 1))

@@ -106,6 +106,12 @@ int bdof_tape_to_real(bdof_ctx* ctx, int i, int B, void* out);
  * windowed (delta,beta) is left in the ctx (bdof_grot). out_wave may be NULL. */
 int bdof_loss_grad(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, void* out_wave);
 int bdof_get_loss(bdof_ctx* ctx, double* loss);
+/* mode 1: the `meas` arrays of bdof_loss_grad hold |measured| - |a0| instead of |measured| (a0: the plane-wave part handed
+ * to bdof_set_probe; every transfer-function step has unit modulus at DC, so |a0| is the carrier's modulus at the detector
+ * too).  The residual is then formed as (|a + e| - |a|) - (m - |a|) with |a + e| - |a| evaluated without cancellation —
+ * three times more accurate gradients for plane-wave illumination.  Real-space detectors (none / near) and a scalar carrier
+ * only; mode 0 (default): plain amplitudes. */
+int bdof_set_meas_mode(bdof_ctx* ctx, int mode);
 
 /* Real-space truncated-kernel propagator: replaces multislice_propagate_cnn (cnn_propagator/propagation.py:18-133), the
  * forward model cnn_propagator/fullfield.py:87,102 and ptychography.py:74 literally call.  The cropped kernel is separable,
