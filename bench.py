@@ -1,17 +1,26 @@
 #!/usr/bin/env python
 """bench.py — Adam iterations of the full-field multislice reconstruction on synthetic data.
 
-One "step" = one Adam iteration of cnn_propagator/fullfield.py:340-362 on this rank's minibatch of
-projection angles: fused rotation + multislice forward, magnitude loss, hand-derived adjoint, rotation
-adjoint, (RCCL all-reduce of the volume gradient when N > 1), fused regulariser + Adam + mask + clip.
-Workload (BASELINE.json configs[2] per GPU, weak scaling): 512^3 charcoal-like random (delta, beta)
-volume, 25 angles per GPU per step, 5 keV, 1 nm voxels, free_prop_cm = 1e-4.
+One "step" = one Adam iteration of cnn_propagator/fullfield.py:340-362 on this rank's minibatch of projection angles:
+fused rotation + multislice forward, magnitude loss, hand-derived adjoint, rotation adjoint, gradient exchange across
+ranks (RCCL reduce-scatter -> Adam on 1/N -> all-gather when N > 1), fused regulariser + Adam + mask + clip — the same
+`FullfieldSolver.step` the entry point `reconstruct_fullfield` runs.
+Workload (BASELINE.json configs[2] per GPU, weak scaling): 512^3 charcoal-like random (delta, beta) volume, 25 angles per
+GPU per step, 5 keV, 1 nm voxels, free_prop_cm = 1e-4.
 
-Prints ONE JSON line (rank 0).  value = slice-steps/s = n_gpus * angles_per_gpu * slices * steps / time.
+`python bench.py --gpus N` starts N ranks by itself (one process per GPU; this parent never touches a GPU) unless it is
+already running as one rank of a launcher (`python -m torch.distributed.run ... bench.py --gpus N`: RANK / WORLD_SIZE set).
+Rank 0 prints ONE JSON line.  value = slice-steps/s = n_gpus * angles_per_gpu * slices * steps / time.
+
+The roofline leg is a separate pass after the timed region: one step with the sub-batch streams off and a HIP-event pair
+around EVERY launch, so that a launch is the whole minibatch and `bytes / duration` needs no assumption about what else
+shares the chip; the matching rocprofv3 summary is profiles/<round>_kernel_stats_1stream.csv (same command with
+BDOF_STREAMS=1).  The timed region itself runs the production configuration (two sub-batch streams).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -20,33 +29,37 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic bytes per pixel per launch (DESIGN.md §4; they sum to SURVEY §8(d)'s 104 B per slice-step)
+ROUND = 'r02'
+# algorithmic bytes per pixel per launch (DESIGN.md §3; they sum to SURVEY §8(d)'s 104 B per slice-step)
 BYTES_PER_PX = {'row_fwd': 24.0, 'col_prop': 16.0, 'row_bwd': 40.0, 'rot_adjoint': 8.0}
 HBM_PEAK = 8.0e12
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command (tools/pmc_summary.py applies the gfx950
 # corrections); a process cannot collect them on itself, so the committed summary is read back here
-PMC_SUMMARY = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_bench.json')
-PMC_KERNEL = {'row_fwd': 'k_row_fwd<512, false, true>', 'col_prop': 'k_row_prop<512>', 'row_bwd': 'k_row_bwd<512, 1>',
+PMC_SUMMARY = os.path.join(ROOT, 'profiles', ROUND + '_pmc_traffic_bench.json')
+STATS_1STREAM = os.path.join(ROOT, 'profiles', ROUND + '_kernel_stats_1stream.csv')
+PMC_KERNEL = {'row_fwd': 'k_row_fwd<512, false, true', 'col_prop': 'k_row_prop<512>', 'row_bwd': 'k_row_bwd<512, 1',
               'rot_adjoint': 'k_rot_adjoint'}
 
 
 def pmc_traffic(kernel_class, n, mb):
-    """Measured L2<->fabric bytes per launch of the class's kernel (512^3, 25 angles only), or None."""
+    """Measured L2<->fabric bytes per launch of the class's kernel (512^3, 25 angles, whole-batch launches), or None."""
     if (n, mb) != (512, 25) or not os.path.exists(PMC_SUMMARY):
         return None
-    k = json.load(open(PMC_SUMMARY))['kernels'].get(PMC_KERNEL[kernel_class])
-    return k['total_bytes_per_launch'] if k else None
+    want = PMC_KERNEL[kernel_class]
+    for name, k in json.load(open(PMC_SUMMARY))['kernels'].items():
+        if name.startswith(want):
+            return k['total_bytes_per_launch']
+    return None
 
 
 def rocprof_avg_ms(kernel_class, n, mb):
-    """Average dispatch duration of the class's kernel in the committed rocprofv3 --kernel-trace --stats summary of this
-    same command (profiles/r01_kernel_stats.csv; 512^3, 25 angles only), or None."""
-    path = os.path.join(ROOT, 'profiles', 'r01_kernel_stats.csv')
-    if (n, mb) != (512, 25) or not os.path.exists(path):
+    """Average dispatch duration of the class's kernel in the committed single-stream rocprofv3 --kernel-trace --stats summary
+    of this command (512^3, 25 angles only), or None."""
+    if (n, mb) != (512, 25) or not os.path.exists(STATS_1STREAM):
         return None
     import csv
     want = PMC_KERNEL[kernel_class]
-    for row in csv.DictReader(open(path)):
+    for row in csv.DictReader(open(STATS_1STREAM)):
         if row['Name'].replace('void ', '').startswith(want):
             return float(row['AverageNs']) * 1e-6
     return None
@@ -81,7 +94,6 @@ def cpu_baseline(size, n_slice, seed=11):
     """The oracle (numpy restatement of np_funcs.py + its adjoint, complex128) timed on the host: one process per core,
     one projection angle each — the reference's one-MPI-rank-per-core model (cnn_propagator/fullfield.py:343).
     Workers are plain subprocesses of this file (`--cpu-worker`), killed after a deadline: they never touch the GPU."""
-    import subprocess
     cores = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)))
     env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
     t0 = time.perf_counter()
@@ -103,10 +115,84 @@ def cpu_baseline(size, n_slice, seed=11):
                       '(incl. interpreter start)'.format(size, n_slice, len(times), wall)}
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` outside a launcher: start N ranks of this same command, one per GPU.  This process only
+    spawns and waits — it never loads the HIP library — and rank 0's stdout is this process's stdout (one JSON line)."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+            if bad:                                    # one rank died: the others would wait for it forever
+                rc = bad[0]
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc or max((p.returncode or 0) for p in procs)
+
+
+def roofline_pass(solver, batch, hyper, n, mb, S):
+    """One step with the sub-batch streams off and every launch bracketed by HIP events on the stream it is launched on."""
+    eng = solver.eng
+    eng.set_streams(1)
+    solver.step(0, batch, **hyper)                     # same kernels, now as whole-batch launches: warm
+    solver.ctx.sync()
+    eng.profile_enable(True, stride=1)
+    solver.step(0, batch, **hyper)
+    solver.ctx.sync()
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    eng.set_streams(-1)
+    px = mb * n * n
+    launches_per_step = {'row_fwd': S, 'col_prop': 2 * S, 'row_bwd': S, 'rot_adjoint': 1}
+    per_class = {}
+    for name, bpp in BYTES_PER_PX.items():
+        cnt, ms = prof[name]
+        if cnt:
+            nbytes = bpp * px * (S if name == 'rot_adjoint' else 1)
+            per_class[name] = {'timed_launches': cnt, 'avg_ms': ms / cnt, 'bytes_per_launch': nbytes,
+                               'GBps': nbytes / (ms / cnt * 1e-3) / 1e9, 'frac': nbytes / (ms / cnt * 1e-3) / HBM_PEAK,
+                               'avg_ms_rocprof_1stream': rocprof_avg_ms(name, n, mb)}
+    if not per_class:
+        return None
+    dom = max(per_class, key=lambda k: per_class[k]['avg_ms'] * launches_per_step[k])
+    d = per_class[dom]
+    tb = pmc_traffic(dom, n, mb)
+    return {'bound': 'hbm', 'kernel': dom, 'achieved': d['GBps'], 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': d['frac'],
+            'traffic': None if tb is None else tb / (d['avg_ms'] * 1e-3) / 1e9,
+            'traffic_bytes_per_launch': tb, 'algorithmic_bytes_per_launch': d['bytes_per_launch'],
+            'avg_launch_ms_events': d['avg_ms'], 'avg_launch_ms_rocprof': d['avg_ms_rocprof_1stream'],
+            'rocprof_summary': os.path.relpath(STATS_1STREAM, ROOT) if d['avg_ms_rocprof_1stream'] else None,
+            'traffic_source': (os.path.relpath(PMC_SUMMARY, ROOT) + ' (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE x1)') if tb else None,
+            'note': 'dominant kernel = largest share of the step; achieved = algorithmic bytes of one whole-minibatch launch / '
+                    'its average HIP-event interval on the launch stream, measured in a single-stream pass after the timed region '
+                    '(the timed region runs two sub-batch streams: its figure is whole_step_frac)',
+            'per_kernel': per_class}
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == '--cpu-worker':
         print(_cpu_sample((int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))))
-        return
+        return 0
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -116,12 +202,14 @@ def main():
     ap.add_argument('--n-theta', type=int, default=200)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-slices', type=int, default=192)
-    ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='skip the roofline pass')
+    ap.add_argument('--recompute', action='store_true', help='tape-free adjoint (bdof_configure flag 16): psi_z is marched back')
     ap.add_argument('--propagator', default='fft', choices=['fft', 'conv'],
                     help="'conv': the reference entry points' truncated real-space kernel (17 taps), for comparison")
-    ap.add_argument('--profile-stride', type=int, default=64,
-                    help='HIP-event time every n-th launch of the per-slice kernels (each timed launch costs ~9 us of stream time)')
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args.gpus)
 
     # stdout carries exactly one JSON line: native libraries that print there (RCCL's version banner does) are sent to
     # stderr by pointing fd 1 at fd 2 for the rest of the run; the JSON line goes to a private copy of the real stdout.
@@ -132,17 +220,17 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
 
-    from beyond_dof_amd.comm import PseudoComm, TorchComm, minibatch_schedule
+    from beyond_dof_amd import _lib
+    from beyond_dof_amd.comm import comm_backend, get_comm, minibatch_schedule
     from beyond_dof_amd.solver import FullfieldSolver
 
-    comm = PseudoComm()
-    if world > 1 or os.environ.get('BDOF_FORCE_TORCH_COMM'):      # the env switch exercises the RCCL path on one GPU
-        import torch
-        torch.cuda.set_device(local_rank)
-        comm = TorchComm(os.environ.get('BDOF_COMM_BACKEND', 'nccl'))      # gloo: rehearsal with several ranks on one GPU
+    comm = get_comm()                      # N > 1: RcclComm (RCCL behind the C ABI); BDOF_COMM_BACKEND=gloo: rehearsal
+    device = local_rank
+    if world > 1 and comm_backend() == 'gloo':
+        device = local_rank % max(1, _lib.load().bdof_device_count())     # several rehearsal ranks may share one GPU
 
     n, mb, n_theta = args.size, args.angles_per_gpu, args.n_theta
     sched = minibatch_schedule(n_theta, world, mb, rng=np.random.default_rng(1234))
@@ -150,8 +238,8 @@ def main():
     my_angles = np.unique(np.concatenate(my_batches[:min(len(my_batches), args.steps + args.warmup)]))
 
     t_setup = time.time()
-    solver = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, comm=comm, device=local_rank,
-                             propagator=args.propagator)
+    solver = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, comm=comm, device=device,
+                             propagator=args.propagator, recompute=args.recompute)
     true_d, true_b = make_phantom(n)
     solver.set_volume(true_d, true_b)
     meas = np.zeros((n_theta, n, n), dtype=np.float32)
@@ -165,10 +253,10 @@ def main():
     solver.set_mask(np.ones((n, n, n), dtype=np.float32))
     del true_d, true_b, init_d, init_b
     hyper = dict(learning_rate=1e-7, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)     # params_cone, reconstruct_fullfield.py:50-56
-    n_slabs = solver.tune_allreduce()          # slab-pipelined vs whole-volume all-reduce tail: timed here, outside the run
+    n_slabs, sharded = solver.tune_tail()     # slab count of the exchange + Adam pipeline: timed here, outside the run
     if rank == 0:
-        print('[bench] setup {:.1f} s; all-reduce tail: {} slab(s) {}'.format(time.time() - t_setup, n_slabs, solver.tuned or ''),
-              file=sys.stderr)
+        print('[bench] setup {:.1f} s; exchange: {} slab(s){} {}'.format(time.time() - t_setup, n_slabs, ', sharded Adam' if sharded else '',
+                                                                       solver.tuned or ''), file=sys.stderr)
 
     def run(i):
         solver.step(i % len(my_batches), my_batches[i % len(my_batches)], want_loss=False, **hyper)
@@ -177,8 +265,6 @@ def main():
         run(i)
     solver.ctx.sync()
     comm.Barrier()
-    if not args.no_profile:
-        solver.eng.profile_enable(True, stride=args.profile_stride)
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         run(i)
@@ -186,65 +272,33 @@ def main():
     comm.Barrier()
     elapsed = time.perf_counter() - t0
     if comm.size > 1:
-        elapsed = float(comm.allreduce_sum_host(np.array([elapsed if r == rank else 0.0 for r in range(world)])).max())
-    prof = solver.eng.profile_read() if not args.no_profile else {}
+        elapsed = float(comm.allreduce_max_host(np.array([elapsed]))[0])
+    groups = solver.eng.batch_groups(mb)
+    S = n
+    roof = None if args.no_profile or args.propagator != 'fft' else roofline_pass(solver, my_batches[0], hyper, n, mb, S)
     loss = solver.loss_and_grad(my_batches[0], want_loss=True)
+    comm.Barrier()
 
     if rank == 0:
-        S = n
         slice_steps = world * mb * S * args.steps
-        px = mb * n * n
-        roof = None
-        if prof:
-            # A batch may run as `groups` sub-batches on concurrent streams (bdof_set_streams): every per-slice launch
-            # then carries 1/groups of the batch and shares the chip with the same launch of the other groups, so the
-            # chip-wide rate of the kernel is groups x (bytes of one launch / its duration).  Both figures are reported.
-            groups = solver.eng.batch_groups(mb)
-            per_class = {}
-            for name, bpp in BYTES_PER_PX.items():
-                cnt, ms = prof[name]
-                if cnt:
-                    g = 1 if name == 'rot_adjoint' else groups
-                    nbytes = bpp * px * (S if name == 'rot_adjoint' else 1) / g
-                    per_class[name] = {'timed_launches': cnt, 'avg_ms': ms / cnt, 'bytes_per_launch': nbytes,
-                                       'concurrent_launches': g, 'GBps_one_launch': nbytes / (ms / cnt * 1e-3) / 1e9,
-                                       'GBps': g * nbytes / (ms / cnt * 1e-3) / 1e9}
-            launches_per_step = {'row_fwd': S, 'col_prop': 2 * S, 'row_bwd': S, 'rot_adjoint': 1}
-            dom = max(per_class, key=lambda k: per_class[k]['avg_ms'] * launches_per_step[k] * (1 if k == 'rot_adjoint' else groups))
-            ach = per_class[dom]['GBps']
-            tb = pmc_traffic(dom, n, mb)
-            g = per_class[dom]['concurrent_launches']
-            if tb is not None:
-                # the PMC passes serialise kernels, so the library may have run them un-split (one launch per batch) while
-                # the timed run splits the batch in g sub-batches: bring the measured bytes to the timed run's launch size
-                full = BYTES_PER_PX[dom] * px * (S if dom == 'rot_adjoint' else 1)
-                g_pmc = 1 if tb > 0.75 * full else g
-                tb = tb * g_pmc / g
-            roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                    'frac': ach * 1e9 / HBM_PEAK,
-                    'traffic': None if tb is None else g * tb / (per_class[dom]['avg_ms'] * 1e-3) / 1e9,
-                    'concurrent_launches': g,
-                    'avg_launch_ms_events': per_class[dom]['avg_ms'],
-                    'avg_launch_ms_rocprof': rocprof_avg_ms(dom, n, mb),
-                    'note': ('achieved = concurrent_launches x algorithmic bytes of one launch / its event interval; with two '
-                             'sub-batch streams the event interval on a stream (end of its previous kernel -> end of this one) '
-                             'includes the wait for CU slots the other stream holds, rocprofv3 reports the dispatch alone '
-                             '(avg_launch_ms_rocprof, from the committed profiles/r01_kernel_stats.csv)')
-                            if g > 1 else 'achieved = algorithmic bytes of one launch / its average duration',
-                    'traffic_bytes_per_launch': tb, 'algorithmic_bytes_per_launch': per_class[dom]['bytes_per_launch'],
-                    'traffic_source': 'profiles/r01_pmc_traffic_bench.json (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE x1)' if tb else None,
-                    'per_kernel': per_class,
-                    'whole_step_frac': 104.0 * n * n * (slice_steps / world) / elapsed / HBM_PEAK}
+        if roof is not None:
+            roof['whole_step_frac'] = 104.0 * n * n * (slice_steps / world) / elapsed / HBM_PEAK
+            roof['sub_batch_streams_in_timed_region'] = groups
         out = {'metric': 'multislice fwd+adjoint slice-steps/s (full Adam iteration: rotation, forward, loss, adjoint, '
-                         'gradient all-reduce, regulariser+Adam)',
+                         'gradient exchange, regulariser+Adam)',
                'value': slice_steps / elapsed, 'unit': 'slice-steps/s', 'n_gpus': world, 'steps': args.steps,
                'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'adam_iters_per_s': args.steps / elapsed, 'final_loss': loss,
-               'config': {'workload': 'cfg3: {0}^3 charcoal-like random (delta,beta) volume, {1} of {2} angles per GPU per '
-                                      'Adam step, {0} slices, 5 keV, 1 nm, free_prop_cm=1e-4, plane probe'.format(n, mb, n_theta),
-                          'global_batch_angles': world * mb, 'parallelism': 'angle-sharded dp{}'.format(world), 'allreduce_slabs': n_slabs,
-                          'propagator': args.propagator},
+               'config': {'workload': '{3}: {0}^3 charcoal-like random (delta,beta) volume, {1} of {2} angles per GPU per '
+                                      'Adam step, {0} slices, 5 keV, 1 nm, free_prop_cm=1e-4, plane probe'.format(
+                                          n, mb, n_theta, 'cfg3' if (n, n_theta) == (512, 200) else 'cfg3-shaped (non-default size)'),
+                          'global_batch_angles': world * mb, 'parallelism': 'angle-sharded dp{}'.format(world),
+                          'exchange': ('none (1 rank)' if world == 1 and not getattr(comm, 'always_reduce', False) else
+                                       '{} ({} slab(s), {})'.format(comm.backend, n_slabs, 'reduce-scatter + sharded Adam + all-gather'
+                                                                    if sharded else 'all-reduce')),
+                          'allreduce_slabs': n_slabs, 'sharded_adam': bool(sharded), 'propagator': args.propagator,
+                          'adjoint': 'recompute (tape-free)' if args.recompute else 'tape'},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n, args.cpu_slices)
@@ -252,7 +306,8 @@ def main():
         real_stdout.flush()
     sys.stdout.flush()
     comm.close()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -50,11 +50,25 @@ _SIGNATURES = {
     'bdof_adam_step_slab': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
                             + [ctypes.c_float] * 8 + [ctypes.c_int] * 4),
     'bdof_mask_shrink': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_float]),
+    'bdof_gather_fields': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_size_t]),
     'bdof_set_streams': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_batch_groups': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_profile_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_profile_read': (ctypes.c_int, [_vp, ctypes.c_int, _c_int_p, ctypes.POINTER(ctypes.c_double)]),
     'bdof_malloc': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
+    'bdof_ctx_malloc': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_size_t]),
+    'bdof_comm_unique_id': (ctypes.c_int, [_vp, ctypes.c_size_t]),
+    'bdof_comm_create': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t]),
+    'bdof_comm_destroy': (None, [_vp]),
+    'bdof_comm_last_error': (ctypes.c_char_p, [_vp]),
+    'bdof_comm_size': (ctypes.c_int, [_vp]),
+    'bdof_comm_rank': (ctypes.c_int, [_vp]),
+    'bdof_allreduce_grad': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _c_int_p]),
+    'bdof_reduce_scatter_grad': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _c_int_p]),
+    'bdof_allgather_volume': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, _c_int_p]),
+    'bdof_bcast_volume': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int, _c_int_p]),
+    'bdof_comm_wait': (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
+    'bdof_comm_sync': (ctypes.c_int, [_vp]),
     'bdof_free': (ctypes.c_int, [_vp]),
     'bdof_memcpy_h2d': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
     'bdof_memcpy_d2h': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t]),
@@ -82,12 +96,12 @@ def load():
         raise BdofError('HIP extension not built: {} is missing (run __graft_entry__.build())'.format(LIB_PATH))
     # torch ships its own libamdhip64.so (same SONAME as /opt/rocm's, requested under another file name): whichever of
     # torch and libbdof.so is loaded first decides which HIP runtime the process gets, and when libbdof.so comes first
-    # torch loads a SECOND runtime that cannot see the GPU.  Whenever the process is going to use torch.distributed
-    # (multi-rank launch, or the switches below) torch is therefore imported before the library.
+    # torch loads a SECOND runtime that cannot see the GPU.  The product path does not use torch (RCCL sits behind the C
+    # ABI); only the gloo rehearsal backend does, and then torch is imported before the library.
     global TORCH_FIRST
     if 'torch' in sys.modules:
         TORCH_FIRST = True
-    elif (int(os.environ.get('WORLD_SIZE', '1')) > 1 or os.environ.get('BDOF_FORCE_TORCH_COMM')
+    elif ((int(os.environ.get('WORLD_SIZE', '1')) > 1 and os.environ.get('BDOF_COMM_BACKEND', '').lower() == 'gloo')
           or os.environ.get('BDOF_PRELOAD_TORCH')):
         import torch  # noqa: F401
         TORCH_FIRST = True
@@ -121,9 +135,9 @@ class DeviceBuffer(object):
         self.dtype = np.dtype(dtype)
         self.shape = tuple(shape) if shape is not None else (self.nbytes // self.dtype.itemsize,)
         p = _vp()
-        rc = ctx.lib.bdof_malloc(ctypes.byref(p), max(self.nbytes, 1))
+        rc = ctx.lib.bdof_ctx_malloc(ctx.handle, ctypes.byref(p), max(self.nbytes, 1))
         if rc != 0 or not p.value:
-            raise BdofError('bdof_malloc({} bytes) failed with hip error {}'.format(nbytes, rc))
+            raise BdofError('bdof_ctx_malloc({} bytes) failed with hip error {}'.format(nbytes, rc))
         self.ptr = p.value
 
     @classmethod

@@ -13,6 +13,7 @@
 #include "bdof_kernels.h"
 #include "bdof_generic.h"
 #include "bdof_resident.h"
+#include "bdof_comm.h"
 #include <rocfft/rocfft.h>
 #include <map>
 
@@ -21,6 +22,7 @@
 #define BDOF_ERR_SIZE (-3)
 
 #define BDOF_MAX_GROUPS 4
+#define BDOF_MAX_DEVICES 64
 struct bdof_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -572,10 +574,10 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
 // ---- LDS-resident engine ---------------------------------------------------------------------------
 template <int N, int T, int WPE> static int resident_launch_t(bdof_ctx* c, const ResArgs& a, int grid) {
     const size_t lds = sizeof(cf) * ((size_t)N * (N | 1) + N) + sizeof(long long) * 3 * N;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[BDOF_MAX_DEVICES] = {};      // the attribute is per device (a process may hold ctxs on several)
+    if (!attr_set[c->device % BDOF_MAX_DEVICES]) {
         HIPC(c, hipFuncSetAttribute((const void*)k_resident<N, T, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[c->device % BDOF_MAX_DEVICES] = true;
     }
     hipLaunchKernelGGL((k_resident<N, T, WPE>), dim3(grid), dim3(T), lds, c->stream, a);
     return 0;
@@ -1111,10 +1113,10 @@ static int conv_lds_bytes(const bdof_ctx* c) {
 
 template <bool BWD, int H> static int launch_conv_h(bdof_ctx* c, ConvArgs& a) {
     const int lds = conv_lds_bytes(c);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[BDOF_MAX_DEVICES] = {};
+    if (!attr_set[c->device % BDOF_MAX_DEVICES]) {
         HIPC(c, hipFuncSetAttribute((const void*)k_conv<BWD, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        attr_set = true;
+        attr_set[c->device % BDOF_MAX_DEVICES] = true;
     }
     const int tiles = a.B * (a.NX / BDOF_CONV_TX) * (a.NY / BDOF_CONV_TY);
     const int grid = balanced_grid(c, tiles, 2);
@@ -1386,6 +1388,17 @@ int bdof_mask_shrink(bdof_ctx* c, const void* x, float* mask, size_t n, float th
     return 0;
 }
 
+int bdof_gather_fields(bdof_ctx* c, void* dst, const void* src, const int* idx, int B, size_t bytes_per_field) {
+    if (!c || !dst || !src || !idx || B < 1) return BDOF_ERR_ARG;
+    if (bytes_per_field % 16) return fail(c, BDOF_ERR_SIZE, "bdof_gather_fields: fields must be multiples of 16 bytes");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t n16 = bytes_per_field / 16;
+    const int gx = (int)std::min<size_t>((n16 + 255) / 256, 64);
+    hipLaunchKernelGGL(k_gather_fields, dim3(gx, B < 1024 ? B : 1024), dim3(256), 0, c->stream, (float4*)dst, (const float4*)src, idx, B, n16);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
 int bdof_set_streams(bdof_ctx* c, int n) {
     if (!c) return -1;
     if (n == 0 || n > BDOF_MAX_GROUPS) return fail(c, -2, "bdof_set_streams: n must be -1 or 1..4");
@@ -1423,28 +1436,172 @@ int bdof_malloc(void** ptr, size_t bytes) {
     if (!ptr) return BDOF_ERR_ARG;
     return (int)hipMalloc(ptr, bytes);
 }
+int bdof_ctx_malloc(bdof_ctx* c, void** ptr, size_t bytes) {
+    if (!c || !ptr) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMalloc(ptr, bytes));
+    return 0;
+}
 int bdof_free(void* ptr) { return (int)hipFree(ptr); }
 int bdof_memcpy_h2d(bdof_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 int bdof_memcpy_d2h(bdof_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 int bdof_memset(bdof_ctx* c, void* dst, int value, size_t bytes) {
     if (!c) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipMemsetAsync(dst, value, bytes, c->stream));
     return 0;
 }
 
 int bdof_memcpy_d2d(bdof_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+
+// =================================================================================================
+// Collectives (RCCL over xGMI): comm.Allreduce(this_grads, grads) of cnn_propagator/fullfield.py:348-351
+// =================================================================================================
+static int comm_fail(bdof_comm* m, int code, const std::string& msg) {
+    if (m) m->err = msg;
+    g_rccl.err = msg;
+    return code;
+}
+#define NCCLC(m, call)                                                                                     \
+    do {                                                                                                   \
+        ncclResult_t r_ = (call);                                                                          \
+        if (r_ != ncclSuccess)                                                                             \
+            return comm_fail((m), 1000 + (int)r_, std::string(#call) + ": " + g_rccl.GetErrorString(r_));  \
+    } while (0)
+#define HIPM(m, call)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return comm_fail((m), (int)e_, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int bdof_comm_unique_id(void* id, size_t bytes) {
+    if (!id || bytes < sizeof(ncclUniqueId)) return BDOF_ERR_ARG;
+    if (!rccl_load()) return BDOF_ERR_STATE;
+    ncclUniqueId u;
+    ncclResult_t r = g_rccl.GetUniqueId(&u);
+    if (r != ncclSuccess) { g_rccl.err = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return 1000 + (int)r; }
+    std::memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+const char* bdof_comm_last_error(const bdof_comm* m) { return m ? m->err.c_str() : g_rccl.err.c_str(); }
+
+int bdof_comm_create(bdof_comm** out, int device, int nranks, int rank, const void* id, size_t bytes) {
+    if (!out || !id || bytes < sizeof(ncclUniqueId) || nranks < 1 || rank < 0 || rank >= nranks) return BDOF_ERR_ARG;
+    *out = nullptr;
+    if (!rccl_load()) return BDOF_ERR_STATE;
+    bdof_comm* m = new bdof_comm();
+    m->device = device; m->nranks = nranks; m->rank = rank;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming);
+    for (int i = 0; e == hipSuccess && i < BDOF_COMM_TICKETS; ++i) e = hipEventCreateWithFlags(&m->ticket[i], hipEventDisableTiming);
+    if (e != hipSuccess) { g_rccl.err = std::string("bdof_comm_create: ") + hipGetErrorString(e); delete m; return (int)e; }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    ncclResult_t r = g_rccl.CommInitRank(&m->comm, nranks, u, rank);
+    if (r != ncclSuccess) {
+        g_rccl.err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r);
+        delete m;
+        return 1000 + (int)r;
+    }
+    *out = m;
+    return 0;
+}
+
+void bdof_comm_destroy(bdof_comm* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->comm) (void)g_rccl.CommDestroy(m->comm);
+    for (int i = 0; i < BDOF_COMM_TICKETS; ++i) if (m->ticket[i]) (void)hipEventDestroy(m->ticket[i]);
+    if (m->ev_in) (void)hipEventDestroy(m->ev_in);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int bdof_comm_size(const bdof_comm* m) { return m ? m->nranks : 0; }
+int bdof_comm_rank(const bdof_comm* m) { return m ? m->rank : -1; }
+
+// the communicator's stream picks up behind everything the ctx stream holds now
+static int comm_enter(bdof_comm* m, bdof_ctx* c) {
+    if (!m || !c) return BDOF_ERR_ARG;
+    if (m->device != c->device) return comm_fail(m, BDOF_ERR_ARG, "communicator and ctx live on different devices");
+    HIPM(m, hipSetDevice(m->device));
+    HIPM(m, hipEventRecord(m->ev_in, c->stream));
+    HIPM(m, hipStreamWaitEvent(m->stream, m->ev_in, 0));
+    return 0;
+}
+static int comm_leave(bdof_comm* m, int* ticket) {
+    const unsigned t = m->next++ % BDOF_COMM_TICKETS;
+    HIPM(m, hipEventRecord(m->ticket[t], m->stream));
+    if (ticket) *ticket = (int)t;
+    return 0;
+}
+
+int bdof_allreduce_grad(bdof_comm* m, bdof_ctx* c, void* buf, size_t count, int* ticket) {
+    int r = comm_enter(m, c);
+    if (r) return r;
+    if (!buf) return comm_fail(m, BDOF_ERR_ARG, "null buffer");
+    if (count) NCCLC(m, g_rccl.AllReduce(buf, buf, count, ncclFloat, ncclSum, m->comm, m->stream));
+    return comm_leave(m, ticket);
+}
+
+int bdof_reduce_scatter_grad(bdof_comm* m, bdof_ctx* c, void* buf, size_t count_per_rank, int* ticket) {
+    int r = comm_enter(m, c);
+    if (r) return r;
+    if (!buf) return comm_fail(m, BDOF_ERR_ARG, "null buffer");
+    if (count_per_rank)
+        NCCLC(m, g_rccl.ReduceScatter(buf, (float*)buf + (size_t)m->rank * count_per_rank, count_per_rank, ncclFloat, ncclSum, m->comm, m->stream));
+    return comm_leave(m, ticket);
+}
+
+int bdof_allgather_volume(bdof_comm* m, bdof_ctx* c, void* buf, size_t count_per_rank, int* ticket) {
+    int r = comm_enter(m, c);
+    if (r) return r;
+    if (!buf) return comm_fail(m, BDOF_ERR_ARG, "null buffer");
+    if (count_per_rank)
+        NCCLC(m, g_rccl.AllGather((const float*)buf + (size_t)m->rank * count_per_rank, buf, count_per_rank, ncclFloat, m->comm, m->stream));
+    return comm_leave(m, ticket);
+}
+
+int bdof_bcast_volume(bdof_comm* m, bdof_ctx* c, void* buf, size_t count, int root, int* ticket) {
+    int r = comm_enter(m, c);
+    if (r) return r;
+    if (!buf || root < 0 || root >= m->nranks) return comm_fail(m, BDOF_ERR_ARG, "bad buffer / root");
+    if (count) NCCLC(m, g_rccl.Broadcast(buf, buf, count, ncclFloat, root, m->comm, m->stream));
+    return comm_leave(m, ticket);
+}
+
+int bdof_comm_wait(bdof_comm* m, bdof_ctx* c, int ticket) {
+    if (!m || !c || ticket < 0 || ticket >= BDOF_COMM_TICKETS) return BDOF_ERR_ARG;
+    HIPM(m, hipSetDevice(m->device));
+    HIPM(m, hipStreamWaitEvent(c->stream, m->ticket[ticket], 0));
+    return 0;
+}
+
+int bdof_comm_sync(bdof_comm* m) {
+    if (!m) return BDOF_ERR_ARG;
+    HIPM(m, hipSetDevice(m->device));
+    HIPM(m, hipStreamSynchronize(m->stream));
     return 0;
 }
 

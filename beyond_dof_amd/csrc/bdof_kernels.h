@@ -742,6 +742,17 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
     }
 }
 
+// dst[b][:] = src[idx[b]][:] for B fields of n16 16-byte words: the minibatch's measured amplitudes picked out of the
+// resident stack of all angles in one launch (this_prj_batch = prj[this_ind_batch], cnn_propagator/fullfield.py:344).
+__global__ __launch_bounds__(256) void k_gather_fields(float4* __restrict__ dst, const float4* __restrict__ src,
+                                                        const int* __restrict__ idx, int B, size_t n16) {
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        const float4* s = src + (size_t)idx[b] * n16;
+        float4* d = dst + (size_t)b * n16;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+    }
+}
+
 // shrink-wrap of the finite-support mask: mask *= (delta > thresh)      cnn_propagator/fullfield.py:365-368
 __global__ __launch_bounds__(256) void k_mask_shrink(const float2* x, float* mask, size_t n, float thresh) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)

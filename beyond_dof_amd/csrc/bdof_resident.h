@@ -38,8 +38,8 @@ static inline bool resident_supported(int n) {
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() on gfx9 also drains vmcnt, i.e. every barrier would wait
 // for the global loads prefetched for the next slice and for the tape / gradient stores of the previous one — one HBM round
-// trip per barrier.  Nothing here communicates between threads through global memory (a thread re-reads only the tape
-// elements it wrote itself), so waiting for the LDS counter is sufficient.
+// trip per barrier.  Inside a sweep nothing communicates between threads through global memory, so waiting for the LDS
+// counter is sufficient; the one hand-over through global memory (forward tape -> adjoint sweep) has a full barrier.
 __device__ __forceinline__ void res_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ROUND: how sqrt(3)/2 is represented (see mul_sqrt_half in bdof_fft.h): 0 hi + lo pair, 1 nearest float32 (1.8e-8 short),
@@ -574,7 +574,12 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
             rowbuf[((a.S - 1) % 3) * N + tid] = Pipe::row_of(a, b, a.S - 1, tid);
             rowbuf[((a.S + 1) % 3) * N + tid] = Pipe::row_of(a, b, a.S - 2, tid);      // (S - 2) mod 3
         }
-        res_sync();
+        // The adjoint sweep reads tape elements in a different thread mapping than the forward sweep wrote them whenever a
+        // fused plan has CNT * T != N * N / R butterflies (N = 36) — communication between threads through global memory.  Once per
+        // wavefield the barrier therefore also drains the stores (vmcnt) and makes them visible workgroup-wide; the
+        // per-pass barriers (res_sync) stay LDS-only.
+        __threadfence();
+        __syncthreads();
         cf t[EPT];
         if constexpr (!FUSE) {
             Pipe::load_factors(a, rowbuf + ((a.S - 1) % 3) * N, y0, tid, m);

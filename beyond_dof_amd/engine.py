@@ -25,7 +25,8 @@ _GAIN_CACHE = {}      # free-space energy calibration per (geometry, physics, pr
 class MultisliceEngine(object):
     """One wavefield geometry (NY x NX x S) on one GPU."""
 
-    def __init__(self, ny, nx, n_slice, batch_max, with_grad=True, device=0, stream=None, force_generic=False, engine='auto'):
+    def __init__(self, ny, nx, n_slice, batch_max, with_grad=True, device=0, stream=None, force_generic=False, engine='auto',
+                 recompute=None):
         """Engines (include/bdof.h, bdof_configure): powers of two in 64..1024 run on the fused streaming kernels; small
         square fields (32..128, e.g. the 72 x 72 ptychography probe) on the LDS-resident kernel when there is no fused plan
         or the batch is large; every other size on the generic engine (rocFFT).  engine='generic' (= force_generic=True),
@@ -33,6 +34,9 @@ class MultisliceEngine(object):
         if engine not in ('auto', 'generic', 'streaming', 'resident'):
             raise ValueError('engine must be auto, generic, streaming or resident')
         force_generic = force_generic or engine == 'generic'
+        if recompute is None:
+            recompute = bool(int(os.environ.get('BDOF_RECOMPUTE', '0')))
+        self.recompute = bool(recompute)
         self.ctx = _lib.Context(device, stream)
         self.lib = self.ctx.lib
         self.h = self.ctx.handle
@@ -40,7 +44,8 @@ class MultisliceEngine(object):
         self.with_grad = bool(with_grad)
         self.ctx.check(self.lib.bdof_configure(self.h, self.ny, self.nx, self.n_slice, self.batch_max,
                                                int(bool(with_grad)) | (2 if (force_generic or os.environ.get('BDOF_FORCE_GENERIC')) else 0)
-                                               | (4 if engine == 'streaming' else 0) | (8 if engine == 'resident' else 0)))
+                                               | (4 if engine == 'streaming' else 0) | (8 if engine == 'resident' else 0)
+                                               | (16 if self.recompute else 0)))
         self._engine_arg = 'generic' if force_generic else engine
         self._device = device
         self.calibrate_energy = True      # see set_probe

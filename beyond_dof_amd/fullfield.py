@@ -15,6 +15,7 @@ Differences, all deliberate:
   * a missing finite-support mask means "no mask" instead of a Paganin reconstruction from files that do not exist.
 """
 import os
+import struct
 import time
 
 import numpy as np
@@ -46,7 +47,7 @@ def _read_mask(save_path, n_slices):
                    lambda: tiffio.read_tiff(os.path.join(save_path, 'fin_sup_mask', 'mask.tiff'))):
         try:
             return np.asarray(loader(), dtype=np.float32)
-        except (IOError, OSError):
+        except (IOError, OSError, KeyError, ValueError, IndexError, struct.error):      # missing or not a TIFF we can parse
             continue
     return None
 
@@ -70,6 +71,9 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
     # 'fft' (default): transfer-function propagator of np_funcs.py; 'conv': truncated real-space kernel of propagation.py,
     # the reference's own choice in this entry point, with `kernel_size` taps per axis
     propagator = kwargs.get('propagator', 'fft')
+    # gradient accumulation over n_batch_per_update minibatches exists only in the TF twin (tensorflow_recon/fullfield.py:
+    # 413-425); the cnn variant accepts the keyword and ignores it (default 5!), so it is opt-in here
+    accumulate = bool(kwargs.get('accumulate_gradients', False))
 
     print_flush('Reading data...', 0, rank)
     t0 = time.time()
@@ -153,14 +157,7 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
         else:
             raise ValueError("Invalid wavefront type. Choose from 'plane', 'fixed', 'optimizable'.")
 
-        folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(dim_y, dim_x, dim_x, n_theta)
-        try:
-            coord_ls = util.read_all_origin_coords(folder, n_theta)
-        except (IOError, OSError):
-            if rank == 0:
-                util.save_rotation_lookup([dim_y, dim_x, dim_x], n_theta)
-            comm.Barrier()
-            coord_ls = util.read_all_origin_coords(folder, n_theta)
+        coord_ls = util.rotation_lookup_files([dim_y, dim_x, dim_x], n_theta, comm)
 
         solver = FullfieldSolver(dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm * ds_level,
                                  free_prop_cm=free_prop_cm, probe_real=probe_real, probe_imag=probe_imag, variant=variant,
@@ -168,7 +165,7 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
         solver.set_volume(obj_delta, obj_beta)
         solver.set_mask(mask)
         solver.set_measurements(np.abs(prj))
-        solver.tune_allreduce()                  # N ranks: slab-pipelined or whole-volume all-reduce tail, by measurement
+        solver.tune_tail()                       # N ranks: slab count of the exchange + Adam pipeline, by measurement; step() uses it
 
         print_flush('Optimizer started.', 0, rank)
         if rank == 0:
@@ -187,10 +184,9 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
             for i_batch, chunk in enumerate(ind_ls):
                 t00 = time.time()
                 this_ind_batch = chunk[rank * minibatch_size:(rank + 1) * minibatch_size]
-                solver.loss_and_grad(this_ind_batch, want_loss=False)
-                if size > 1:
-                    comm.allreduce_sum_device(solver.g, stream_sync=solver.ctx.sync)
-                solver.adam_update(i_batch, learning_rate, reg_d, reg_b, gamma, clip=True, use_mask=use_mask)
+                # loss_grad -> Allreduce -> /size -> Adam -> mask, clip (fullfield.py:345-362): one pipelined device step
+                solver.step(i_batch, this_ind_batch, learning_rate, reg_d, reg_b, gamma, use_mask=use_mask,
+                            n_batch_per_update=n_batch_per_update if accumulate else 1, last_of_epoch=i_batch == len(ind_ls) - 1)
                 if save_intermediate and rank == 0:
                     d, _ = solver.get_volume()
                     tiffio.write_tiff(d, os.path.join(output_folder, 'intermediate', 'current'), dtype='float32', overwrite=True)

@@ -89,14 +89,7 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
         if minibatch_size is None:
             minibatch_size = n_pos
 
-        folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(*this_obj_size, n_theta)
-        try:
-            coord_ls = util.read_all_origin_coords(folder, n_theta)
-        except (IOError, OSError):
-            if rank == 0:
-                util.save_rotation_lookup(this_obj_size, n_theta)
-            comm.Barrier()
-            coord_ls = util.read_all_origin_coords(folder, n_theta)
+        coord_ls = util.rotation_lookup_files(this_obj_size, n_theta, comm)
 
         np.random.seed(seed)                               # rank 0 initialises and broadcasts in the reference (:169-208)
         if first_level:
@@ -139,6 +132,7 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
                               psize_cm * ds_level, probe_real, probe_imag, variant=variant, comm=comm, device=comm.local_rank,
                               coord_ls=coord_ls, propagator=propagator, kernel_size=kwargs.get('kernel_size', 17))
         solver.set_volume(obj_delta, obj_beta)
+        solver.tune_tail()
         print_flush('Optimizer started.', 0, rank)
         if rank == 0:
             create_summary(output_folder, locals(), preset='ptycho')
@@ -160,10 +154,8 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
                 this_prj_batch = np.abs(prj[int(prj_theta_ind[this_i_theta]), this_ind_rank.tolist()])
                 if ds_level > 1:
                     this_prj_batch = this_prj_batch[:, ::ds_level, ::ds_level]
-                solver.loss_and_grad(this_i_theta, this_ind_rank, this_prj_batch, want_loss=False)
-                if size > 1:
-                    comm.allreduce_sum_device(solver.g, stream_sync=solver.ctx.sync)
-                solver.adam_update(i_batch, learning_rate, clip=True)
+                # loss_grad -> Allreduce -> /size -> Adam -> clip (ptychography.py:301-310): one pipelined device step
+                solver.step(i_batch, this_i_theta, this_ind_rank, this_prj_batch, learning_rate)
                 if save_intermediate and rank == 0:
                     d, _ = solver.get_volume()
                     tiffio.write_tiff(d, os.path.join(output_folder, 'intermediate', 'current'), dtype='float32', overwrite=True)

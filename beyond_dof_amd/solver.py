@@ -1,6 +1,19 @@
-"""Device-resident state of a full-field reconstruction: the (delta, beta) volume, its Adam moments,
-the rotation tables and the measured amplitudes, plus the Adam iteration built from libbdof calls.
-This is the loop body of cnn_propagator/fullfield.py:340-362 with every array kept in HBM."""
+"""Device-resident state of a reconstruction: the (delta, beta) volume, its Adam moments, the rotation tables and the
+measured amplitudes, plus the Adam iteration built from libbdof calls.  This is the loop body of
+cnn_propagator/fullfield.py:340-362 and ptychography.py:285-310 with every array kept in HBM.
+
+One Adam iteration (`step`):
+    forward + adjoint sweeps of this rank's wavefields                     bdof_loss_grad
+    then, pipelined over x-slabs of the [X][Z][Y] volume (the "tail"):
+      rotation adjoint of slab c                                          bdof_rotation_adjoint_rows
+      gradient exchange of slab c across ranks                            bdof_reduce_scatter_grad | bdof_allreduce_grad
+      regulariser + Adam + mask + clip on slab c (sharded: on this rank's 1/N of it)   bdof_adam_step_slab
+      sharded: all-gather of the updated slab                             bdof_allgather_volume
+The collectives run on the communicator's stream; the ctx stream only waits for slab c two slabs later, so the producer
+of the next slabs and the consumer of the previous ones run while a slab is on the wire.  The TV stencil reads the
+pre-update volume (x_old), which no slab overwrites: slab-wise, sharded and whole-volume execution give identical results.
+"""
+import ctypes
 import os
 
 import numpy as np
@@ -12,32 +25,12 @@ from .comm import PseudoComm
 from .engine import MultisliceEngine
 
 
-class FullfieldSolver(object):
-    def __init__(self, dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm, free_prop_cm=None,
-                 probe_real=None, probe_imag=None, variant='numpy_skip_last', comm=None, device=0, stream=None,
-                 coord_ls=None, propagator='fft', kernel_size=17):
-        """propagator='fft': the transfer-function step of np_funcs.py (north-star path); 'conv': the truncated real-space
-        kernel of propagation.py, what cnn_propagator/fullfield.py:87,102 calls (kernel_size taps per axis)."""
-        self.conv = propagator == 'conv'
-        self.dim_y, self.dim_x, self.dim_z = int(dim_y), int(dim_x), int(dim_z)
-        self.n_theta, self.mb = int(n_theta), int(minibatch_size)
-        self.comm = comm or PseudoComm()
-        self.eng = MultisliceEngine(self.dim_y, self.dim_x, self.dim_z, self.mb, with_grad=True, device=device, stream=stream)
-        self.ctx = self.eng.ctx
-        self.eng.set_physics(energy_ev, psize_cm, free_prop_cm, variant=variant)
-        if self.conv:
-            self.eng.set_conv(energy_ev, psize_cm, kernel_size)
-        if probe_real is None:
-            probe_real, probe_imag = np.ones((dim_y, dim_x)), np.zeros((dim_y, dim_x))   # 'plane', fullfield.py:276-278
-        self.eng.set_probe(probe_real, probe_imag)
-        # rotation lookup tables (cnn_propagator/util.py:294-347), uploaded once
-        if coord_ls is None:
-            coord_ls = util.rotation_lookup([dim_y, dim_x, dim_z], n_theta)
-        tab, off, order = util.device_rotation_tables(coord_ls, self.dim_x, self.dim_z)
-        self.tab = DeviceBuffer.from_host(self.ctx, tab)
-        self.off = DeviceBuffer.from_host(self.ctx, off)
-        self.order = DeviceBuffer.from_host(self.ctx, order)
-        nvox = self.dim_x * self.dim_z * self.dim_y
+class _VolumeSolver(object):
+    """What the full-field and ptychography solvers share: volume double buffer, gradient, moments, the tail of the step."""
+
+    lookahead = 2              # slabs in flight between a collective's start and the Adam pass that consumes it
+
+    def _init_volume(self):
         shape = (self.dim_x, self.dim_z, self.dim_y, 2)
         self.x = [DeviceBuffer.zeros(self.ctx, shape, np.float32), DeviceBuffer.zeros(self.ctx, shape, np.float32)]
         self.cur = 0
@@ -45,15 +38,11 @@ class FullfieldSolver(object):
         self.m = DeviceBuffer.zeros(self.ctx, shape, np.float32)
         self.v = DeviceBuffer.zeros(self.ctx, shape, np.float32)
         self.mask = None
-        self.meas = None
-        self.meas_stage = DeviceBuffer(self.ctx, self.mb * self.dim_x * self.dim_y * 4, np.float32,
-                                       (self.mb, self.dim_x, self.dim_y))
-        self.angle_buf = DeviceBuffer(self.ctx, self.mb * 4, np.int32, (self.mb,))
-        self.nvox = nvox
-        self._n_slabs = None
+        self.nvox = self.dim_x * self.dim_z * self.dim_y
+        self._plan = None
         self.tuned = None
-        self._bind_volume()
-        self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
+        self._acc = 0              # minibatches accumulated in self.g since the last update (n_batch_per_update)
+        self.comm.attach(self.ctx)
 
     def _bind_volume(self):
         self.eng.set_volume(self.x[self.cur], self.dim_x * self.dim_z, self.dim_y, self.tab, self.dim_x, self.n_theta)
@@ -71,15 +60,197 @@ class FullfieldSolver(object):
         self.mask = None if mask is None else DeviceBuffer.from_host(
             self.ctx, np.ascontiguousarray(np.asarray(mask, dtype=np.float32).transpose(1, 2, 0)))
 
-    def set_measurements(self, prj_abs):
-        """|prj| for every angle, (n_theta, Y, X) (loss uses np.abs(this_prj_batch), fullfield.py:106)."""
-        self.meas = DeviceBuffer.from_host(self.ctx, self.eng.meas_layout(prj_abs))
-
     def reset_moments(self):
         """m, v = (None, None) at the start of every epoch (fullfield.py:338, quirk Q10)."""
         lib, h = self.ctx.lib, self.ctx.handle
         self.ctx.check(lib.bdof_memset(h, self.m.ptr, 0, self.m.nbytes))
         self.ctx.check(lib.bdof_memset(h, self.v.ptr, 0, self.v.nbytes))
+        self._acc = 0
+
+    def bcast_volume(self, root=0):
+        """Rank `root`'s volume to every rank (the init_*_temp.npy hand-over of ptychography.py:169-208)."""
+        if self.comm.size > 1:
+            self.comm.bcast_device(self.ctx, self.x[self.cur], root)
+            self._bind_volume()
+
+    def _get_loss(self):
+        loss = ctypes.c_double(0)
+        self.ctx.check(self.ctx.lib.bdof_get_loss(self.ctx.handle, ctypes.byref(loss)))
+        return loss.value
+
+    def gradient_to_host(self):
+        self.ctx.sync()
+        return util.rows_to_volume(self.g.download())
+
+    # ---- the tail of the step ----------------------------------------------------------------
+    def _reduces(self):
+        return self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)
+
+    def slab_bounds(self, n_slabs):
+        """x-plane ranges [(x0, nx)] of n_slabs nearly equal slabs of the [X][Z][Y] volume."""
+        n_slabs = max(1, min(int(n_slabs), self.dim_x))
+        edges = [(self.dim_x * i) // n_slabs for i in range(n_slabs + 1)]
+        return [(edges[i], edges[i + 1] - edges[i]) for i in range(n_slabs)]
+
+    def tail_plan(self, n_slabs=None, sharded=None):
+        """(n_slabs, sharded) of the exchange.  sharded = reduce-scatter -> Adam on this rank's 1/size of each slab ->
+        all-gather: needs every slab to split evenly over the ranks, else the all-reduce form is used.
+        BDOF_ALLREDUCE_SLABS / BDOF_SHARDED_ADAM override; tune_tail() picks the slab count by measurement."""
+        if not self._reduces():
+            return 1, False
+        if n_slabs is None and sharded is None and self._plan is not None:
+            return self._plan
+        if n_slabs is None:
+            n_slabs = int(os.environ.get('BDOF_ALLREDUCE_SLABS', '8'))
+        if sharded is None:
+            sharded = getattr(self.comm, 'sharded', False) and os.environ.get('BDOF_SHARDED_ADAM', '1') != '0'
+        n_slabs = max(1, min(int(n_slabs), self.dim_x))
+        if sharded:
+            n = n_slabs
+            while n > 1 and self.dim_x % (n * self.comm.size):
+                n -= 1
+            if self.dim_x % (n * self.comm.size) == 0:
+                n_slabs = n
+            else:
+                sharded = False
+        return n_slabs, bool(sharded)
+
+    def _adam_slab(self, i_update, learning_rate, alpha_d, alpha_b, gamma, clip, use_mask, slab, g_scale):
+        new = 1 - self.cur
+        self.eng.adam_step(self.x[self.cur], self.x[new], self.g, self.m, self.v, self.mask if use_mask else None,
+                           (self.dim_x, self.dim_z, self.dim_y), i_update, learning_rate, g_scale=g_scale,
+                           alpha_d=alpha_d, alpha_b=alpha_b, gamma=gamma, clip=clip, slab=slab)
+
+    def _flip(self):
+        self.cur = 1 - self.cur
+        self._bind_volume()
+
+    def _tail(self, produce, i_update, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, clip=True, use_mask=True,
+              n_slabs=None, sharded=None, flip=True, n_acc=1):
+        """produce(x0, nx): enqueue the kernels that leave this rank's gradient of x-planes [x0, x0+nx) in self.g.
+        Then exchange + regulariser + Adam (+ mask, clip), slab by slab.  g_scale = 1 / (size * n_acc)
+        (grads /= size, fullfield.py:351; accumulated minibatches are averaged, tensorflow_recon/fullfield.py:424)."""
+        comm, ctx = self.comm, self.ctx
+        g_scale = 1.0 / (comm.size * n_acc)
+        args = (i_update, learning_rate, alpha_d, alpha_b, gamma, clip, use_mask)
+        if not self._reduces():
+            produce(0, self.dim_x)
+            self._adam_slab(*args, slab=None, g_scale=g_scale)
+            if flip:
+                self._flip()
+            return
+        n_slabs, sharded = self.tail_plan(n_slabs, sharded)
+        slabs = self.slab_bounds(n_slabs)
+        per_x = self.dim_z * self.dim_y * 2                  # floats per x-plane of the gradient / volume
+        size, rank = comm.size, comm.rank
+        tickets, gathers = [None] * len(slabs), []
+        x_new = self.x[1 - self.cur]
+
+        def finish(c):
+            x0, nx = slabs[c]
+            comm.wait(ctx, tickets[c])
+            if sharded:
+                w = nx // size
+                self._adam_slab(*args, slab=(x0 + rank * w, w), g_scale=g_scale)
+                gathers.append(comm.start_allgather(ctx, x_new, x0 * per_x, w * per_x))
+            else:
+                self._adam_slab(*args, slab=(x0, nx), g_scale=g_scale)
+
+        for c, (x0, nx) in enumerate(slabs):
+            produce(x0, nx)
+            if sharded:
+                tickets[c] = comm.start_reduce_scatter(ctx, self.g, x0 * per_x, (nx // size) * per_x)
+            else:
+                tickets[c] = comm.start_allreduce(ctx, self.g, x0 * per_x, (x0 + nx) * per_x)
+            if c >= self.lookahead:
+                finish(c - self.lookahead)
+        for c in range(max(0, len(slabs) - self.lookahead), len(slabs)):
+            finish(c)
+        for t in gathers:
+            comm.wait(ctx, t)
+        if flip:
+            self._flip()
+
+    def tune_tail(self, candidates=(1, 8), reps=2):
+        """Pick the number of slabs of the pipelined tail by timing it on this machine and process layout (the collective,
+        the streams it runs on and the kernels either side interact in ways that differ between runtimes).  Dry run with
+        learning rate 0 on a zeroed rotated-frame gradient: the gradient buffer, the spare volume buffer and the Adam
+        moments are scratch afterwards (the moments are zeroed again), the volume is not touched.  Every rank takes the
+        same decision (max of the timings over ranks).  `step` uses the result."""
+        import time
+        if not self._reduces() or os.environ.get('BDOF_ALLREDUCE_SLABS'):
+            self._plan = self.tail_plan()
+            return self._plan
+        self._zero_rotated_gradient()
+        plans = []
+        for n in candidates:
+            p = self.tail_plan(n)
+            if p not in plans:
+                plans.append(p)
+        times = []
+        for p in plans:
+            self._dry_tail(*p)                                # first use: communicator / stream set-up
+            self.ctx.sync()
+            self.comm.Barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self._dry_tail(*p)
+            self.ctx.sync()
+            times.append(time.perf_counter() - t0)
+        worst = self.comm.allreduce_max_host(np.array(times))
+        self._plan = plans[int(np.argmin(worst))]
+        self.tuned = {'{}slab{}'.format(p[0], '_sharded' if p[1] else ''): float(t) / reps for p, t in zip(plans, worst)}
+        self.reset_moments()
+        return self._plan
+
+    def _zero_rotated_gradient(self):
+        lib, h = self.ctx.lib, self.ctx.handle
+        n = self.mb * self.dim_z * self.eng.nx * self.eng.ny * 8
+        self.ctx.check(lib.bdof_memset(h, lib.bdof_grot(h), 0, n))
+
+    def shrink_wrap(self, thresh=1e-15):
+        """mask = mask * (obj_delta > 1e-15)   (cnn_propagator/fullfield.py:365-368, intended behaviour, quirk Q8)."""
+        if self.mask is not None:
+            self.ctx.check(self.ctx.lib.bdof_mask_shrink(self.ctx.handle, self.x[self.cur].ptr, self.mask.ptr, self.nvox, thresh))
+
+
+class FullfieldSolver(_VolumeSolver):
+    def __init__(self, dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm, free_prop_cm=None,
+                 probe_real=None, probe_imag=None, variant='numpy_skip_last', comm=None, device=0, stream=None,
+                 coord_ls=None, propagator='fft', kernel_size=17, recompute=None):
+        """propagator='fft': the transfer-function step of np_funcs.py (north-star path); 'conv': the truncated real-space
+        kernel of propagation.py, what cnn_propagator/fullfield.py:87,102 calls (kernel_size taps per axis)."""
+        self.conv = propagator == 'conv'
+        self.dim_y, self.dim_x, self.dim_z = int(dim_y), int(dim_x), int(dim_z)
+        self.n_theta, self.mb = int(n_theta), int(minibatch_size)
+        self.comm = comm or PseudoComm()
+        self.eng = MultisliceEngine(self.dim_y, self.dim_x, self.dim_z, self.mb, with_grad=True, device=device, stream=stream,
+                                    recompute=recompute)
+        self.ctx = self.eng.ctx
+        self.eng.set_physics(energy_ev, psize_cm, free_prop_cm, variant=variant)
+        if self.conv:
+            self.eng.set_conv(energy_ev, psize_cm, kernel_size)
+        if probe_real is None:
+            probe_real, probe_imag = np.ones((dim_y, dim_x)), np.zeros((dim_y, dim_x))   # 'plane', fullfield.py:276-278
+        self.eng.set_probe(probe_real, probe_imag)
+        # rotation lookup tables (cnn_propagator/util.py:294-347), uploaded once
+        if coord_ls is None:
+            coord_ls = util.rotation_lookup([dim_y, dim_x, dim_z], n_theta)
+        tab, off, order = util.device_rotation_tables(coord_ls, self.dim_x, self.dim_z)
+        self.tab = DeviceBuffer.from_host(self.ctx, tab)
+        self.off = DeviceBuffer.from_host(self.ctx, off)
+        self.order = DeviceBuffer.from_host(self.ctx, order)
+        self._init_volume()
+        self.meas = None
+        self.meas_stage = DeviceBuffer(self.ctx, self.mb * self.dim_x * self.dim_y * 4, np.float32,
+                                       (self.mb, self.dim_x, self.dim_y))
+        self.angle_buf = DeviceBuffer(self.ctx, self.mb * 4, np.int32, (self.mb,))
+        self._bind_volume()
+        self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
+
+    def set_measurements(self, prj_abs):
+        """|prj| for every angle, (n_theta, Y, X) (loss uses np.abs(this_prj_batch), fullfield.py:106)."""
+        self.meas = DeviceBuffer.from_host(self.ctx, self.eng.meas_layout(prj_abs))
 
     # ---- one Adam iteration ------------------------------------------------------------------
     def _stage_batch(self, angle_idx):
@@ -87,15 +258,9 @@ class FullfieldSolver(object):
         idx = np.asarray(angle_idx, dtype=np.int32)
         assert len(idx) == self.mb
         self.angle_buf.upload(idx)
-        per = self.dim_x * self.dim_y * 4
-        for b, j in enumerate(idx):
-            self.ctx.check(lib.bdof_memcpy_d2d(h, self.meas_stage.ptr + b * per, self.meas.ptr + int(j) * per, per))
-
-    def _get_loss(self):
-        import ctypes
-        loss = ctypes.c_double(0)
-        self.ctx.check(self.ctx.lib.bdof_get_loss(self.ctx.handle, ctypes.byref(loss)))
-        return loss.value
+        # this_prj_batch = prj[this_ind_batch] (fullfield.py:344): one gather launch on the resident stack
+        self.ctx.check(lib.bdof_gather_fields(h, self.meas_stage.ptr, self.meas.ptr, self.angle_buf.ptr, self.mb,
+                                              self.dim_x * self.dim_y * 4))
 
     def _rot_loss_grad(self, angle_idx):
         """Forward + adjoint sweeps of this rank's angles: the gradient w.r.t. the rotated objects stays in the ctx."""
@@ -104,109 +269,48 @@ class FullfieldSolver(object):
         fn = lib.bdof_loss_grad_conv if self.conv else lib.bdof_loss_grad
         self.ctx.check(fn(h, self.mb, self.angle_buf.ptr, None, None, self.meas_stage.ptr, None))
 
-    def loss_and_grad(self, angle_idx, want_loss=True):
-        """Data-term loss and its gradient w.r.t. the volume for this rank's angles (left in self.g)."""
+    def _produce(self, accumulate=False):
         lib, h = self.ctx.lib, self.ctx.handle
+
+        def produce(x0, nx):
+            self.ctx.check(lib.bdof_rotation_adjoint_rows(h, self.mb, self.angle_buf.ptr, self.g.ptr, x0 * self.dim_z,
+                                                          nx * self.dim_z, int(accumulate), 1.0))
+        return produce
+
+    def loss_and_grad(self, angle_idx, want_loss=True):
+        """Data-term loss and its gradient w.r.t. the volume for this rank's angles (left in self.g, not reduced)."""
         self._rot_loss_grad(angle_idx)
-        self.ctx.check(lib.bdof_rotation_adjoint(h, self.mb, self.angle_buf.ptr, self.g.ptr, 0, 1.0))
+        self._produce()(0, self.dim_x)
         return self._get_loss() if want_loss else None
 
-    def adam_update(self, i_batch, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, clip=True, use_mask=True, slab=None,
-                    flip=True):
-        new = 1 - self.cur
-        self.eng.adam_step(self.x[self.cur], self.x[new], self.g, self.m, self.v, self.mask if use_mask else None,
-                           (self.dim_x, self.dim_z, self.dim_y), i_batch, learning_rate, g_scale=1.0 / self.comm.size,
-                           alpha_d=alpha_d, alpha_b=alpha_b, gamma=gamma, clip=clip, slab=slab)
-        if flip:
-            self.cur = new
-            self._bind_volume()
+    def adam_update(self, i_batch, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, clip=True, use_mask=True):
+        """Regulariser + Adam on the gradient in self.g (whole volume, no exchange)."""
+        self._adam_slab(i_batch, learning_rate, alpha_d, alpha_b, gamma, clip, use_mask, None, 1.0 / self.comm.size)
+        self._flip()
 
-    def slab_bounds(self, n_slabs):
-        """x-plane ranges [(x0, nx)] of n_slabs nearly equal slabs of the [X][Z][Y] volume."""
-        n_slabs = max(1, min(int(n_slabs), self.dim_x))
-        edges = [(self.dim_x * i) // n_slabs for i in range(n_slabs + 1)]
-        return [(edges[i], edges[i + 1] - edges[i]) for i in range(n_slabs)]
-
-    def _tail(self, i_batch, learning_rate, alpha_d, alpha_b, gamma, n_slabs, flip=True):
-        """Rotation adjoint -> all-reduce -> regulariser + Adam, whole volume (n_slabs <= 1) or pipelined over x-slabs."""
-        lib, h = self.ctx.lib, self.ctx.handle
-        reduce = self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)
-        if not reduce or n_slabs <= 1:
-            self.ctx.check(lib.bdof_rotation_adjoint(h, self.mb, self.angle_buf.ptr, self.g.ptr, 0, 1.0))
-            if reduce:
-                self.comm.allreduce_sum_device(self.g, stream_sync=self.ctx.sync)
-            self.adam_update(i_batch, learning_rate, alpha_d, alpha_b, gamma, flip=flip)
-            return
-        slabs = self.slab_bounds(n_slabs)
-        per_x = self.dim_z * self.dim_y * 2               # floats per x-plane of the gradient
-        bounds = [s[0] * per_x for s in slabs] + [self.dim_x * per_x]
-
-        def produce(c):
-            x0, nx = slabs[c]
-            self.ctx.check(lib.bdof_rotation_adjoint_rows(h, self.mb, self.angle_buf.ptr, self.g.ptr, x0 * self.dim_z,
-                                                          nx * self.dim_z, 0, 1.0))
-
-        def consume(c):
-            self.adam_update(i_batch, learning_rate, alpha_d, alpha_b, gamma, slab=slabs[c], flip=False)
-
-        self.comm.pipelined_allreduce(self.g, bounds, produce, consume, stream_ptr=self.eng.stream_ptr())
-        if flip:
-            self.cur = 1 - self.cur
-            self._bind_volume()
-
-    def default_slabs(self):
-        if self._n_slabs is None:
-            reduce = self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)
-            self._n_slabs = int(os.environ.get('BDOF_ALLREDUCE_SLABS', '8')) if reduce else 1
-        return self._n_slabs
-
-    def tune_allreduce(self, candidates=(1, 8), reps=2):
-        """Pick the number of slabs of the pipelined tail by timing it on this machine and process layout (the collective,
-        the streams it runs on and the kernels either side interact in ways that differ between runtimes).  Dry run: the
-        gradient buffer and the Adam moments are scratch afterwards (the moments are zeroed again), the volume is not
-        touched.  Every rank takes the same decision (max of the timings over ranks).  Call before the epoch loop."""
-        import time
-        reduce = self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)
-        if not reduce or os.environ.get('BDOF_ALLREDUCE_SLABS'):
-            return self.default_slabs()
+    def _dry_tail(self, n_slabs, sharded):
         self.angle_buf.upload(np.arange(self.mb, dtype=np.int32) % self.n_theta)
-        times = []
-        for n in candidates:
-            self._tail(0, 0.0, 0.0, 0.0, 0.0, n, flip=False)             # first use: communicator / stream set-up
-            self.ctx.sync()
-            self.comm.Barrier()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                self._tail(0, 0.0, 0.0, 0.0, 0.0, n, flip=False)
-            self.ctx.sync()
-            times.append(time.perf_counter() - t0)
-        worst = self.comm.allreduce_max_host(np.array(times))
-        self._n_slabs = int(candidates[int(np.argmin(worst))])
-        self.tuned = dict(zip([int(c) for c in candidates], [float(t) / reps for t in worst]))
-        self.reset_moments()
-        return self._n_slabs
+        self._tail(self._produce(), 0, 0.0, n_slabs=n_slabs, sharded=sharded, flip=False)
 
-    def step(self, i_batch, angle_idx, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, want_loss=False, n_slabs=None):
+    def step(self, i_batch, angle_idx, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, want_loss=False, n_slabs=None,
+             sharded=None, use_mask=True, clip=True, n_batch_per_update=1, last_of_epoch=False):
         """grads = loss_grad(...); Allreduce; /size; Adam; mask; clip   (fullfield.py:345-362).
 
-        With more than one rank the tail of the step is pipelined over x-slabs of the volume: rotation adjoint of slab
-        c -> all-reduce of slab c (RCCL, asynchronous) -> regulariser + Adam of slab c, so that the 8 B/voxel collective
-        overlaps the kernels either side of it (the TV stencil reads the pre-update volume, which no slab overwrites).
-        Slab-wise and whole-volume execution give identical results."""
-        if n_slabs is None:
-            n_slabs = self.default_slabs()
+        n_batch_per_update > 1 (tensorflow_recon/fullfield.py:413-425,512-530): the volume gradient of consecutive
+        minibatches is accumulated and applied (averaged) every n-th minibatch or at the last one of the epoch; the Adam
+        bias-correction exponent then counts updates, not minibatches."""
         self._rot_loss_grad(angle_idx)
-        self._tail(i_batch, learning_rate, alpha_d, alpha_b, gamma, n_slabs)
+        nb = max(1, int(n_batch_per_update))
+        if nb > 1:
+            self._produce(accumulate=self._acc > 0)(0, self.dim_x)
+            self._acc += 1
+            if self._acc == nb or last_of_epoch:
+                n_acc, self._acc = self._acc, 0
+                self._tail(lambda x0, nx: None, i_batch // nb, learning_rate, alpha_d, alpha_b, gamma, clip, use_mask, n_slabs,
+                           sharded, n_acc=n_acc)
+        else:
+            self._tail(self._produce(), i_batch, learning_rate, alpha_d, alpha_b, gamma, clip, use_mask, n_slabs, sharded)
         return self._get_loss() if want_loss else None
-
-    def shrink_wrap(self, thresh=1e-15):
-        """mask = mask * (obj_delta > 1e-15)   (cnn_propagator/fullfield.py:365-368, intended behaviour, quirk Q8)."""
-        if self.mask is not None:
-            self.ctx.check(self.ctx.lib.bdof_mask_shrink(self.ctx.handle, self.x[self.cur].ptr, self.mask.ptr, self.nvox, thresh))
-
-    def gradient_to_host(self):
-        self.ctx.sync()
-        return util.rows_to_volume(self.g.download())
 
     def forward_angles(self, angle_idx):
         """Detector waves (len(idx), Y, X) of the current volume — the forward_pass of fullfield.py:79-91."""
@@ -218,7 +322,7 @@ class FullfieldSolver(object):
         return np.concatenate(out, axis=0)
 
 
-class PtychoSolver(object):
+class PtychoSolver(_VolumeSolver):
     """Device-resident state of a ptychographic reconstruction (cnn_propagator/ptychography.py:285-310): volume,
     Adam moments, rotation tables, all diffraction amplitudes; windows are cut by index math inside the kernels."""
 
@@ -248,32 +352,12 @@ class PtychoSolver(object):
         self.tab = DeviceBuffer.from_host(self.ctx, tab)
         self.off = DeviceBuffer.from_host(self.ctx, off)
         self.order = DeviceBuffer.from_host(self.ctx, order)
-        shape = (self.dim_x, self.dim_z, self.dim_y, 2)
-        self.x = [DeviceBuffer.zeros(self.ctx, shape, np.float32), DeviceBuffer.zeros(self.ctx, shape, np.float32)]
-        self.cur = 0
-        self.g = DeviceBuffer.zeros(self.ctx, shape, np.float32)
-        self.m = DeviceBuffer.zeros(self.ctx, shape, np.float32)
-        self.v = DeviceBuffer.zeros(self.ctx, shape, np.float32)
+        self._init_volume()
         self.meas_stage = DeviceBuffer(self.ctx, self.mb * self.py * self.px * 4, np.float32, (self.mb, self.py, self.px))
         self.idx_buf = DeviceBuffer(self.ctx, 3 * self.mb * 4, np.int32, (3, self.mb))
         self._bind_volume()
         self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
-
-    def _bind_volume(self):
-        self.eng.set_volume(self.x[self.cur], self.dim_x * self.dim_z, self.dim_y, self.tab, self.dim_x, self.n_theta)
-
-    def set_volume(self, obj_delta, obj_beta):
-        self.x[self.cur].upload(util.volume_to_rows(obj_delta, obj_beta))
-        self._bind_volume()
-
-    def get_volume(self):
-        self.ctx.sync()
-        return util.rows_to_volume(self.x[self.cur].download())
-
-    def reset_moments(self):
-        lib, h = self.ctx.lib, self.ctx.handle
-        self.ctx.check(lib.bdof_memset(h, self.m.ptr, 0, self.m.nbytes))
-        self.ctx.check(lib.bdof_memset(h, self.v.ptr, 0, self.v.nbytes))
+        self._last = None
 
     def _stage(self, i_theta, pos_idx, prj_abs_batch):
         pos = self.probe_pos[np.asarray(pos_idx)]
@@ -286,19 +370,34 @@ class PtychoSolver(object):
         p = self.idx_buf.ptr
         return p, p + 4 * self.mb, p + 8 * self.mb
 
-    def loss_and_grad(self, i_theta, pos_idx, prj_abs_batch, want_loss=True):
-        """prj_abs_batch: |this_prj_batch| (mb, py, px) for probe positions pos_idx at angle i_theta."""
-        import ctypes
+    def _win_loss_grad(self, i_theta, pos_idx, prj_abs_batch):
         lib, h = self.ctx.lib, self.ctx.handle
         a, xo, yo = self._stage(i_theta, pos_idx, prj_abs_batch)
         fn = lib.bdof_loss_grad_conv if self.conv else lib.bdof_loss_grad
         self.ctx.check(fn(h, self.mb, a, xo, yo, self.meas_stage.ptr, None))
-        self.ctx.check(lib.bdof_window_rotation_adjoint(h, self.mb, int(i_theta), xo, yo, self.g.ptr, 0, 1.0))
-        if want_loss:
-            loss = ctypes.c_double(0)
-            self.ctx.check(lib.bdof_get_loss(h, ctypes.byref(loss)))
-            return loss.value
-        return None
+        self._last = (int(i_theta), xo, yo)
+
+    def _produce_all(self):
+        lib, h = self.ctx.lib, self.ctx.handle
+        i_theta, xo, yo = self._last
+        self.ctx.check(lib.bdof_window_rotation_adjoint(h, self.mb, i_theta, xo, yo, self.g.ptr, 0, 1.0))
+
+    def loss_and_grad(self, i_theta, pos_idx, prj_abs_batch, want_loss=True):
+        """prj_abs_batch: |this_prj_batch| (mb, py, px) for probe positions pos_idx at angle i_theta."""
+        self._win_loss_grad(i_theta, pos_idx, prj_abs_batch)
+        self._produce_all()
+        return self._get_loss() if want_loss else None
+
+    def _dry_tail(self, n_slabs, sharded):
+        self._tail(lambda x0, nx: None, 0, 0.0, n_slabs=n_slabs, sharded=sharded, flip=False, use_mask=False)
+
+    def step(self, i_batch, i_theta, pos_idx, prj_abs_batch, learning_rate, want_loss=False, n_slabs=None, sharded=None, clip=True):
+        """One Adam iteration of ptychography.py:301-310: loss_grad, Allreduce, /size, Adam, clip (no regulariser, no mask).
+        The window/rotation adjoint produces the whole volume gradient in one pass; exchange and Adam are still slab-wise."""
+        self._win_loss_grad(i_theta, pos_idx, prj_abs_batch)
+        self._produce_all()
+        self._tail(lambda x0, nx: None, i_batch, learning_rate, clip=clip, use_mask=False, n_slabs=n_slabs, sharded=sharded)
+        return self._get_loss() if want_loss else None
 
     def forward(self, i_theta, pos_idx):
         pos = self.probe_pos[np.asarray(pos_idx)]
@@ -306,12 +405,5 @@ class PtychoSolver(object):
                                 yoff=pos[:, 0] - self.half[0], conv=self.conv)
 
     def adam_update(self, i_batch, learning_rate, clip=True):
-        new = 1 - self.cur
-        self.eng.adam_step(self.x[self.cur], self.x[new], self.g, self.m, self.v, None, (self.dim_x, self.dim_z, self.dim_y),
-                           i_batch, learning_rate, g_scale=1.0 / self.comm.size, clip=clip)
-        self.cur = new
-        self._bind_volume()
-
-    def gradient_to_host(self):
-        self.ctx.sync()
-        return util.rows_to_volume(self.g.download())
+        self._adam_slab(i_batch, learning_rate, 0.0, 0.0, 0.0, clip, False, None, 1.0 / self.comm.size)
+        self._flip()

@@ -102,21 +102,40 @@ def rotation_lookup(array_size, n_theta):
 
 
 def save_rotation_lookup(array_size, n_theta, dest_folder=None):
-    """Drop-in for cnn_propagator/util.py:294-347: writes the same .npy files and returns the tables."""
+    """Drop-in for cnn_propagator/util.py:294-347: writes the same .npy files and returns the tables.  The folder appears
+    atomically (written under a temporary name, then renamed), so a concurrent reader never sees half of it."""
     coords = rotation_lookup(array_size, n_theta)
     if dest_folder is None:
         dest_folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(array_size[0], array_size[1], array_size[2], n_theta)
-    if not os.path.exists(dest_folder):
-        os.mkdir(dest_folder)
+    tmp = '{}.tmp{}'.format(dest_folder.rstrip('/'), os.getpid())
+    os.makedirs(tmp, exist_ok=True)
     for i, arr in enumerate(coords):
-        np.save(os.path.join(dest_folder, '{:04}'.format(i)), arr)
+        np.save(os.path.join(tmp, '{:04}'.format(i)), arr)
     ny, nx, nz = [int(a) for a in array_size]
     coord0 = np.repeat(np.arange(ny), nx * nz)
     coord1 = np.tile(np.repeat(np.arange(nx), nz), ny).astype(float)
     coord2 = np.tile(np.tile(np.arange(nz), nx), ny).astype(float)
     for i, coord in enumerate([coord0, coord1, coord2]):
-        np.save(os.path.join(dest_folder, 'coord{}_vec'.format(i)), coord)
+        np.save(os.path.join(tmp, 'coord{}_vec'.format(i)), coord)
+    if os.path.isdir(dest_folder):                      # refresh an existing (possibly incomplete) folder file by file
+        for f in os.listdir(tmp):
+            os.replace(os.path.join(tmp, f), os.path.join(dest_folder, f))
+        os.rmdir(tmp)
+    else:
+        os.rename(tmp, dest_folder)
     return coords
+
+
+def rotation_lookup_files(array_size, n_theta, comm):
+    """The tables of the run, through the reference's files (cnn_propagator/fullfield.py:209-215, ptychography.py:149-158):
+    rank 0 writes the folder if it is missing or incomplete, EVERY rank passes the same barrier, then every rank reads."""
+    folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(array_size[0], array_size[1], array_size[2], n_theta)
+    if comm.rank == 0:
+        complete = all(os.path.exists(os.path.join(folder, '{:04}.npy'.format(i))) for i in range(n_theta))
+        if not complete:
+            save_rotation_lookup(array_size, n_theta, folder)
+    comm.Barrier()
+    return read_all_origin_coords(folder, n_theta)
 
 
 def read_all_origin_coords(src_folder, n_theta):

@@ -151,6 +151,10 @@ int bdof_adam_step_slab(bdof_ctx* ctx, const void* x_old, void* x_new, const voi
                         int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
                         float lr, float b1, float b2, float eps, int i_batch, int clip, int x0, int nx);
 
+/* dst[b] = src[idx[b]] for B fields of bytes_per_field bytes (a multiple of 16; idx: device int32 [B]) in one launch:
+ * this_prj_batch = prj[this_ind_batch] (cnn_propagator/fullfield.py:344) on the device-resident stack of amplitudes. */
+int bdof_gather_fields(bdof_ctx* ctx, void* dst, const void* src, const int* idx, int B, size_t bytes_per_field);
+
 /* Shrink-wrap (cnn_propagator/fullfield.py:365-368): mask[i] *= (delta[i] > thresh) over n voxels. */
 int bdof_mask_shrink(bdof_ctx* ctx, const void* x, float* mask, size_t n, float thresh);
 
@@ -167,7 +171,40 @@ int bdof_batch_groups(bdof_ctx* ctx, int B);
 int bdof_profile_enable(bdof_ctx* ctx, int enable);
 int bdof_profile_read(bdof_ctx* ctx, int kernel_class, int* n_launches, double* total_ms);
 
-/* Device memory helpers for hosts without an allocator of their own. */
+/* ---- Collectives: the gradient exchange of the data-parallel loop ------------------------------------------------
+ * Replaces comm.Allreduce(this_grads, grads) (mpi4py, host float64 buffers: cnn_propagator/fullfield.py:348-351,
+ * ptychography.py:302-306) with RCCL over xGMI on device float32 buffers, one process per GPU.  librccl is opened at
+ * run time by the first bdof_comm_* call; single-GPU use never loads it.
+ *   bdof_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId); the host hands it to every rank over any
+ *                         channel it likes (the Python host: a unix-domain socket rendezvous, comm.py);
+ *   bdof_comm_create      ncclCommInitRank on `device` (collective: every rank calls it);
+ *   bdof_allreduce_grad   in-place SUM of `count` floats;
+ *   bdof_reduce_scatter_grad / bdof_allgather_volume   in place on a buffer of nranks * count_per_rank floats: after the
+ *                         reduce-scatter rank r holds the sum in its part [r*count, (r+1)*count); the all-gather
+ *                         distributes every rank's part — the "reduce-scatter -> Adam on 1/N -> all-gather" form of
+ *                         the step, same wire bytes as the all-reduce and 1/N of the Adam traffic;
+ *   bdof_bcast_volume     in-place broadcast from `root` (initial guess of rank 0, ptychography.py:169-208).
+ * Every collective runs on the communicator's own stream, ordered BEHIND the work the ctx stream holds at the call, and
+ * returns a ticket; bdof_comm_wait(comm, ctx, ticket) makes the ctx stream wait for it (stream-side, no host block), so
+ * kernels enqueued between the two calls overlap the transfer.  Tickets are a ring of 256.  Errors: 1000 + ncclResult_t,
+ * text via bdof_comm_last_error (NULL: the error of a failed create / unique_id). */
+typedef struct bdof_comm bdof_comm;
+int bdof_comm_unique_id(void* id, size_t bytes);
+int bdof_comm_create(bdof_comm** out, int device, int nranks, int rank, const void* id, size_t bytes);
+void bdof_comm_destroy(bdof_comm* comm);
+const char* bdof_comm_last_error(const bdof_comm* comm);
+int bdof_comm_size(const bdof_comm* comm);
+int bdof_comm_rank(const bdof_comm* comm);
+int bdof_allreduce_grad(bdof_comm* comm, bdof_ctx* ctx, void* buf, size_t count, int* ticket);
+int bdof_reduce_scatter_grad(bdof_comm* comm, bdof_ctx* ctx, void* buf, size_t count_per_rank, int* ticket);
+int bdof_allgather_volume(bdof_comm* comm, bdof_ctx* ctx, void* buf, size_t count_per_rank, int* ticket);
+int bdof_bcast_volume(bdof_comm* comm, bdof_ctx* ctx, void* buf, size_t count, int root, int* ticket);
+int bdof_comm_wait(bdof_comm* comm, bdof_ctx* ctx, int ticket);
+int bdof_comm_sync(bdof_comm* comm);
+
+/* Device memory helpers for hosts without an allocator of their own.  bdof_malloc allocates on the calling thread's
+ * current device, bdof_ctx_malloc on the ctx's device. */
+int bdof_ctx_malloc(bdof_ctx* ctx, void** ptr, size_t bytes);
 int bdof_malloc(void** ptr, size_t bytes);
 int bdof_free(void* ptr);
 int bdof_memcpy_h2d(bdof_ctx* ctx, void* dst, const void* src, size_t bytes);

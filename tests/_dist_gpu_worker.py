@@ -19,10 +19,12 @@ def problem():
 
 
 def main(out_dir):
-    from beyond_dof_amd.comm import TorchComm, minibatch_schedule
+    from beyond_dof_amd.comm import TorchComm, get_comm, minibatch_schedule
     from beyond_dof_amd.solver import FullfieldSolver
     from beyond_dof_amd import util
-    comm = TorchComm('gloo')
+    comm = get_comm()                      # BDOF_COMM_BACKEND=gloo in the environment
+    assert isinstance(comm, TorchComm)
+    sharded = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
     n, n_theta, mb, meas, init_d = problem()
     coords = util.rotation_lookup([n, n, n], n_theta)
     s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, coord_ls=coords, comm=comm, device=0)
@@ -33,10 +35,10 @@ def main(out_dir):
     losses = []
     for i, chunk in enumerate(sched):
         mine = chunk[comm.rank * mb:(comm.rank + 1) * mb]
-        losses.append(s.step(i, mine, 1e-7, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11, want_loss=True, n_slabs=4))
+        losses.append(s.step(i, mine, 1e-7, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11, want_loss=True, n_slabs=4, sharded=sharded))
     g = s.gradient_to_host()
     d, b = s.get_volume()
-    np.savez(os.path.join(out_dir, 'rank{}.npz'.format(comm.rank)), d=d, b=b, gd=g[0], gb=g[1], losses=np.array(losses),
+    np.savez(os.path.join(out_dir, 'rank{}_{}.npz'.format(comm.rank, int(sharded))), d=d, b=b, gd=g[0], gb=g[1], losses=np.array(losses),
              sched=np.array(sched))
     comm.Barrier()
     comm.close()

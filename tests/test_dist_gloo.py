@@ -1,4 +1,4 @@
-"""Multi-rank path on CPU: 2 processes, gloo.  Each rank produces the gradient of ITS angles (here with the
+"""Multi-rank path on CPU: 2 processes.  (a) gloo:  Each rank produces the gradient of ITS angles (here with the
 oracle, the GPU is not needed to test the exchange), the volume gradient is SUM-all-reduced through
 beyond_dof_amd.comm.TorchComm and divided by size exactly as the solver does; the result must equal the
 single-rank gradient of the union minibatch (cnn_propagator/fullfield.py:343-351)."""
@@ -45,27 +45,22 @@ def _worker(rank, world, port, out_dir):
     _, gd, gb = orc.fullfield_loss_and_grad(od, ob, coords, mine, prj[mine], one, zero, 5000., 1e-7, free_prop_cm=1e-4,
                                             with_reg=False)
     g = torch.from_numpy(np.stack([gd, gb]))
-    comm.allreduce_sum_device(g)
+    comm.allreduce_sum_device(None, g)
     g = g.numpy() / comm.size
-    # the slab pipeline of FullfieldSolver.step: produce slab c, all-reduce it, consume it — same result, fixed order
-    g2 = torch.zeros(g.size, dtype=torch.float64)
+    # the collectives of the solver's sharded tail on a slab [lo, lo + size*per): reduce-scatter leaves this rank's part
+    # summed, the all-gather hands every rank's part to all — together they equal the all-reduce
     src = torch.from_numpy(np.stack([gd, gb])).reshape(-1)
-    bounds = [0, 100, 101, 700, g2.numel()]
-    log, seen = [], []
-
-    def produce(c):
-        log.append(('p', c))
-        g2[bounds[c]:bounds[c + 1]] = src[bounds[c]:bounds[c + 1]]
-
-    def consume(c):
-        log.append(('c', c))
-        seen.append(g2[bounds[c]:bounds[c + 1]].clone())
-
-    comm.pipelined_allreduce(g2, bounds, produce, consume)
-    assert [e for e in log if e[0] == 'p'] == [('p', c) for c in range(4)]
-    assert [e for e in log if e[0] == 'c'] == [('c', c) for c in range(4)]
-    assert all(log.index(('p', c)) < log.index(('c', c)) for c in range(4))
-    assert np.array_equal(torch.cat(seen).numpy() / comm.size, g.reshape(-1))
+    g2 = src.clone()
+    lo, per = 96, 200
+    assert comm.start_reduce_scatter(None, g2, lo, per) is None
+    mine_lo = lo + rank * per
+    assert np.array_equal(g2[mine_lo:mine_lo + per].numpy() / comm.size, g.reshape(-1)[mine_lo:mine_lo + per])
+    g3 = torch.full_like(src, -7.0)
+    g3[mine_lo:mine_lo + per] = g2[mine_lo:mine_lo + per]
+    comm.start_allgather(None, g3, lo, per)
+    comm.wait(None, None)
+    assert np.array_equal(g3[lo:lo + world * per].numpy() / comm.size, g.reshape(-1)[lo:lo + world * per])
+    assert float(g3[0]) == -7.0 and float(g3[lo + world * per]) == -7.0          # nothing outside the slab is touched
     loss_sum = comm.allreduce_sum_host(np.array([float(rank + 1)]))
     idx = comm.bcast_host(np.arange(4) if rank == 0 else np.zeros(4, dtype=np.int64), root=0)
     comm.Barrier()
@@ -100,3 +95,55 @@ def test_single_rank_fallback():
     c.Barrier()
     x = np.arange(3.0)
     assert c.allreduce_sum_host(x) is x
+
+
+# ---- control plane of the native (RCCL) path: unix-socket rendezvous + host collectives, no GPU needed ----------------
+def _socket_worker(rank, world, path, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), BDOF_RDZV=path)
+    from beyond_dof_amd.comm import RcclComm, get_comm
+    comm = get_comm()
+    assert isinstance(comm, RcclComm) and comm.size == world and comm.rank == rank and comm.backend == 'rccl'
+    tot = comm.allreduce_sum_host(np.array([rank + 1.0, 10.0 * (rank + 1)]))
+    mx = comm.allreduce_max_host(np.array([float(rank), -float(rank)]))
+    big = comm.bcast_host(np.arange(300000, dtype=np.float64) if rank == 0 else None, root=0)      # > one socket buffer
+    uid = comm.group.bcast(b'x' * 128 if rank == 0 else None)
+    where = comm.group.allgather(('host', rank))
+    comm.Barrier()
+    np.savez(os.path.join(out_dir, 'sock{}.npz'.format(rank)), tot=tot, mx=mx, big_sum=big.sum(), uid_len=len(uid),
+             where=np.array([w[1] for w in where]))
+    comm.close()
+
+
+@pytest.mark.timeout(120)
+def test_socket_rendezvous_and_host_collectives(tmp_path):
+    world = 3
+    path = str(tmp_path / 'rdzv.sock')
+    open(path, 'w').close()                       # a stale file of a dead job must not be in the way
+    mp.spawn(_socket_worker, args=(world, path, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        d = np.load(str(tmp_path / 'sock{}.npz'.format(r)))
+        assert np.array_equal(d['tot'], [6.0, 60.0]) and np.array_equal(d['mx'], [2.0, 0.0])
+        assert d['big_sum'] == 300000 * 299999 / 2 and d['uid_len'] == 128 and np.array_equal(d['where'], [0, 1, 2])
+    assert not os.path.exists(path)               # rank 0 removes the socket file once everyone is connected
+
+
+def test_solver_tail_plan_without_a_gpu():
+    """Which form of the exchange a volume of dim_x planes takes (solver._VolumeSolver.tail_plan): pure host logic."""
+    from beyond_dof_amd.solver import _VolumeSolver
+
+    class C(object):
+        size, rank, sharded = 8, 0, True
+
+    s = _VolumeSolver.__new__(_VolumeSolver)
+    s.comm, s._plan = C(), None
+    for dim_x, want in ((512, (8, True)), (64, (8, True)), (72, (3, True)), (48, (6, True)), (8, (1, True)), (20, (8, False)), (7, (7, False))):
+        s.dim_x = dim_x
+        got = s.tail_plan()
+        if want[1]:
+            assert got == want, (dim_x, got)
+            assert dim_x % (got[0] * 8) == 0
+        else:
+            assert got[1] is False
+    s.dim_x = 512
+    assert s.tail_plan(n_slabs=3, sharded=False) == (3, False)
+    assert sum(nx for _, nx in s.slab_bounds(3)) == 512

@@ -1,6 +1,7 @@
-"""Two ranks, one GPU: the N-rank Adam step (angle-sharded minibatch, slab-pipelined rotation adjoint -> all-reduce ->
-Adam) against the single-rank step on the union minibatch.  gloo carries the collective because RCCL does not accept two
-ranks on one device; the RCCL flavour of the same pipeline runs on one rank in test_gpu_fullfield.py."""
+"""Two ranks, one GPU: the N-rank Adam step (angle-sharded minibatch, slab-pipelined rotation adjoint -> exchange ->
+Adam, in the all-reduce and in the reduce-scatter / sharded-Adam / all-gather form) against the single-rank step on the
+union minibatch.  gloo carries the collective because RCCL does not accept two ranks on one device; the RCCL flavour of
+the same pipeline (the library's own communicator) runs on one rank in test_gpu_fullfield.py."""
 import os
 import socket
 import subprocess
@@ -22,17 +23,13 @@ def _free_port():
     return port
 
 
-def test_two_ranks_on_one_gpu_match_the_union_minibatch(tmp_path):
-    import __graft_entry__ as entry
-    entry.build()
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
-    import _dist_gpu_worker as w
+def _run_two_ranks(tmp_path, sharded):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
-                   LOCAL_RANK=str(rank))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_dist_gpu_worker.py'), str(tmp_path)],
+                   LOCAL_RANK=str(rank), BDOF_COMM_BACKEND='gloo')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_dist_gpu_worker.py'), str(tmp_path), str(int(sharded))],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:
@@ -43,10 +40,22 @@ def test_two_ranks_on_one_gpu_match_the_union_minibatch(tmp_path):
                 q.kill()
             raise
     assert all(p.returncode == 0 for p in procs), '\n'.join(o[-3000:] for o in outs)
-    r0, r1 = np.load(str(tmp_path / 'rank0.npz')), np.load(str(tmp_path / 'rank1.npz'))
+    return [np.load(str(tmp_path / 'rank{}_{}.npz'.format(r, int(sharded)))) for r in range(2)]
+
+
+def test_two_ranks_on_one_gpu_match_the_union_minibatch(tmp_path):
+    import __graft_entry__ as entry
+    entry.build()
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import _dist_gpu_worker as w
+    r0, r1 = _run_two_ranks(tmp_path, sharded=False)
     # every rank ends with the same volume, bit for bit (same reduced gradient, same Adam)
     assert np.array_equal(r0['d'], r1['d']) and np.array_equal(r0['b'], r1['b'])
     assert np.array_equal(r0['gd'], r1['gd'])
+    # reduce-scatter -> Adam on this rank's half of every slab -> all-gather: the same volume as the all-reduce form
+    s0, s1 = _run_two_ranks(tmp_path, sharded=True)
+    assert np.array_equal(s0['d'], s1['d']) and np.array_equal(s0['b'], s1['b'])
+    assert np.array_equal(s0['d'], r0['d']) and np.array_equal(s0['b'], r0['b'])
 
     # single rank, union minibatch (cnn_propagator/fullfield.py:343-351: the ranks' chunks tile the sorted minibatch)
     from beyond_dof_amd import util
@@ -75,17 +84,39 @@ def test_two_ranks_on_one_gpu_match_the_union_minibatch(tmp_path):
 
 
 def test_bench_py_two_rank_rehearsal(tmp_path):
-    """bench.py's own N-rank path (sharded schedule, tune_allreduce on two ranks, max-over-ranks timing, one JSON line from
-    rank 0) with two ranks sharing the GPU and gloo as the collective backend (tools/rehearse_2ranks.sh)."""
+    """Plain `python bench.py --gpus 2`: the parent starts the two ranks itself (no launcher, no RANK / WORLD_SIZE in its
+    environment), sharded schedule, tuned exchange, max-over-ranks timing, exactly one JSON line from rank 0.  The two
+    ranks share this box's one GPU, so gloo carries the collective (BDOF_COMM_BACKEND=gloo); everything else is what an
+    N-GPU run executes."""
     import json
-    env = dict(os.environ, MASTER_PORT=str(_free_port()))
-    r = subprocess.run([os.path.join(ROOT, 'tools', 'rehearse_2ranks.sh'), '--size', '64', '--angles-per-gpu', '4', '--n-theta', '16',
-                        '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE,
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env['BDOF_COMM_BACKEND'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '64', '--angles-per-gpu', '4',
+                        '--n-theta', '16', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
     assert len(lines) == 1                                           # exactly one JSON line on stdout
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['value'] > 0 and d['scaling'] == 'weak'
-    assert d['config']['global_batch_angles'] == 8 and d['config']['allreduce_slabs'] in (1, 8)
-    assert np.isfinite(d['final_loss'])
+    assert d['config']['global_batch_angles'] == 8 and d['config']['allreduce_slabs'] in (1, 8) and d['config']['sharded_adam']
+    assert d['config']['exchange'].startswith('gloo') and np.isfinite(d['final_loss'])
+    assert d['roofline'] is not None and d['roofline']['frac'] > 0
+
+
+def test_bench_py_single_rank_matches_contract():
+    """`python bench.py` (N = 1): one JSON line with roofline + cpu_baseline, no collective."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--size', '64', '--angles-per-gpu', '4', '--n-theta', '16',
+                        '--steps', '2', '--warmup', '1', '--cpu-slices', '8'], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['config']['exchange'].startswith('none') and d['vs_baseline'] is None
+    ro = d['roofline']
+    assert ro['bound'] == 'hbm' and abs(ro['frac'] - ro['achieved'] / ro['peak']) < 1e-12
+    assert abs(ro['achieved'] * 1e9 - ro['algorithmic_bytes_per_launch'] / (ro['avg_launch_ms_events'] * 1e-3)) <= 1e-6 * ro['achieved'] * 1e9
+    assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 0

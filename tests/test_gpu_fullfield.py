@@ -90,13 +90,15 @@ def test_reconstruct_fullfield_end_to_end(tmp_path, monkeypatch):
 
 
 class _LoopbackComm(object):
-    """One rank that still runs the reduce branch of FullfieldSolver.step (through PseudoComm's slab loop)."""
-    size, rank, local_rank, always_reduce = 1, 0, 0, True
+    """One rank that still runs the exchange branch of the solver's tail (slab loop, sharded Adam, all-gather calls) with
+    collectives that are the identity — what they are on a single rank."""
+    size, rank, local_rank, always_reduce, sharded, backend = 1, 0, 0, True, True, 'loopback'
 
     def __init__(self):
-        from beyond_dof_amd.comm import PseudoComm
-        self._p = PseudoComm()
         self.calls = []
+
+    def attach(self, ctx):
+        pass
 
     def Barrier(self):
         pass
@@ -104,14 +106,17 @@ class _LoopbackComm(object):
     def allreduce_max_host(self, arr):
         return arr
 
-    def allreduce_sum_device(self, buf, stream_sync=None):
-        if stream_sync is not None:
-            stream_sync()
-        return buf
+    def start_allreduce(self, ctx, buf, lo, hi):
+        self.calls.append(('ar', lo, hi))
 
-    def pipelined_allreduce(self, buf, bounds, produce, consume, stream_ptr=0, lookahead=2):
-        self.calls.append(list(bounds))
-        return self._p.pipelined_allreduce(buf, bounds, produce, consume, stream_ptr, lookahead)
+    def start_reduce_scatter(self, ctx, buf, lo, per):
+        self.calls.append(('rs', lo, per))
+
+    def start_allgather(self, ctx, buf, lo, per):
+        self.calls.append(('ag', lo, per))
+
+    def wait(self, ctx, ticket):
+        pass
 
 
 def _two_steps(solver, sched, **kw):
@@ -121,7 +126,7 @@ def _two_steps(solver, sched, **kw):
     return solver.get_volume()
 
 
-def _slab_case(comm, check_calls=False):
+def _slab_case(comm):
     from beyond_dof_amd.solver import FullfieldSolver
     rng = np.random.default_rng(1)
     n, n_theta, mb = 64, 8, 4
@@ -130,52 +135,60 @@ def _slab_case(comm, check_calls=False):
     init_d = np.clip(rng.normal(8.7e-7, 1e-7, size=(n, n, n)), 0, None)
     sched = [np.arange(0, 4), np.arange(4, 8)]
     vols = []
-    for n_slabs, c in ((1, None), (5, comm), (64, comm)):
+    for n_slabs, sharded, c in ((1, False, None), (5, False, comm), (64, False, comm), (8, True, comm), (1, True, comm)):
         s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, coord_ls=coords, comm=c)
         s.set_measurements(meas)
         s.set_volume(init_d, 0.1 * init_d)
-        vols.append(_two_steps(s, sched, n_slabs=n_slabs))
+        vols.append(_two_steps(s, sched, n_slabs=n_slabs, sharded=sharded))
     for v in vols[1:]:
         assert np.array_equal(v[0], vols[0][0]) and np.array_equal(v[1], vols[0][1])
     assert not np.array_equal(vols[0][0], init_d)
-    # the tuner times both forms of the tail in a dry run: it must pick one of them and leave the volume alone
+    # the tuner times the candidate plans of the tail in a dry run: it must pick one of them and leave the volume alone
     before = s.get_volume()
     n_calls = len(getattr(comm, 'calls', []))
-    assert s.tune_allreduce(candidates=(1, 8)) in (1, 8) and set(s.tuned) == {1, 8}
+    plan = s.tune_tail(candidates=(1, 8))
+    assert plan in ((1, True), (8, True)) and len(s.tuned) == 2 and s.tail_plan() == plan
     after = s.get_volume()
     assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    v2 = _two_steps(s, sched)                        # and step() then runs the tuned plan
+    s2 = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, coord_ls=coords)
+    s2.set_measurements(meas)
+    s2.set_volume(before[0], before[1])
+    v1 = _two_steps(s2, sched)
+    assert np.array_equal(v1[0], v2[0]) and np.array_equal(v1[1], v2[1])
     if hasattr(comm, 'calls'):
         del comm.calls[n_calls:]
 
 
 def test_slab_pipelined_step_is_bit_identical():
-    """rotation adjoint -> all-reduce -> Adam, slab by slab (FullfieldSolver.step with more than one rank), gives the very
-    same volume as the whole-volume sequence (loop-back comm: the slab kernels and their ordering)."""
+    """rotation adjoint -> exchange -> Adam, slab by slab, in the all-reduce and in the reduce-scatter / sharded-Adam /
+    all-gather form (FullfieldSolver.step with more than one rank), gives the very same volume as the whole-volume
+    sequence (loop-back comm: the slab kernels, their ordering and the ranges handed to the collectives)."""
     import __graft_entry__ as entry
     entry.build()
     comm = _LoopbackComm()
     _slab_case(comm)
-    assert len(comm.calls) == 4 and len(comm.calls[0]) == 6 and len(comm.calls[-1]) == 65
+    per_x = 64 * 64 * 2
+    kinds = [c[0] for c in comm.calls]
+    assert kinds.count('ar') == 2 * (5 + 64) and kinds.count('rs') == 2 * (8 + 1) and kinds.count('ag') == 2 * (8 + 1)
+    ar = [c for c in comm.calls if c[0] == 'ar'][:5]
+    assert ar[0][1] == 0 and ar[-1][2] == 64 * per_x and all(ar[i][2] == ar[i + 1][1] for i in range(4))      # slabs tile the volume
+    rs = [c for c in comm.calls if c[0] == 'rs'][:8]
+    assert [c[1] for c in rs] == [i * 8 * per_x for i in range(8)] and all(c[2] == 8 * per_x for c in rs)
 
 
 def test_slab_pipelined_step_through_rccl():
-    """The same through torch.distributed / RCCL on one rank: asynchronous all-reduce per slab, ordered against the ctx
-    stream without host synchronisation.  Runs in a child process: torch has to be loaded before libbdof.so
-    (beyond_dof_amd/_lib.py), which this process can no longer guarantee."""
+    """The same through the library's own RCCL communicator on one rank (bdof_comm_*: ncclCommInitRank with a unique id,
+    reduce-scatter / all-gather / all-reduce per slab on the communicator's stream, ordered against the ctx stream by
+    events, no host synchronisation).  In a child process so that librccl is only mapped there."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ('import sys; sys.path.insert(0, {0!r}); sys.path.insert(0, {1!r})\n'
             'import test_gpu_fullfield as t\n'
-            'from beyond_dof_amd.comm import TorchComm\n'
-            'c = TorchComm("nccl"); assert c.always_reduce\n'
-            't._slab_case(c); c.close(); print("SLAB_RCCL_OK")\n').format(root, os.path.join(root, 'tests'))
-    import socket
-    sock = socket.socket()
-    sock.bind(('127.0.0.1', 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    env = dict(os.environ, BDOF_FORCE_TORCH_COMM='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
-               LOCAL_RANK='0')
+            'from beyond_dof_amd.comm import RcclComm\n'
+            'c = RcclComm(); assert c.always_reduce and c.size == 1\n'
+            't._slab_case(c); c.close(); assert "torch" not in sys.modules; print("SLAB_RCCL_OK")\n').format(root, os.path.join(root, 'tests'))
+    env = dict(os.environ, BDOF_FORCE_COMM='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and b'SLAB_RCCL_OK' in r.stdout, r.stdout.decode()[-3000:]
