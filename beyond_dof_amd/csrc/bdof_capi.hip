@@ -42,10 +42,14 @@ struct bdof_ctx {
     cf *hs = nullptr, *hdet = nullptr, *hcomb = nullptr, *probe = nullptr;
     cf *bufA = nullptr, *bufB = nullptr, *tape = nullptr;
     float2* grot = nullptr;
+    double2 *gcar = nullptr, *gt0 = nullptr;     // adjoint carrier per wavefield (AdjCarrier, bdof_kernels.h)
     double *partial = nullptr, *loss_dev = nullptr;
     int npartial = 0;
     float k = 0.f;
     std::complex<double> h00{1.0, 0.0}, hdet00{1.0, 0.0}, a0{0.0, 0.0};   // carrier splitting (bdof_kernels.h)
+    std::complex<double> cbm1{0.0, 0.0};        // cbar - 1: mean modulation factor of the object minus one (modulate_eps_s)
+    double2* cbar_dev = nullptr;                // [npartial_cb + 1] per-workgroup sums of the modulation table, then the mean
+    int ncb = 0;
     // real-space truncated-kernel propagator (bdof_set_conv)
     bool have_conv = false;
     ConvTaps taps{};
@@ -103,14 +107,16 @@ static int fail(bdof_ctx* c, int code, const std::string& msg) {
         }                                                                                          \
     } while (0)
 
-// constant part of the wave entering slice z: a_z = a_0 * H00^z  (H00 = DC value of the transfer function)
-static cf carrier_at(const bdof_ctx* c, int z) {
-    const std::complex<double> a = c->a0 * std::pow(c->h00, z);
-    return make_float2((float)a.real(), (float)a.imag());
-}
+// Mean-refraction carrier (modulate_eps_s): constant part of the wave entering slice z, a_z = a_0 (cbar H00)^z
+// (H00 = DC value of the transfer function, cbar = mean modulation factor of the object)
+static std::complex<double> carrier_z(const bdof_ctx* c, int z) { return c->a0 * std::pow((1.0 + c->cbm1) * c->h00, z); }
+static cf cfl(std::complex<double> a) { return make_float2((float)a.real(), (float)a.imag()); }
+static cf carrier_at(const bdof_ctx* c, int z) { return cfl(carrier_z(c, z)); }
+static cf cshift_at(const bdof_ctx* c, int z) { return cfl(carrier_z(c, z) * c->cbm1); }                  // a_z (cbar - 1)
+static cf carrier_phi_at(const bdof_ctx* c, int z) { return cfl(carrier_z(c, z) * (1.0 + c->cbm1)); }      // constant part of phi_z
 // constant part of the detector wave (real-space detectors) / of the wave whose fft2 is the far field
 static std::complex<double> carrier_end(const bdof_ctx* c) {
-    std::complex<double> a = c->a0 * std::pow(c->h00, c->S - 1);
+    std::complex<double> a = carrier_z(c, c->S - 1) * (1.0 + c->cbm1);
     if (c->det_mode != BDOF_DET_FAR && c->variant == BDOF_VARIANT_TF_ALL) a *= c->h00;
     if (c->det_mode == BDOF_DET_NEAR) a *= c->hdet00;
     return a;
@@ -119,6 +125,25 @@ static cf carrier_det(const bdof_ctx* c) {
     std::complex<double> a = carrier_end(c);
     if (c->det_mode == BDOF_DET_FAR) a *= (double)c->NX * (double)c->NY;
     return make_float2((float)a.real(), (float)a.imag());
+}
+// bdof_set_meas_mode(1): the host subtracted |a_0| from the amplitudes; the detector carrier has modulus |a_0| |cbar|^S
+static float meas_dref(const bdof_ctx* c) { return (float)(std::abs(carrier_end(c)) - std::abs(c->a0)); }
+// the object's mean modulation factor rides on the carrier when the carrier is a scalar of the transfer-function path
+static bool want_cbar(const bdof_ctx* c) {
+    static const bool off = std::getenv("BDOF_NO_MEAN_CARRIER") != nullptr;
+    return !off && std::abs(c->a0) > 0.0 && !c->pstack && !c->have_conv;
+}
+
+// far-field detector + plane-wave carrier: the DC seed of the adjoint is carried as a float64 scalar (AdjCarrier)
+static bool use_adj_carrier(const bdof_ctx* c) {
+    static const bool off = std::getenv("BDOF_NO_ADJ_CARRIER") != nullptr;
+    return !off && c->det_mode == BDOF_DET_FAR && !c->pstack && c->gcar && std::abs(c->a0) > 0.0;
+}
+static double2 d2(std::complex<double> v) { return make_double2(v.real(), v.imag()); }
+// conj(H00)^n: what the adjoint carrier picks up in n adjoint transfer-function steps
+static AdjCarrier adj_carrier_at(const bdof_ctx* c, int steps_back) {
+    if (!use_adj_carrier(c)) return AdjCarrier{nullptr, nullptr, make_double2(1.0, 0.0), make_float2(0.f, 0.f)};
+    return AdjCarrier{c->gcar + c->sub_b0, c->gt0 + c->sub_b0, d2(std::pow(std::conj((1.0 + c->cbm1) * c->h00), steps_back)), cfl(c->cbm1)};
 }
 
 static bool supported_n(int n) { return n == 64 || n == 128 || n == 256 || n == 512 || n == 1024; }
@@ -295,7 +320,7 @@ static const cf* slice_carrier_field(const bdof_ctx* c, int z) { return c->pstac
 static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore, cf* phi_out = nullptr) {
     ProfScope ps(c, BDOF_K_ROW_FWD);
     RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), sub_field(c, phi_out), sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
-                 slice_carrier_field(c, z)};
+                 slice_carrier_field(c, z), cshift_at(c, z)};
     const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
@@ -333,12 +358,16 @@ static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* t
     ProfScope ps(c, BDOF_K_ROW_BWD);
     RowBwdArgs a{sub_field(c, gin), hist == 2 ? c->probe : sub_field(c, tape), sub_field(c, gout),
                  c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
-                 slice_carrier_field(c, z)};
+                 slice_carrier_field(c, z), adj_carrier_at(c, c->S - 1 - z), cshift_at(c, z), carrier_phi_at(c, z)};
     const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
-        if (pf) {
+        if (a.ac.gcar) {         // far field + plane-wave carrier (never together with a carrier field)
+            if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0, false, true>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1, false, true>), grid, blk, 0, c->sub_stream, a);
+            else hipLaunchKernelGGL((k_row_bwd<N_, 2, false, true>), grid, blk, 0, c->sub_stream, a);
+        } else if (pf) {
             if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0, true>), grid, blk, 0, c->sub_stream, a);
             else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1, true>), grid, blk, 0, c->sub_stream, a);
             else hipLaunchKernelGGL((k_row_bwd<N_, 2, true>), grid, blk, 0, c->sub_stream, a);
@@ -355,7 +384,8 @@ static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool 
                             float in_scale, float out_scale, float seed_scale, cf carrier, const cf* pfield = nullptr) {
     ProfScope ps(c, BDOF_K_LOSS);
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NX,
-               in_scale, out_scale, seed_scale, carrier, c->twY, pfield, c->meas_dev};
+               in_scale, out_scale, seed_scale, carrier, c->twY, pfield, c->meas_dev, nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0),
+               c->meas_dev ? meas_dref(c) : 0.f};
     int grid = 0;
     DISPATCH_N(c->NY, {
         grid = rows_grid<N_>(c, B, c->NX);
@@ -369,8 +399,11 @@ static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool 
 static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* out_wave, const float* meas, float in_scale,
                            float out_scale, float seed_scale, const cf* pfield = nullptr) {
     ProfScope ps(c, BDOF_K_LOSS);
+    const bool gc = meas && out_hyb && use_adj_carrier(c);
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NY,
-               in_scale, out_scale, seed_scale, carrier_det(c), c->twX, pfield, 0};
+               in_scale, out_scale, seed_scale, carrier_det(c), c->twX, pfield, 0,
+               gc ? c->gcar + c->sub_b0 : nullptr, gc ? c->gt0 + c->sub_b0 : nullptr,
+               d2(carrier_end(c) * ((double)c->NX * (double)c->NY)), d2(carrier_end(c)), 0.f};
     int grid = 0;
     DISPATCH_N(c->NX, {
         grid = rows_grid<N_>(c, B, c->NY);
@@ -427,8 +460,25 @@ static int ensure_modulation(bdof_ctx* c) {
     }
     size_t need = (n + 255) / 256;
     int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
-    hipLaunchKernelGGL(k_modulation_table, dim3(grid), dim3(256), 0, c->stream, c->obj_src, c->mod, n, c->k);
+    const bool mean = want_cbar(c);
+    if (mean && c->ncb < grid + 1) {
+        if (c->cbar_dev) (void)hipFree(c->cbar_dev);
+        c->cbar_dev = nullptr; c->ncb = 0;
+        HIPC(c, hipMalloc((void**)&c->cbar_dev, sizeof(double2) * (size_t)(c->ncu * 16 + 1)));
+        c->ncb = c->ncu * 16 + 1;
+    }
+    hipLaunchKernelGGL(k_modulation_table, dim3(grid), dim3(256), 0, c->stream, c->obj_src, c->mod, n, c->k, mean ? c->cbar_dev : nullptr);
     HIPC(c, hipGetLastError());
+    std::complex<double> cb(0.0, 0.0);
+    if (mean) {
+        // cbar is needed by the HOST (it forms the carrier scalars in float64): one small read-back per object update
+        hipLaunchKernelGGL(k_sum_mean, dim3(1), dim3(64), 0, c->stream, c->cbar_dev, grid, 1.0 / (double)n, c->cbar_dev + grid);
+        double2 m;
+        HIPC(c, hipMemcpyAsync(&m, c->cbar_dev + grid, sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        cb = std::complex<double>(m.x, m.y);
+    }
+    if (cb != c->cbm1) { c->cbm1 = cb; c->res_dirty = true; }
     c->obj.vol = c->mod;
     c->mod_dirty = false;
     return 0;
@@ -501,8 +551,10 @@ static int generic_forward_sweep(bdof_ctx* c, int B, bool tape, rocfft_plan pf, 
         {
             ProfScope ps(c, BDOF_K_ROW_FWD);
             GModArgs m{c->bufA, z == 0 ? c->probe : nullptr, tape ? c->tape + (size_t)z * fld : nullptr, c->obj, B, c->NX, c->NY, z,
-                       make_float2((float)a.real(), (float)a.imag()), c->pstack ? c->pstack + (size_t)z * c->NX * c->NY : nullptr};
+                       make_float2((float)a.real(), (float)a.imag()), c->pstack ? c->pstack + (size_t)z * c->NX * c->NY : nullptr,
+                       cfl(a * c->cbm1)};
             hipLaunchKernelGGL(k_g_modulate, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, m);
+            a *= 1.0 + c->cbm1;                  // mean-refraction carrier: phi_z rides on cbar a_z
         }
         const bool last = z == c->S - 1;
         if (!last || (tf_all && c->det_mode != BDOF_DET_FAR)) {
@@ -531,7 +583,7 @@ static int generic_forward(bdof_ctx* c, int B, void* out_wave, bool keep_tape) {
     if (out_wave) {
         const size_t n = (size_t)B * c->NX * c->NY;
         GLossArgs la{c->bufA, (cf*)out_wave, nullptr, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
-                     make_float2((float)a.real(), (float)a.imag()), 0.f, c->pdet, 0};
+                     make_float2((float)a.real(), (float)a.imag()), 0.f, c->pdet, 0, 0.f, nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
         hipLaunchKernelGGL(k_g_loss, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, la);
     }
     return 0;
@@ -549,8 +601,10 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
     const int egrid = g_elem_grid(c, n);
     {
         ProfScope ps(c, BDOF_K_LOSS);
+        const bool gc = use_adj_carrier(c);
         GLossArgs la{c->bufA, (cf*)out_wave, meas, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
-                     make_float2((float)a.real(), (float)a.imag()), 2.f / ((float)B * (float)c->NX * (float)c->NY), c->pdet, c->meas_dev};
+                     make_float2((float)a.real(), (float)a.imag()), 2.f / ((float)B * (float)c->NX * (float)c->NY), c->pdet, c->meas_dev,
+                     c->meas_dev ? meas_dref(c) : 0.f, gc ? c->gcar : nullptr, gc ? c->gt0 : nullptr, d2(a), d2(carrier_end(c))};
         hipLaunchKernelGGL(k_g_loss, dim3(egrid), dim3(256), 0, c->stream, la);
     }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, egrid, 1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
@@ -565,7 +619,8 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
         const bool prop_after = z < c->S - 1 || (tf_all && c->det_mode != BDOF_DET_FAR);
         if (prop_after && (r = generic_prop(c, B, pf, pi, c->bufA, c->hs, 1))) return r;
         ProfScope ps(c, BDOF_K_ROW_BWD);
-        GBwdArgs ba{c->bufA, c->tape + (size_t)z * fld, c->grot, c->obj, B, c->NX, c->NY, z, c->k, carrier_at(c, z), c->pstack ? 1 : 0};
+        GBwdArgs ba{c->bufA, c->tape + (size_t)z * fld, c->grot, c->obj, B, c->NX, c->NY, z, c->k, carrier_phi_at(c, z), c->pstack ? 1 : 0,
+                    adj_carrier_at(c, c->S - 1 - z)};
         hipLaunchKernelGGL(k_g_bwd, dim3(egrid), dim3(256), 0, c->stream, ba);
     }
     return 0;
@@ -591,22 +646,26 @@ template <int N> static int resident_launch(bdof_ctx* c, const ResArgs& a, int g
 // sizes without a fused plan always take it (the alternative is the unfused rocFFT engine).
 static bool use_resident(const bdof_ctx* c, int B) {
     if (!c->resident) return false;
+    // far field + plane-wave carrier needs the adjoint carrier (AdjCarrier), which the resident kernel does not carry: the
+    // streaming / generic engines take that case (plane-wave full-field at a resident-plan size)
+    if (c->det_mode == BDOF_DET_FAR && !c->pstack && std::abs(c->a0) > 0.0 && !std::getenv("BDOF_NO_ADJ_CARRIER")) return false;
     return c->generic || c->res_always || B * 4 >= c->ncu;
 }
 
 static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, bool do_grad) {
     if (c->res_dirty) {
-        std::vector<cf> car(c->S);
-        for (int z = 0; z < c->S; ++z) car[z] = carrier_at(c, z);
+        std::vector<cf> car(2 * (size_t)c->S);
+        for (int z = 0; z < c->S; ++z) { car[z] = carrier_at(c, z); car[c->S + z] = cshift_at(c, z); }
         HIPC(c, hipStreamSynchronize(c->stream));
-        HIPC(c, hipMemcpy(c->res_carrier, car.data(), sizeof(cf) * c->S, hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpy(c->res_carrier, car.data(), sizeof(cf) * car.size(), hipMemcpyHostToDevice));
         c->res_dirty = false;
     }
     ProfScope ps(c, BDOF_K_ROW_FWD);
     const bool grad = do_grad && meas;
     ResArgs a{c->probe, c->hsT, c->hdetT, grad ? c->tape : nullptr, (size_t)c->Bmax * c->NX * c->NY, c->grot, c->obj, c->res_carrier,
               carrier_det(c), c->pstack, c->pdet, meas, (cf*)out_wave, c->partial, c->twR, B, c->S, c->det_mode,
-              c->variant == BDOF_VARIANT_TF_ALL ? 1 : 0, grad ? 1 : 0, c->k, 2.f / ((float)B * (float)c->NX * (float)c->NY), c->meas_dev};
+              c->variant == BDOF_VARIANT_TF_ALL ? 1 : 0, grad ? 1 : 0, c->k, 2.f / ((float)B * (float)c->NX * (float)c->NY), c->meas_dev,
+              c->meas_dev ? meas_dref(c) : 0.f};
     const int grid = B < c->npartial ? B : c->npartial;
     int r = 0;
     switch (c->NX) {
@@ -682,7 +741,7 @@ static void free_generic(bdof_ctx* c) {
 
 static void free_workspace(bdof_ctx* c) {
     free_generic(c);
-    void* ptrs[] = {c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->partial, c->loss_dev};
+    void* ptrs[] = {c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
     c->pstack = c->pdet = c->pdetT = nullptr;
@@ -691,6 +750,7 @@ static void free_workspace(bdof_ctx* c) {
     c->have_conv = false;
     c->twY = c->twX = c->hs = c->hdet = c->hcomb = c->probe = c->bufA = c->bufB = c->tape = nullptr;
     c->grot = nullptr;
+    c->gcar = c->gt0 = nullptr;
     c->partial = c->loss_dev = nullptr;
 }
 
@@ -703,6 +763,7 @@ void bdof_ctx_destroy(bdof_ctx* c) {
     if (c->winpad) (void)hipFree(c->winpad);
     if (c->win_angle) (void)hipFree(c->win_angle);
     if (c->mod) (void)hipFree(c->mod);
+    if (c->cbar_dev) (void)hipFree(c->cbar_dev);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
     for (hipStream_t s : c->side_all) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     for (int i = 0; i < BDOF_MAX_GROUPS - 1; ++i)
@@ -771,7 +832,7 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
         if ((r = upload_twiddle(c, NX, &c->twR))) return r;
         HIPC(c, hipMalloc((void**)&c->hsT, sizeof(cf) * NX * NY));
         HIPC(c, hipMalloc((void**)&c->hdetT, sizeof(cf) * NX * NY));
-        HIPC(c, hipMalloc((void**)&c->res_carrier, sizeof(cf) * (size_t)S));
+        HIPC(c, hipMalloc((void**)&c->res_carrier, sizeof(cf) * 2 * (size_t)S));
     }
     if (!generic) {
         if ((r = upload_twiddle(c, NY, &c->twY))) return r;
@@ -787,6 +848,8 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     if (c->with_grad) {
         HIPC(c, hipMalloc((void**)&c->tape, sizeof(cf) * fld * (size_t)S));
         HIPC(c, hipMalloc((void**)&c->grot, sizeof(float2) * fld * (size_t)S));
+        HIPC(c, hipMalloc((void**)&c->gcar, sizeof(double2) * (size_t)Bmax));
+        HIPC(c, hipMalloc((void**)&c->gt0, sizeof(double2) * (size_t)Bmax));
     }
     c->npartial = c->ncu * 16 + 64;
     HIPC(c, hipMalloc((void**)&c->partial, sizeof(double) * 2 * c->npartial));
@@ -849,6 +912,7 @@ int bdof_set_probe(bdof_ctx* c, const float* probe, double a0_re, double a0_im) 
     HIPC(c, hipStreamSynchronize(c->stream));
     c->a0 = std::complex<double>(a0_re, a0_im);
     c->res_dirty = true;
+    c->mod_dirty = true;            // whether the mean modulation rides on the carrier depends on a0 (want_cbar)
     c->have_probe = true;
     return 0;
 }
@@ -873,6 +937,7 @@ int bdof_set_probe_stack(bdof_ctx* c, const float* stack, const float* det) {
     if (c->pstack) { (void)hipFree(c->pstack); c->pstack = nullptr; }
     if (c->pdet) { (void)hipFree(c->pdet); c->pdet = nullptr; }
     if (c->pdetT) { (void)hipFree(c->pdetT); c->pdetT = nullptr; }
+    c->mod_dirty = true;
     if (!stack && !det) return 0;
     if (!stack || !det) return fail(c, BDOF_ERR_ARG, "bdof_set_probe_stack: both arrays or neither");
     const size_t fld = sizeof(cf) * (size_t)c->NX * c->NY;
@@ -988,7 +1053,7 @@ int bdof_tape_to_real(bdof_ctx* c, int i, int B, void* out) {
     } else {
         if (!c->last_valid)
             return fail(c, BDOF_ERR_STATE, "the last slice's wave is only kept after bdof_forward(keep_tape=1) with the numpy_skip_last variant");
-        launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out, nullptr, 1.f / c->NY, 1.f, 0.f, carrier_at(c, c->S - 1),
+        launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out, nullptr, 1.f / c->NY, 1.f, 0.f, carrier_phi_at(c, c->S - 1),
                          slice_carrier_field(c, c->S - 1));
     }
     HIPC(c, hipGetLastError());

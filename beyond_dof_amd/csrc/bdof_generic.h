@@ -13,6 +13,7 @@ struct GModArgs {
     int B, NX, NY, z;
     cf carrier;
     const cf* pz;        // nullable: carrier field of the slice, [x][y] (bdof_set_probe_stack); the tape then holds the full phi
+    cf cshift;           // a_z (cbar - 1), scalar carrier only (modulate_eps_s)
 };
 
 __device__ __forceinline__ float2 g_mod_value(const ObjView& o, int b, int x, int y, int z, int NX) {
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void k_g_modulate(GModArgs a) {
         const int x = r % a.NX, b = r / a.NX;
         const cf e = a.probe ? a.probe[(size_t)x * a.NY + y] : a.field[idx];
         const cf pc = a.pz ? a.pz[(size_t)x * a.NY + y] : a.carrier;
-        const cf phi = modulate_eps(e, pc, g_mod_value(a.obj, b, x, y, a.z, a.NX));
+        const cf phi = modulate_eps_s(e, pc, g_mod_value(a.obj, b, x, y, a.z, a.NX), a.cshift);
         a.field[idx] = phi;
         if (a.tape) a.tape[idx] = a.pz ? cadd(phi, pc) : phi;
     }
@@ -60,6 +61,10 @@ struct GLossArgs {
     float seed_scale;
     const cf* pdet;      // nullable: carrier field at the detector, [x][y] / far field [kx][ky] (replaces `carrier`)
     int meas_dev;        // `meas` holds m - |carrier| (loss_seed_dev, bdof_kernels.h)
+    float dref;
+    double2* gcar;       // nullable [B]: adjoint carrier (AdjCarrier, bdof_kernels.h) — far field with a plane-wave carrier
+    double2* gt0;
+    double2 carrier_dd, a_end;
 };
 
 __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
@@ -74,13 +79,27 @@ __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
             const size_t oidx = idx;
             if (a.out_wave) a.out_wave[oidx] = cadd(d, a.carrier);
             a.field[idx] = loss_seed_dev(d, a.carrier, sqrtf(a.carrier.x * a.carrier.x + a.carrier.y * a.carrier.y), a.meas[oidx],
-                                         a.seed_scale, acc, acc2);
+                                         a.seed_scale, acc, acc2, a.dref);
             continue;
         }
+        const cf e0 = d;
         if (a.pdet) d = cadd(d, a.pdet[(size_t)x * a.NY + y]);
         else if (!a.far || (x == 0 && y == 0)) d = cadd(d, a.carrier);
         const size_t oidx = a.far ? ((size_t)b * a.NY + y) * a.NX + x : idx;
         if (a.out_wave) a.out_wave[oidx] = d;
+        if (a.meas && a.gcar && a.far && x == 0 && y == 0) {
+            // DC bin in float64, its seed kept out of the transforms (AdjCarrier)
+            const double dx = a.carrier_dd.x + (double)e0.x, dy = a.carrier_dd.y + (double)e0.y;
+            const double ab = sqrt(dx * dx + dy * dy), rr = ab - (double)a.meas[oidx];
+            acc += rr * rr;
+            acc2 += rr * ab;
+            const double f = ab > 0.0 ? (double)a.seed_scale * rr / ab : 0.0;
+            const double2 s0 = make_double2(dx * f, dy * f);
+            a.gcar[b] = s0;
+            a.gt0[b] = make_double2(a.a_end.x * s0.x + a.a_end.y * s0.y, a.a_end.x * s0.y - a.a_end.y * s0.x);
+            a.field[idx] = make_float2(0.f, 0.f);
+            continue;
+        }
         if (a.meas) a.field[idx] = loss_seed(d, a.meas[oidx], a.seed_scale, acc, acc2);
     }
     if (a.meas) {
@@ -103,8 +122,9 @@ struct GBwdArgs {
     ObjView obj;
     int B, NX, NY, z;
     float k;
-    cf carrier;
+    cf carrier;          // cbar a_z: constant part of phi_z
     int full_tape;       // the tape holds the full phi (carrier field), not its scattered part
+    AdjCarrier ac;       // gcar nullable
 };
 
 __global__ __launch_bounds__(256) void k_g_bwd(GBwdArgs a) {
@@ -114,10 +134,18 @@ __global__ __launch_bounds__(256) void k_g_bwd(GBwdArgs a) {
         const size_t r = idx / a.NY;
         const int x = r % a.NX, b = r / a.NX;
         const cf G = a.g[idx];
-        const cf phi = a.full_tape ? a.tape[idx] : cadd(a.tape[idx], a.carrier);
-        const cf t = cmulc(G, phi);
-        a.grot[(((size_t)b * a.obj.S + a.z) * a.NX + x) * a.NY + y] = make_float2(a.k * t.y, -a.k * t.x);
+        const cf e = a.tape[idx];
+        const cf phi = a.full_tape ? e : cadd(e, a.carrier);
+        cf t = cmulc(G, phi);
         const float2 m1 = g_mod_value(a.obj, b, x, y, a.z, a.NX);
-        a.g[idx] = cmulc(G, make_float2(1.f + m1.x, m1.y));
+        cf Gn = cmulc(G, make_float2(1.f + m1.x, m1.y));
+        if (a.ac.gcar) {
+            cf gam, t0;
+            adj_carrier_load(a.ac, b, gam, t0);
+            t = cadd(cadd(t, cmulc(gam, e)), t0);
+            Gn = cadd(Gn, cmulc(gam, csub(m1, a.ac.cbm1)));
+        }
+        a.grot[(((size_t)b * a.obj.S + a.z) * a.NX + x) * a.NY + y] = make_float2(a.k * t.y, -a.k * t.x);
+        a.g[idx] = Gn;
     }
 }

@@ -134,12 +134,44 @@ __device__ __forceinline__ cf slice_modulation_m1(float2 db, float k) {
 __device__ __forceinline__ cf modulate_eps(cf eps, cf carrier, cf cm1) {
     return cadd(eps, cmul(cm1, cadd(carrier, eps)));
 }
+// Mean-refraction carrier.  The plane-wave part is not only propagated (a_{z+1} = a_z H00) but also modulated by the MEAN
+// modulation factor cbar of the object (mean of c over the volume, k_modulation_table): entering slice z the wave is
+// a_z + eps_z with a_z = a_0 (cbar H00)^z, leaving it cbar a_z + eps'_z with
+//     eps' = c (a + eps) - cbar a = eps + (c - 1)(a + eps) - a (cbar - 1)          (cshift = a (cbar - 1), host float64).
+// Exact algebra for ANY cbar; with cbar the object's mean, eps no longer collects the mean phase shift / absorption of the
+// slices passed (20 x the structured part for a random 512-slice object), so the round-off of the float32 transforms,
+// which scales with |eps|, drops by that factor — what limits far-field residuals and the gradient.
+__device__ __forceinline__ cf modulate_eps_s(cf eps, cf carrier, cf cm1, cf cshift) {
+    return csub(cadd(eps, cmul(cm1, cadd(carrier, eps))), cshift);
+}
 
 // The modulation factors of the whole object, once per object update (one pass, 16 B/voxel): every voxel row is used by
 // ~25 angles per Adam step, so evaluating sincos/exp here instead of in A and A' removes a third of their arithmetic.
-__global__ __launch_bounds__(256) void k_modulation_table(const float2* __restrict__ db, float2* __restrict__ cm1, size_t n, float k) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        cm1[i] = slice_modulation_m1(db[i], k);
+// partial (nullable): [gridDim.x] per-workgroup sums of c - 1 in float64, summed in a fixed order by k_sum_mean (deterministic)
+__global__ __launch_bounds__(256) void k_modulation_table(const float2* __restrict__ db, float2* __restrict__ cm1, size_t n, float k,
+                                                           double2* __restrict__ partial) {
+    double sx = 0.0, sy = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float2 v = slice_modulation_m1(db[i], k);
+        cm1[i] = v;
+        sx += (double)v.x;
+        sy += (double)v.y;
+    }
+    if (partial) {
+        __shared__ double w[2][4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off, 64); sy += __shfl_down(sy, off, 64); }
+        if ((threadIdx.x & 63) == 0) { w[0][threadIdx.x >> 6] = sx; w[1][threadIdx.x >> 6] = sy; }
+        __syncthreads();
+        if (threadIdx.x == 0) partial[blockIdx.x] = make_double2(w[0][0] + w[0][1] + w[0][2] + w[0][3], w[1][0] + w[1][1] + w[1][2] + w[1][3]);
+    }
+}
+__global__ void k_sum_mean(const double2* partial, int n, double inv_count, double2* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double sx = 0.0, sy = 0.0;
+        for (int j = 0; j < n; ++j) { sx += partial[j].x; sy += partial[j].y; }
+        out[0] = make_double2(sx * inv_count, sy * inv_count);
+    }
 }
 
 // Loads are unconditional (clamped address) and zeroed afterwards: a branch around each load makes hipcc wait
@@ -170,6 +202,7 @@ struct RowFwdArgs {
     cf carrier;        // a_z: constant part of the wave entering slice z
     const cf* twiddle;
     const cf* pz;      // PF kernels: carrier FIELD of slice z, [NX][NY] (bdof_set_probe_stack); replaces `carrier`
+    cf cshift;         // a_z (cbar - 1): see modulate_eps_s (0 with a carrier field)
 };
 
 // PF: the carrier is a field (localised probe), one more coalesced 8-B read per pixel; the plane-wave instances are untouched
@@ -208,7 +241,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
             } else {
                 if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], a.carrier, db[m]);
+                for (int m = 0; m < 8; ++m) u[m] = modulate_eps_s(u[m], a.carrier, db[m], a.cshift);
             }
             if (a.phi_out) {
                 cf* pdst = a.phi_out + (size_t)(row0 + r) * NY;
@@ -329,7 +362,35 @@ struct LossArgs {
     const cf* pfield;    // nullable: carrier field at this plane in the row layout of `in` ([R][N], the same for every batch
                          // element); replaces `carrier`
     int meas_dev;        // `meas` holds m - |carrier| (loss_seed_dev); real-space detectors with a scalar carrier only
+    // Adjoint carrier (far field + plane-wave carrier, see AdjCarrier below): the DC bin is evaluated in float64 and its seed
+    // is NOT sent through the transforms; it is left in gcar[b] (and conj(a_end) * seed in gt0[b]) for the adjoint kernels.
+    double2* gcar;       // nullable [B]
+    double2* gt0;        // [B]
+    double2 carrier_dd;  // a_end * NX * NY in float64 (= `carrier`)
+    double2 a_end;       // a_end: constant part of phi_{S-1}
+    float dref;          // meas_dev: |carrier| - reference subtracted by the host (loss_seed_dev)
 };
+
+// Adjoint carrier.  With a plane-wave probe and a far-field detector nearly all of the detector wave sits in ONE bin (DC,
+// |d| ~ NX NY), so the adjoint field G = F^H seed is a large constant gamma plus a small structured part Gamma.  The
+// gradient is k Im / -k Re of conj(phi) G with phi = a + e, and the product of the two constants, conj(a) gamma, is
+// (nearly) real: in float32 its imaginary part is round-off of size 1e-7 |a| |gamma|, which swamps the true delta-gradient
+// (seen: 25 % error at 128^2).  So gamma is split off exactly as the forward carrier is: the DC seed is formed in float64 by
+// the loss kernel and never enters the float32 transforms; it is carried as a scalar per wavefield, gamma_z = gamma_S
+// conj(cbar H00)^(slices back) (float64), conj(c)(gamma + Gamma) = conj(cbar) gamma + [conj(c) Gamma + conj(c - cbar) gamma],
+// and conj(a_z) gamma_z = conj(a_end) gamma_S =: t0 (constant parts of phi_z and of G(phi_z)) is the same at every slice and
+// is formed once, in float64.
+struct AdjCarrier {
+    const double2* gcar;   // nullable [B]: gamma at the plane the adjoint sweep starts from
+    const double2* gt0;    // [B]: conj(a_end) * gamma
+    double2 fac;           // conj(cbar H00)^(number of slices between that plane and this one): what gamma picks up on the way
+    cf cbm1;               // cbar - 1 (mean-refraction carrier, modulate_eps_s)
+};
+__device__ __forceinline__ void adj_carrier_load(const AdjCarrier& ac, int b, cf& gam, cf& t0) {
+    const double2 g = ac.gcar[b], t = ac.gt0[b];
+    gam = make_float2((float)(g.x * ac.fac.x - g.y * ac.fac.y), (float)(g.x * ac.fac.y + g.y * ac.fac.x));
+    t0 = make_float2((float)t.x, (float)t.y);
+}
 
 __device__ __forceinline__ cf loss_seed(cf d, float m, float seed_scale, double& acc, double& acc2) {
     const float a = sqrtf(d.x * d.x + d.y * d.y);
@@ -345,11 +406,13 @@ __device__ __forceinline__ cf loss_seed(cf d, float m, float seed_scale, double&
 // i.e. 3e-6 of a 2 % residual.  |a + e| - |a| = (2 Re(conj(a) e) + |e|^2) / (|a + e| + |a|) has no cancellation, and the host
 // hands the measurement over as mdev = m - |a| (float64 subtraction, then float32): r = (|d| - |a|) - mdev is as accurate
 // as the scattered wave e itself.
-__device__ __forceinline__ cf loss_seed_dev(cf e, cf a, float abs_a, float mdev, float seed_scale, double& acc, double& acc2) {
+// dref = |a| - (the reference the host subtracted): the host subtracts |a_0|, the carrier at the detector has modulus
+// |a_0| |cbar|^S (mean-refraction carrier), the difference (float64 on the host) is added back here.
+__device__ __forceinline__ cf loss_seed_dev(cf e, cf a, float abs_a, float mdev, float seed_scale, double& acc, double& acc2, float dref = 0.f) {
     const cf d = cadd(a, e);
     const float ab = sqrtf(d.x * d.x + d.y * d.y);
     const float q = fmaf(2.f * a.x, e.x, fmaf(2.f * a.y, e.y, fmaf(e.x, e.x, e.y * e.y)));
-    const float r = q / (ab + abs_a) - mdev;
+    const float r = q / (ab + abs_a) - (mdev - dref);
     acc += (double)r * (double)r;
     acc2 += (double)r * (double)ab;
     const float f = ab > 0.f ? seed_scale * r / ab : 0.f;
@@ -389,6 +452,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
 #pragma unroll
             for (int m = 0; m < 8; ++m) u[m] = cscale(u[m], a.in_scale);
             const bool dev = !FAR && a.meas_dev && a.meas && !a.pfield;
+            cf e0 = make_float2(0.f, 0.f);        // FAR: scattered part of the DC bin
             if (dev) {
                 // u is still the scattered part: the seed comes from (e, a) directly, the detector wave is a + e
                 const float abs_a = sqrtf(a.carrier.x * a.carrier.x + a.carrier.y * a.carrier.y);
@@ -397,14 +461,14 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
                     for (int m = 0; m < 8; ++m) a.out_wave[off + tid + m * C::T] = cadd(u[m], a.carrier);
                 }
 #pragma unroll
-                for (int m = 0; m < 8; ++m) u[m] = loss_seed_dev(u[m], a.carrier, abs_a, mm[m], a.seed_scale, acc, acc2);
+                for (int m = 0; m < 8; ++m) u[m] = loss_seed_dev(u[m], a.carrier, abs_a, mm[m], a.seed_scale, acc, acc2, a.dref);
             } else {
                 if (a.pfield) {
                     const cf* pf = a.pfield + (size_t)(r0 + r) * N;
 #pragma unroll
                     for (int m = 0; m < 8; ++m) u[m] = cadd(u[m], pf[tid + m * C::T]);
                 } else if constexpr (FAR) {
-                    if (r0 + r == 0 && tid == 0) u[0] = cadd(u[0], a.carrier);       // DC bin of the un-shifted fft2
+                    if (r0 + r == 0 && tid == 0) { e0 = u[0]; u[0] = cadd(u[0], a.carrier); }       // DC bin of the un-shifted fft2
                 } else {
 #pragma unroll
                     for (int m = 0; m < 8; ++m) u[m] = cadd(u[m], a.carrier);
@@ -414,6 +478,21 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
                     for (int m = 0; m < 8; ++m) a.out_wave[off + tid + m * C::T] = u[m];
                 }
                 if (a.meas) {
+                    if constexpr (FAR) {
+                        if (a.gcar && r0 + r == 0 && tid == 0) {
+                            // DC bin in float64; its seed stays out of the transforms (AdjCarrier).  u[0] = (m, 0) makes the
+                            // float32 path below contribute exactly nothing for this bin.
+                            const double dx = a.carrier_dd.x + (double)e0.x, dy = a.carrier_dd.y + (double)e0.y;
+                            const double ab = sqrt(dx * dx + dy * dy), rr = ab - (double)mm[0];
+                            acc += rr * rr;
+                            acc2 += rr * ab;
+                            const double f = ab > 0.0 ? (double)a.seed_scale * rr / ab : 0.0;
+                            const double2 s0 = make_double2(dx * f, dy * f);
+                            a.gcar[b] = s0;
+                            a.gt0[b] = make_double2(a.a_end.x * s0.x + a.a_end.y * s0.y, a.a_end.x * s0.y - a.a_end.y * s0.x);
+                            u[0] = make_float2(mm[0], 0.f);
+                        }
+                    }
 #pragma unroll
                     for (int m = 0; m < 8; ++m) u[m] = loss_seed(u[m], mm[m], a.seed_scale, acc, acc2);
                 }
@@ -462,16 +541,19 @@ struct RowBwdArgs {
     ObjView obj;
     int B, NX, z;
     float k;
-    cf carrier;        // constant part of phi_z (= a_z: the modulation moves no weight into it)
+    cf carrier;        // a_z: constant part of psi_z
     const cf* twiddle;
     const cf* pz;      // PF kernels: carrier field of slice z, [NX][NY]
+    AdjCarrier ac;     // GC kernels: constant part of the adjoint field (far field + plane-wave carrier)
+    cf cshift;         // a_z (cbar - 1)
+    cf carrier_phi;    // cbar a_z: constant part of phi_z
 };
 
 // HIST = 0: phi_z (scattered part) is read from the tape A_z wrote.  HIST = 1: the tape holds the per-slice history
 // psi_hat_z (the INPUT of A_z, written by the transfer-function kernel anyway) and phi_z is recomputed here with A_z's own
 // operations (inverse transform, modulation) — one more transform per launch, 8 B per pixel less traffic in A.
 // HIST = 2: slice 0 of that mode, phi_0 from the probe (no transform).
-template <int NY, int HIST, bool PF = false>
+template <int NY, int HIST, bool PF = false, bool GC = false>
 __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd(RowBwdArgs a) {
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
@@ -485,6 +567,8 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
         const int row0 = tile * C::TILE;
         const int b = row0 / a.NX, x0 = row0 - b * a.NX;
         const int y0 = a.obj.yoff ? a.obj.yoff[b] : 0;
+        cf gam = make_float2(0.f, 0.f), t0 = make_float2(0.f, 0.f);
+        if constexpr (GC) adj_carrier_load(a.ac, b, gam, t0);
 #pragma nounroll
         for (int pass = 0; pass < C::PASSES; ++pass) {
             const int r = pass * C::RPP + rl;
@@ -507,16 +591,18 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
             if constexpr (HIST == 1) line_fft<NY, +1>(p, tw, tid, lds);                // psi_hat_z -> psi_z (scattered part)
             if constexpr (HIST != 0) {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) p[m] = modulate_eps(p[m], PF ? pc[m] : a.carrier, db[m]);
+                for (int m = 0; m < 8; ++m) p[m] = PF ? modulate_eps(p[m], pc[m], db[m]) : modulate_eps_s(p[m], a.carrier, db[m], a.cshift);
             }
             line_fft<NY, +1>(g, tw, tid, lds);
             float2* gdst = a.grot + (((size_t)b * a.obj.S + a.z) * a.NX + x) * NY;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                const cf phi = cadd(p[m], PF ? pc[m] : a.carrier);
-                const cf t = cmulc(g[m], phi);                       // G * conj(phi)
+                const cf phi = cadd(p[m], PF ? pc[m] : a.carrier_phi);
+                cf t = cmulc(g[m], phi);                             // G * conj(phi)
+                if constexpr (GC) t = cadd(cadd(t, cmulc(gam, p[m])), t0);      // + gamma conj(e) + gamma conj(a)
                 gdst[tid + m * C::T] = make_float2(a.k * t.y, -a.k * t.x);
                 g[m] = cmulc(g[m], make_float2(1.f + db[m].x, db[m].y));    // conj(c) G,  c = 1 + (c - 1)
+                if constexpr (GC) g[m] = cadd(g[m], cmulc(gam, csub(db[m], a.ac.cbm1)));   // + conj(c - cbar) gamma (conj(cbar) gamma rides on)
             }
             if (a.gout) line_fft_partial<NY, -1>(g, tw, tid, lds);
         }

@@ -275,7 +275,7 @@ struct ResArgs {
     size_t tape_stride;
     float2* grot;          // [B][S][N][N]
     ObjView obj;
-    const cf* carrier;     // device [S]: a_z
+    const cf* carrier;     // device [2 S]: a_z, then a_z (cbar - 1) (mean-refraction carrier, modulate_eps_s)
     cf carrier_det;        // constant part of the detector wave (far field: DC bin value)
     // Carrier FIELD (bdof_set_probe_stack): the probe propagated through free space, p_z [S][N][N] at the entrance of every
     // slice and pdet [N][N] at the detector (far field: its un-normalised fft2, [kx][ky]), computed by the host in
@@ -290,6 +290,7 @@ struct ResArgs {
     int B, S, det_mode, tf_all, do_grad;
     float k, seed_scale;
     int meas_dev;          // `meas` holds m - |carrier_det| (loss_seed_dev, bdof_kernels.h)
+    float dref;
 };
 
 // transfer-function multiply folded into the last pass of the forward transform: the thread writing element (kx, ky)
@@ -393,7 +394,7 @@ template <int N, int T> struct EpiMod {
     const ResArgs* a;
     const long long* rows;     // object rows of slice z+1
     cf* tape;                  // nullable: tape of slice z+1 for this wavefield
-    cf car;
+    cf car, csh;
     const cf* pz;              // nullable: carrier field of slice z+1
     int y0;
     float2 fac[ResLast<N, T>::CNT][ResLast<N, T>::R];
@@ -407,7 +408,7 @@ template <int N, int T> struct EpiMod {
     }
     __device__ __forceinline__ cf post(int c, int m, int line, int pos, cf v) {
         const cf pc = pz ? pz[pos * N + line] : car;
-        const cf phi = modulate_eps(v, pc, fac[c][m]);
+        const cf phi = modulate_eps_s(v, pc, fac[c][m], csh);
         if (tape) tape[pos * N + line] = pz ? cadd(phi, pc) : phi;      // carrier field: the tape holds the FULL phi (see adjoint)
         return phi;
     }
@@ -449,7 +450,7 @@ template <int N, int T> struct ResPoint {
 
     // phi = c psi : modulation of the slice whose factors are in m; phi goes to the LDS image and to the tape
     // pz: nullable carrier field of the slice ([x][y], read where it is used: an L2-resident table shared by all wavefields)
-    static __device__ __forceinline__ void modulate(cf* f, cf* tape, cf car, const cf* pz, const float2 (&m)[EPT], int tid) {
+    static __device__ __forceinline__ void modulate(cf* f, cf* tape, cf car, cf csh, const cf* pz, const float2 (&m)[EPT], int tid) {
         asm volatile("" : "+v"(tid));
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
@@ -457,7 +458,7 @@ template <int N, int T> struct ResPoint {
             if (EPT * T == N * N || e < N * N) {
                 const int x = e / N, y = e - x * N;
                 const cf pc = pz ? pz[e] : car;
-                const cf phi = modulate_eps(f[x * P + y], pc, m[i]);
+                const cf phi = modulate_eps_s(f[x * P + y], pc, m[i], csh);
                 f[x * P + y] = phi;
                 if (tape) tape[e] = pz ? cadd(phi, pc) : phi;      // carrier field: the tape holds the FULL phi, so that the
                                                                     // adjoint sweep does not have to read p_z again
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
         Pipe::load_factors(a, rowbuf, y0, tid, m);
         if constexpr (FUSE) {
             // slice 0 is modulated on its own; every later slice inside the propagation step that produces it (EpiMod)
-            Point::modulate(f, tape0, a.carrier[0], a.pstack, m, tid);
+            Point::modulate(f, tape0, a.carrier[0], a.carrier[a.S], a.pstack, m, tid);
             for (int z = 0; z < a.S; ++z) {
                 const long long r2 = Pipe::row_of(a, b, z + 2, tid);
                 if (z + 1 < a.S) {
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     em.rows = rowbuf + ((z + 1) % 3) * N;
                     em.tape = tape0 ? tape0 + (size_t)(z + 1) * a.tape_stride : nullptr;
                     em.car = a.carrier[z + 1];
+                    em.csh = a.carrier[a.S + z + 1];
                     em.pz = a.pstack ? a.pstack + (size_t)(z + 1) * fsz : nullptr;
                     em.y0 = y0;
                     res_prop<N, T, false>(f, a.hsT, tw, tid, em);
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
         } else {
             for (int z = 0; z < a.S; ++z) {
                 const long long r2 = Pipe::row_of(a, b, z + 2, tid);
-                Point::modulate(f, tape0 ? tape0 + (size_t)z * a.tape_stride : nullptr, a.carrier[z],
+                Point::modulate(f, tape0 ? tape0 + (size_t)z * a.tape_stride : nullptr, a.carrier[z], a.carrier[a.S + z],
                                 a.pstack ? a.pstack + (size_t)z * fsz : nullptr, m, tid);
                 if (z + 1 < a.S) Pipe::load_factors(a, rowbuf + ((z + 1) % 3) * N, y0, tid, m);      // in flight during the step
                 if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                 const size_t o = b * fsz + e;
                 if (a.out_wave) a.out_wave[o] = cadd(d, a.carrier_det);
                 f[x * P + y] = loss_seed_dev(d, a.carrier_det, sqrtf(a.carrier_det.x * a.carrier_det.x + a.carrier_det.y * a.carrier_det.y),
-                                             a.meas[o], a.seed_scale, acc, acc2);
+                                             a.meas[o], a.seed_scale, acc, acc2, a.dref);
                 continue;
             }
             if (a.pdet) d = cadd(d, a.pdet[e]);
@@ -599,7 +601,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     eb.rows = rowbuf + (z % 3) * N;
                     eb.tape = tape;
                     eb.gdst = gdst;
-                    eb.car = a.carrier[z];
+                    eb.car = cadd(a.carrier[z], a.carrier[a.S + z]);      // cbar a_z: constant part of phi_z
                     eb.pz = a.pstack ? a.pstack + (size_t)z * fsz : nullptr;
                     eb.y0 = y0;
                     res_prop<N, T, true>(f, a.hsT, tw, tid, eb);
@@ -607,11 +609,11 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     // the slice the adjoint sweep starts from when no transfer-function step follows the last slice
                     Pipe::load_factors(a, rowbuf + (z % 3) * N, y0, tid, m);
                     Pipe::load_field(tape, tid, t);
-                    Point::adjoint(f, t, m, a.carrier[z], a.pstack ? a.pstack + (size_t)z * fsz : nullptr, a.k, gdst, tid);
+                    Point::adjoint(f, t, m, cadd(a.carrier[z], a.carrier[a.S + z]), a.pstack ? a.pstack + (size_t)z * fsz : nullptr, a.k, gdst, tid);
                 }
             } else {
                 if (prop_after) res_prop<N, T, true>(f, a.hsT, tw, tid);
-                Point::adjoint(f, t, m, a.carrier[z], a.pstack ? a.pstack + (size_t)z * fsz : nullptr, a.k, gdst, tid);
+                Point::adjoint(f, t, m, cadd(a.carrier[z], a.carrier[a.S + z]), a.pstack ? a.pstack + (size_t)z * fsz : nullptr, a.k, gdst, tid);
                 if (z > 0) {                                           // in flight during the next adjoint step
                     Pipe::load_factors(a, rowbuf + ((z - 1) % 3) * N, y0, tid, m);
                     Pipe::load_field(tape0 + (size_t)(z - 1) * a.tape_stride, tid, t);
