@@ -298,7 +298,8 @@ def main():
                                        '{} ({} slab(s), {})'.format(comm.backend, n_slabs, 'reduce-scatter + sharded Adam + all-gather'
                                                                     if sharded else 'all-reduce')),
                           'allreduce_slabs': n_slabs, 'sharded_adam': bool(sharded), 'propagator': args.propagator,
-                          'adjoint': 'recompute (tape-free)' if args.recompute else 'tape'},
+                          'adjoint': 'recompute (tape-free)' if args.recompute else 'tape',
+                          'hbm_used_GiB': solver.ctx.mem_used() / 2.0 ** 30},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(n, args.cpu_slices)

@@ -56,6 +56,7 @@ _SIGNATURES = {
     'bdof_profile_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_profile_read': (ctypes.c_int, [_vp, ctypes.c_int, _c_int_p, ctypes.POINTER(ctypes.c_double)]),
     'bdof_malloc': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_size_t]),
+    'bdof_device_mem': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     'bdof_ctx_malloc': (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.c_size_t]),
     'bdof_comm_unique_id': (ctypes.c_int, [_vp, ctypes.c_size_t]),
     'bdof_comm_create': (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_size_t]),
@@ -204,6 +205,12 @@ class Context(object):
 
     def sync(self):
         self.check(self.lib.bdof_sync(self.handle))
+
+    def mem_used(self):
+        """Bytes of device memory in use on the ctx's device (all processes)."""
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self.check(self.lib.bdof_device_mem(self.handle, ctypes.byref(free), ctypes.byref(total)))
+        return total.value - free.value
 
     def close(self):
         if getattr(self, 'handle', None):

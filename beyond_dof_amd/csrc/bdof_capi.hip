@@ -38,6 +38,7 @@ struct bdof_ctx {
     int ncu = 256;
     int NY = 0, NX = 0, S = 0, Bmax = 0;
     bool with_grad = false;
+    bool recompute = false;                      // tape-free adjoint (bdof_configure flag 16): the tape holds 3 fields, not S
     cf *twY = nullptr, *twX = nullptr;
     cf *hs = nullptr, *hdet = nullptr, *hcomb = nullptr, *probe = nullptr;
     cf *bufA = nullptr, *bufB = nullptr, *tape = nullptr;
@@ -320,7 +321,7 @@ static const cf* slice_carrier_field(const bdof_ctx* c, int z) { return c->pstac
 static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore, cf* phi_out = nullptr) {
     ProfScope ps(c, BDOF_K_ROW_FWD);
     RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), sub_field(c, phi_out), sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
-                 slice_carrier_field(c, z), cshift_at(c, z)};
+                 slice_carrier_field(c, z), cshift_at(c, z), 0, 1.f};
     const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
@@ -343,6 +344,19 @@ static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, boo
     });
 }
 
+// A_z^-1 (tape-free adjoint): scattered part of phi_z (L1 hybrid, or real space) -> R eps(psi_z) in L2
+static void launch_row_unmod(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool real_in, float in_scale) {
+    ProfScope ps(c, BDOF_K_ROW_FWD);
+    RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), nullptr, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
+                 slice_carrier_field(c, z), cshift_at(c, z), real_in ? 1 : 0, in_scale};
+    DISPATCH_N(c->NY, {
+        const dim3 grid(rows_grid<N_>(c, B, c->NX));
+        const dim3 blk(BDOF_THREADS);
+        if (a.pz) hipLaunchKernelGGL((k_row_fwd<N_, false, true, true, true>), grid, blk, 0, c->sub_stream, a);
+        else hipLaunchKernelGGL((k_row_fwd<N_, false, true, false, true>), grid, blk, 0, c->sub_stream, a);
+    });
+}
+
 // B: L2 -> L1
 static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf* h, float scale, int conj_h) {
     ProfScope ps(c, BDOF_K_COL_PROP);
@@ -354,11 +368,11 @@ static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf*
 
 // A'_z: L1 (g) + phi tape -> L2 (g)
 // hist: 0 = `tape` is the phi tape of slice z; 1 = `tape` is psi_hat_z of the history tape; 2 = slice 0 of the history mode
-static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout, int hist = 0) {
+static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout, int hist = 0, float tape_scale = 1.f) {
     ProfScope ps(c, BDOF_K_ROW_BWD);
     RowBwdArgs a{sub_field(c, gin), hist == 2 ? c->probe : sub_field(c, tape), sub_field(c, gout),
                  c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
-                 slice_carrier_field(c, z), adj_carrier_at(c, c->S - 1 - z), cshift_at(c, z), carrier_phi_at(c, z)};
+                 slice_carrier_field(c, z), adj_carrier_at(c, c->S - 1 - z), cshift_at(c, z), carrier_phi_at(c, z), tape_scale};
     const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
@@ -366,15 +380,18 @@ static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* t
         if (a.ac.gcar) {         // far field + plane-wave carrier (never together with a carrier field)
             if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0, false, true>), grid, blk, 0, c->sub_stream, a);
             else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1, false, true>), grid, blk, 0, c->sub_stream, a);
-            else hipLaunchKernelGGL((k_row_bwd<N_, 2, false, true>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 2) hipLaunchKernelGGL((k_row_bwd<N_, 2, false, true>), grid, blk, 0, c->sub_stream, a);
+            else hipLaunchKernelGGL((k_row_bwd<N_, 3, false, true>), grid, blk, 0, c->sub_stream, a);
         } else if (pf) {
             if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0, true>), grid, blk, 0, c->sub_stream, a);
             else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1, true>), grid, blk, 0, c->sub_stream, a);
-            else hipLaunchKernelGGL((k_row_bwd<N_, 2, true>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 2) hipLaunchKernelGGL((k_row_bwd<N_, 2, true>), grid, blk, 0, c->sub_stream, a);
+            else hipLaunchKernelGGL((k_row_bwd<N_, 3, true>), grid, blk, 0, c->sub_stream, a);
         } else {
             if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0>), grid, blk, 0, c->sub_stream, a);
             else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1>), grid, blk, 0, c->sub_stream, a);
-            else hipLaunchKernelGGL((k_row_bwd<N_, 2>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 2) hipLaunchKernelGGL((k_row_bwd<N_, 2>), grid, blk, 0, c->sub_stream, a);
+            else hipLaunchKernelGGL((k_row_bwd<N_, 3>), grid, blk, 0, c->sub_stream, a);
         }
     });
 }
@@ -420,7 +437,8 @@ static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* ou
 //   DET_NEAR                  : bufB = d_hat (L1)    (tf_all: one step with the combined transfer function)
 //   DET_FAR                   : bufA = R phi_{S-1} in L2 order, un-normalised (|fft2| is unchanged by the
 //                               unit-modulus transfer function, so tf_all needs no extra step here)
-enum { TAPE_NONE = 0, TAPE_HISTORY = 1, TAPE_PHI = 2 };
+enum { TAPE_NONE = 0, TAPE_HISTORY = 1, TAPE_PHI = 2, TAPE_LAST = 3 };
+// TAPE_LAST (tape-free adjoint): only the real-space phi_{S-1} is kept (tape slot 0); the adjoint sweep marches it back.
 // TAPE_HISTORY keeps psi_hat_{z+1} (the transfer-function step's output) per slice: probe_array of np_funcs.py:43.
 // TAPE_PHI keeps the real-space phi_z written by A_z: what the adjoint needs, without a third transform in A'_z.
 static void forward_sweep(bdof_ctx* c, const Group* groups, int ngroups, int tape_mode) {
@@ -429,8 +447,8 @@ static void forward_sweep(bdof_ctx* c, const Group* groups, int ngroups, int tap
     for (int z = 0; z < c->S; ++z) {
         const cf* in = nullptr;
         if (z > 0) in = tape_mode == TAPE_HISTORY ? c->tape + (size_t)(z - 1) * fld : c->bufB;
-        cf* phi = tape_mode == TAPE_PHI ? c->tape + (size_t)z * fld : nullptr;
         const bool last = z == c->S - 1;
+        cf* phi = tape_mode == TAPE_PHI ? c->tape + (size_t)z * fld : (tape_mode == TAPE_LAST && last ? c->tape : nullptr);
         for (int gi = 0; gi < ngroups; ++gi) {
             const int B = groups[gi].B;
             use_group(c, groups[gi]);
@@ -645,7 +663,7 @@ template <int N> static int resident_launch(bdof_ctx* c, const ResArgs& a, int g
 // batch fills a good part of the chip (measured at 64^2 / 128^2: 400 / 100 wavefields 4.6x / 1.5x faster, 25 slower);
 // sizes without a fused plan always take it (the alternative is the unfused rocFFT engine).
 static bool use_resident(const bdof_ctx* c, int B) {
-    if (!c->resident) return false;
+    if (!c->resident || c->recompute) return false;
     // far field + plane-wave carrier needs the adjoint carrier (AdjCarrier), which the resident kernel does not carry: the
     // streaming / generic engines take that case (plane-wave full-field at a resident-plan size)
     if (c->det_mode == BDOF_DET_FAR && !c->pstack && std::abs(c->a0) > 0.0 && !std::getenv("BDOF_NO_ADJ_CARRIER")) return false;
@@ -823,6 +841,7 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     free_workspace(c);
     c->NY = NY; c->NX = NX; c->S = S; c->Bmax = Bmax; c->with_grad = (with_grad & 1) != 0;
     c->generic = generic;
+    c->recompute = (with_grad & 16) != 0 && !generic;      // the streaming engine's option; the others keep their tapes
     c->resident = (with_grad & 6) == 0 && NX == NY && resident_supported(NX) && !std::getenv("BDOF_NO_RESIDENT");
     c->res_always = (with_grad & 8) != 0 || std::getenv("BDOF_FORCE_RESIDENT");
     c->res_dirty = true;
@@ -846,7 +865,10 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     HIPC(c, hipMalloc((void**)&c->bufA, sizeof(cf) * fld));
     HIPC(c, hipMalloc((void**)&c->bufB, sizeof(cf) * fld));
     if (c->with_grad) {
-        HIPC(c, hipMalloc((void**)&c->tape, sizeof(cf) * fld * (size_t)S));
+        // tape-free adjoint: phi_{S-1} (real space) + the two fields the marched-back wave alternates between
+        const bool small_tape = c->recompute && !(c->resident && ((with_grad & 8) != 0 || std::getenv("BDOF_FORCE_RESIDENT")));
+        c->recompute = small_tape;
+        HIPC(c, hipMalloc((void**)&c->tape, sizeof(cf) * fld * (size_t)(small_tape ? std::min(S, 3) : S)));
         HIPC(c, hipMalloc((void**)&c->grot, sizeof(float2) * fld * (size_t)S));
         HIPC(c, hipMalloc((void**)&c->gcar, sizeof(double2) * (size_t)Bmax));
         HIPC(c, hipMalloc((void**)&c->gt0, sizeof(double2) * (size_t)Bmax));
@@ -996,6 +1018,7 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
     if (r) return r;
     if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
     if (keep_tape && !c->with_grad) return fail(c, BDOF_ERR_STATE, "keep_tape needs bdof_configure(with_grad=1)");
+    if (keep_tape && c->recompute) return fail(c, BDOF_ERR_STATE, "the per-slice history is not kept in tape-free (recompute) mode");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     if ((r = ensure_modulation(c))) return r;
@@ -1091,8 +1114,10 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     // The tape is the per-slice history psi_hat_z that the transfer-function kernel writes anyway; A'_z recomputes phi_z from
     // it (one more transform per launch, no tape write in A_z: 104 instead of 112 B per pixel per slice-step, 67.6 -> 65.3 ms
     // per step at 512^3 x 25).  BDOF_TAPE_PHI=1 selects the older form (A_z stores phi_z) for comparison; same bits.
-    static const bool hist_tape = std::getenv("BDOF_TAPE_PHI") == nullptr;
-    forward_sweep(c, groups, ng, hist_tape ? TAPE_HISTORY : TAPE_PHI);
+    static const bool hist_env = std::getenv("BDOF_TAPE_PHI") == nullptr;
+    const bool recompute = c->recompute;
+    const bool hist_tape = hist_env && !recompute;
+    forward_sweep(c, groups, ng, recompute ? TAPE_LAST : (hist_tape ? TAPE_HISTORY : TAPE_PHI));
     c->tape_valid = false;      // the tape holds phi_z (or an incomplete history), not what bdof_tape_to_real expects
     c->last_valid = false;
     const float seed_scale = 2.f / ((float)B * (float)c->NX * (float)c->NY);
@@ -1113,9 +1138,29 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
         }
     }
     // backward sweep: A'_z (L1 -> L2), then the adjoint transfer-function step (L2 -> L1)
+    // Tape-free form (bdof_configure flag 16): P is unitary and c_z is invertible, so the forward wave is marched
+    // BACK beside the adjoint field instead of being stored per slice: phi_{z-1} = P^H (phi_z / c_z) — one A_z^-1 launch and
+    // one more adjoint transfer-function launch per slice (+40 B per pixel per slice-step), S - 3 fields per wavefield less
+    // memory.  phi_{S-1} is kept by the forward sweep (real space, tape slot 0); slots 1 / 2 hold the marched-back wave in L1 /
+    // L2 order; slice 0 takes phi_0 from the probe as the history form does.
+    cf* const rc_last = c->tape;
+    cf* const rc1 = c->tape + fld;
+    cf* const rc2 = c->tape + 2 * fld;
     for (int z = c->S - 1; z >= 0; --z) {
         for (int gi = 0; gi < ng; ++gi) {
             use_group(c, groups[gi]);
+            if (recompute) {
+                const bool top = z == c->S - 1;
+                if (z == 0) launch_row_bwd(c, groups[gi].B, z, c->bufB, nullptr, nullptr, 2);
+                else if (top) launch_row_bwd(c, groups[gi].B, z, c->bufB, rc_last, c->bufA, 0);
+                else launch_row_bwd(c, groups[gi].B, z, c->bufB, rc1, c->bufA, 3, 1.f);
+                if (z > 0) launch_row_prop(c, groups[gi].B, c->bufA, c->bufB, c->hs, 1.f, 1);
+                if (z > 1) {
+                    launch_row_unmod(c, groups[gi].B, z, top ? rc_last : rc1, rc2, top, 1.f);
+                    launch_row_prop(c, groups[gi].B, rc2, rc1, c->hs, 1.f, 1);
+                }
+                continue;
+            }
             if (hist_tape)
                 launch_row_bwd(c, groups[gi].B, z, c->bufB, z > 0 ? c->tape + (size_t)(z - 1) * fld : nullptr, z > 0 ? c->bufA : nullptr,
                                z > 0 ? 1 : 2);
@@ -1494,6 +1539,13 @@ int bdof_profile_read(bdof_ctx* c, int kernel_class, int* n_launches, double* to
     prof_collect(c);
     if (n_launches) *n_launches = c->prof_n[kernel_class];
     if (total_ms) *total_ms = c->prof_ms[kernel_class];
+    return 0;
+}
+
+int bdof_device_mem(bdof_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+    if (!c || !free_bytes || !total_bytes) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipMemGetInfo(free_bytes, total_bytes));
     return 0;
 }
 

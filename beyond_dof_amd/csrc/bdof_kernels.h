@@ -203,10 +203,23 @@ struct RowFwdArgs {
     const cf* twiddle;
     const cf* pz;      // PF kernels: carrier FIELD of slice z, [NX][NY] (bdof_set_probe_stack); replaces `carrier`
     cf cshift;         // a_z (cbar - 1): see modulate_eps_s (0 with a carrier field)
+    int real_in;       // INV kernels: `in` is real-space (no inverse transform first)
+    float in_scale;    // INV kernels: factor on the (transformed) input
 };
 
+// Inverse of the modulation, for the tape-free adjoint (bdof_configure flag 16): from the scattered part of phi_z = c psi_z
+// back to the scattered part of psi_z,  eps = (eps' - carrier (c - 1) + cshift) / c     (modulate_eps_s solved for eps).
+__device__ __forceinline__ cf unmodulate_eps(cf epsp, cf carrier, cf cm1, cf cshift) {
+    const cf num = cadd(csub(epsp, cmul(cm1, carrier)), cshift);
+    const float cr = 1.f + cm1.x, ci = cm1.y;
+    const float inv = 1.f / fmaf(cr, cr, ci * ci);
+    return make_float2((num.x * cr + num.y * ci) * inv, (num.y * cr - num.x * ci) * inv);
+}
+
 // PF: the carrier is a field (localised probe), one more coalesced 8-B read per pixel; the plane-wave instances are untouched
-template <int NY, bool FIRST, bool TSTORE, bool PF = false>
+// INV: A_z^-1 — rows of the hybrid (or, real_in, real-space) scattered part of phi_z in, R eps(psi_z) out: the first half
+// of the step phi_z -> phi_{z-1} = P^H (phi_z / c_z) that marches the forward wave back beside the adjoint field.
+template <int NY, bool FIRST, bool TSTORE, bool PF = false, bool INV = false>
 __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd(RowFwdArgs a) {
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
@@ -235,9 +248,19 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
                 cf pc[8];
 #pragma unroll
                 for (int m = 0; m < 8; ++m) pc[m] = a.pz[(size_t)x * NY + tid + m * C::T];
-                if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
+                if constexpr (INV) {
+                    if (!a.real_in) line_fft<NY, +1>(u, tw, tid, lds);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], pc[m], db[m]);
+                    for (int m = 0; m < 8; ++m) u[m] = unmodulate_eps(cscale(u[m], a.in_scale), pc[m], db[m], make_float2(0.f, 0.f));
+                } else {
+                    if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], pc[m], db[m]);
+                }
+            } else if constexpr (INV) {
+                if (!a.real_in) line_fft<NY, +1>(u, tw, tid, lds);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) u[m] = unmodulate_eps(cscale(u[m], a.in_scale), a.carrier, db[m], a.cshift);
             } else {
                 if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
 #pragma unroll
@@ -547,12 +570,15 @@ struct RowBwdArgs {
     AdjCarrier ac;     // GC kernels: constant part of the adjoint field (far field + plane-wave carrier)
     cf cshift;         // a_z (cbar - 1)
     cf carrier_phi;    // cbar a_z: constant part of phi_z
+    float tape_scale;  // HIST 3
 };
 
 // HIST = 0: phi_z (scattered part) is read from the tape A_z wrote.  HIST = 1: the tape holds the per-slice history
 // psi_hat_z (the INPUT of A_z, written by the transfer-function kernel anyway) and phi_z is recomputed here with A_z's own
 // operations (inverse transform, modulation) — one more transform per launch, 8 B per pixel less traffic in A.
 // HIST = 2: slice 0 of that mode, phi_0 from the probe (no transform).
+// HIST = 3: tape-free adjoint — `tape` is the hybrid scattered part of phi_z itself, marched back by A_{z+1}^-1 and the
+// adjoint transfer-function step (one inverse transform here, no modulation); tape_scale multiplies it.
 template <int NY, int HIST, bool PF = false, bool GC = false>
 __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd(RowBwdArgs a) {
     typedef RowCfg<NY> C;
@@ -588,8 +614,12 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
 #pragma unroll
                 for (int m = 0; m < 8; ++m) pc[m] = a.pz[(size_t)x * NY + tid + m * C::T];
             }
-            if constexpr (HIST == 1) line_fft<NY, +1>(p, tw, tid, lds);                // psi_hat_z -> psi_z (scattered part)
-            if constexpr (HIST != 0) {
+            if constexpr (HIST == 1 || HIST == 3) line_fft<NY, +1>(p, tw, tid, lds);   // psi_hat_z -> psi_z (scattered part)
+            if constexpr (HIST == 3) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) p[m] = cscale(p[m], a.tape_scale);
+            }
+            if constexpr (HIST == 1 || HIST == 2) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) p[m] = PF ? modulate_eps(p[m], pc[m], db[m]) : modulate_eps_s(p[m], a.carrier, db[m], a.cshift);
             }

@@ -205,6 +205,7 @@ int bdof_comm_sync(bdof_comm* comm);
 /* Device memory helpers for hosts without an allocator of their own.  bdof_malloc allocates on the calling thread's
  * current device, bdof_ctx_malloc on the ctx's device. */
 int bdof_ctx_malloc(bdof_ctx* ctx, void** ptr, size_t bytes);
+int bdof_device_mem(bdof_ctx* ctx, size_t* free_bytes, size_t* total_bytes);   /* hipMemGetInfo of the ctx's device */
 int bdof_malloc(void** ptr, size_t bytes);
 int bdof_free(void* ptr);
 int bdof_memcpy_h2d(bdof_ctx* ctx, void* dst, const void* src, size_t bytes);
