@@ -35,6 +35,9 @@ _SIGNATURES = {
     'bdof_set_object': (ctypes.c_int, [_vp, _vp, ctypes.c_longlong, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int]),
     'bdof_set_rotation_adjoint': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
     'bdof_forward': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_int]),
+    'bdof_forward_range': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
+    'bdof_tiles_gather': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
+    'bdof_tiles_scatter': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     'bdof_tape_to_real': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     'bdof_loss_grad': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     'bdof_set_conv': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_double] * 5),

@@ -318,15 +318,17 @@ template <class T> static T* sub_field(const bdof_ctx* c, T* p) { return p ? p +
 // A_z: L1 (or the probe) -> L2 (tstore) or L1 (plain)
 static const cf* slice_carrier_field(const bdof_ctx* c, int z) { return c->pstack ? c->pstack + (size_t)z * c->NX * c->NY : nullptr; }
 
-static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore, cf* phi_out = nullptr) {
+// start != nullptr: slice z starts from the real-space fields start[b] (scattered part) instead of the hybrid `in` — the
+// first slice of a range (bdof_forward_range); z == 0 without `start` starts from the probe shared by the batch.
+static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore, cf* phi_out = nullptr, const cf* start = nullptr) {
     ProfScope ps(c, BDOF_K_ROW_FWD);
-    RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), sub_field(c, phi_out), sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
-                 slice_carrier_field(c, z), cshift_at(c, z), 0, 1.f};
+    RowFwdArgs a{sub_field(c, in), start ? sub_field(c, start) : c->probe, sub_field(c, out), sub_field(c, phi_out), sub_obj(c), B, c->NX, z,
+                 c->k, carrier_at(c, z), c->twY, slice_carrier_field(c, z), cshift_at(c, z), 0, 1.f, start ? 1 : 0};
     const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
-        if (z == 0) {
+        if (z == 0 || start) {
             if (pf) {
                 if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, true, true, true>), grid, blk, 0, c->sub_stream, a);
                 else hipLaunchKernelGGL((k_row_fwd<N_, true, false, true>), grid, blk, 0, c->sub_stream, a);
@@ -348,7 +350,7 @@ static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, boo
 static void launch_row_unmod(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool real_in, float in_scale) {
     ProfScope ps(c, BDOF_K_ROW_FWD);
     RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), nullptr, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
-                 slice_carrier_field(c, z), cshift_at(c, z), real_in ? 1 : 0, in_scale};
+                 slice_carrier_field(c, z), cshift_at(c, z), real_in ? 1 : 0, in_scale, 0};
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
@@ -1059,6 +1061,81 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
         }
         c->last_valid = true;
     }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_forward_range(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
+                       const void* in_real, void* out_real, int prop_last) {
+    int r = check_ready(c, B);
+    if (r) return r;
+    if (!in_real || !out_real) return BDOF_ERR_ARG;
+    if (z0 < 0 || nz < 1 || z0 + nz > c->S) return fail(c, BDOF_ERR_ARG, "slice range outside [0, S)");
+    if (c->generic) return fail(c, BDOF_ERR_SIZE, "bdof_forward_range runs on the fused streaming kernels (NY, NX powers of two in 64..1024)");
+    if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
+    HIPC(c, hipSetDevice(c->device));
+    set_batch_views(c, angle_of_b, xoff, yoff);
+    if ((r = ensure_modulation(c))) return r;
+    Group groups[BDOF_MAX_GROUPS];
+    const int ng = batch_groups(c, B, c->NX, 16, groups);
+    if ((r = fork_streams(c, ng))) return r;
+    for (int z = z0; z < z0 + nz; ++z) {
+        const bool last = z == z0 + nz - 1;
+        for (int gi = 0; gi < ng; ++gi) {
+            const int Bg = groups[gi].B;
+            use_group(c, groups[gi]);
+            const cf* start = z == z0 ? (const cf*)in_real : nullptr;
+            if (!last || prop_last) {
+                launch_row_fwd(c, Bg, z, c->bufB, c->bufA, true, nullptr, start);
+                launch_row_prop(c, Bg, c->bufA, c->bufB, c->hs, 1.f, 0);
+            } else {
+                launch_row_fwd(c, Bg, z, c->bufB, c->bufA, false, nullptr, start);
+            }
+        }
+    }
+    // real-space wave after the range: psi_{z0+nz} (prop_last) or phi_{z0+nz-1}
+    const int zl = z0 + nz - 1;
+    for (int gi = 0; gi < ng; ++gi) {
+        use_group(c, groups[gi]);
+        if (prop_last)
+            launch_loss_real(c, groups[gi].B, c->bufB, nullptr, false, (cf*)out_real, nullptr, 1.f, 1.f, 0.f, carrier_at(c, zl + 1),
+                             zl + 1 < c->S ? slice_carrier_field(c, zl + 1) : c->pdet);
+        else
+            launch_loss_real(c, groups[gi].B, c->bufA, nullptr, false, (cf*)out_real, nullptr, 1.f / c->NY, 1.f, 0.f, carrier_phi_at(c, zl),
+                             slice_carrier_field(c, zl));
+    }
+    if ((r = join_streams(c, ng))) return r;
+    c->tape_valid = c->last_valid = false;
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+static int tiles_check(bdof_ctx* c, const void* field, const void* tiles, int B, int FX, int FY, int TX, int TY, const int* x0, const int* y0) {
+    if (!c || !field || !tiles || !x0 || !y0) return BDOF_ERR_ARG;
+    if (B < 1 || FX < 1 || FY < 1 || TX < 1 || TY < 1) return fail(c, BDOF_ERR_ARG, "bad tile / field shape");
+    return 0;
+}
+
+int bdof_tiles_gather(bdof_ctx* c, const void* field, int FX, int FY, void* tiles, int B, int TX, int TY, const int* x0, const int* y0,
+                      int taper) {
+    int r = tiles_check(c, field, tiles, B, FX, FY, TX, TY, x0, y0);
+    if (r) return r;
+    HIPC(c, hipSetDevice(c->device));
+    if (taper < 0 || 2 * taper > TX || 2 * taper > TY) return fail(c, BDOF_ERR_ARG, "taper must fit the tile");
+    TileArgs a{(cf*)field, (cf*)tiles, x0, y0, B, FX, FY, TX, TY, 0, 0, taper};
+    hipLaunchKernelGGL(k_tiles_gather, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_tiles_scatter(bdof_ctx* c, const void* tiles, void* field, int FX, int FY, int B, int TX, int TY, const int* x0, const int* y0,
+                       int halo_x, int halo_y) {
+    int r = tiles_check(c, field, tiles, B, FX, FY, TX, TY, x0, y0);
+    if (r) return r;
+    if (halo_x < 0 || halo_y < 0 || 2 * halo_x >= TX || 2 * halo_y >= TY) return fail(c, BDOF_ERR_ARG, "halo must leave a core");
+    HIPC(c, hipSetDevice(c->device));
+    TileArgs a{(cf*)field, (cf*)tiles, x0, y0, B, FX, FY, TX, TY, halo_x, halo_y, 0};
+    hipLaunchKernelGGL(k_tiles_scatter, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;
 }

@@ -54,14 +54,15 @@ class MultisliceEngine(object):
         self._tables = None
 
     # ---- physics -------------------------------------------------------------------------------
-    def set_physics(self, energy_ev, psize_cm, free_prop_cm=None, variant='numpy_skip_last', pi=util.PI):
-        """k and H exactly as cnn_propagator/np_funcs.py:19-32,45-57 derive them from energy / pixel size."""
+    def set_physics(self, energy_ev, psize_cm, free_prop_cm=None, variant='numpy_skip_last', pi=util.PI, field_shape=None):
+        """k and H exactly as cnn_propagator/np_funcs.py:19-32,45-57 derive them from energy / pixel size.  field_shape: this
+        engine's wavefields are tiles of a (FY, FX) field and apply that field's propagator (util.get_kernel_tile)."""
         voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
         lmbda_nm = 1240. / energy_ev
         delta_nm = voxel_nm[-1]
         k = 2. * pi * delta_nm / lmbda_nm
-        hs = util.device_transfer_function(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi)
-        h00 = np.array(util.transfer_function_dc(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi))
+        hs = util.device_transfer_function(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, field_shape=field_shape)
+        h00 = np.array(util.transfer_function_dc(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, field_shape=field_shape))
         hdet = hdet00 = None
         if free_prop_cm is None:
             det = _lib.DET_NONE
@@ -179,6 +180,15 @@ class MultisliceEngine(object):
         eps = np.ascontiguousarray(((probe.astype(np.complex128) - a0) * gain).T.astype(np.complex64))
         self.ctx.check(self.lib.bdof_set_probe(self.h, eps.ctypes.data, a0.real, a0.imag))
         self._set_meas_mode(a0)
+
+    def set_probe_none(self):
+        """No probe of the ctx's own: every wavefield starts from a caller-supplied field (bdof_forward_range), no carrier."""
+        self._probe_args = None
+        zero = np.zeros((self.nx, self.ny), dtype=np.complex64)
+        self.ctx.check(self.lib.bdof_set_probe(self.h, zero.ctypes.data, 0.0, 0.0))
+        self.ctx.check(self.lib.bdof_set_probe_stack(self.h, None, None))
+        self.probe_stack, self.probe_gain = False, 1.0
+        self._set_meas_mode(0j)
 
     def _set_meas_mode(self, a0):
         """Residual splitting at the detector (include/bdof.h, bdof_set_meas_mode): with a plane-wave carrier and a real-space

@@ -1,0 +1,96 @@
+"""Tiled ("pfft") Fresnel multislice propagation — the feature the reference repository is named after
+(README.md:1-11, "Tiling-based Fresnel multislice propagation"; its scripts live on a branch that is not in the checkout,
+so the whole-field FFT propagator of np_funcs.py:15-65 on the same field is the oracle: parity unpinned by reference code).
+
+A (FY, FX) wavefield too large for one fused FFT plan (BASELINE cfg4: a 512^2 probe zero-padded into 4096^2, 1024 slices) is
+cut into overlapping T x T tiles, T a fused plan size.  The tiles run through libbdof's per-slice kernels as ONE batch
+(bdof_forward_range), each seeing its window of the object (the ptychography window mechanism: origins in xoff / yoff).  A
+tile's own FFT is periodic, so errors enter at its edges and move inwards by at most lambda dz / (2 dx^2) pixels per slice (the
+steepest ray the grid carries); before they have crossed the halo the cores are stitched back into the field and the tiles
+re-cut with fresh halos (bdof_tiles_scatter / bdof_tiles_gather).  The tiles apply the FIELD's transfer function
+(util.get_kernel_tile), not that of a T-point mesh.
+"""
+import numpy as np
+
+from . import _lib, util
+from ._lib import DeviceBuffer
+from .engine import MultisliceEngine
+
+
+class TiledPropagator(object):
+    def __init__(self, field_shape, n_slice, energy_ev, psize_cm, tile=512, halo=64, slices_per_exchange=None, safety=0.5,
+                 taper=None, variant='numpy_skip_last', device=0, pi=util.PI):
+        """field_shape (FY, FX); tile: fused plan size (64 ... 1024); halo: pixels per side that are recomputed, not kept; its
+        outer `taper` pixels (default halo / 2) are ramped to zero so that the tile's periodic boundary has no jump.
+        slices_per_exchange: slices between two stitches; default safety * (halo - taper) / (lambda dz / (2 dx^2))."""
+        self.fy, self.fx = int(field_shape[0]), int(field_shape[1])
+        self.n_slice, self.tile, self.halo = int(n_slice), int(tile), int(halo)
+        if 2 * self.halo >= self.tile:
+            raise ValueError('the halo must leave a core')
+        self.core = self.tile - 2 * self.halo
+        self.taper = self.halo // 2 if taper is None else int(taper)
+        self.variant = variant
+        voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
+        lmbda_nm = 1240. / energy_ev
+        self.spread_px = lmbda_nm * voxel_nm[2] / (2. * voxel_nm[0] ** 2)      # lateral reach of the band-edge ray per slice
+        if slices_per_exchange is None:
+            slices_per_exchange = max(1, int(safety * (self.halo - self.taper) / self.spread_px)) if self.halo > 0 else self.n_slice
+        self.seg = max(1, int(slices_per_exchange))
+        # tile origins: cores tile the field, halos reach periodically across its edges
+        ox = [i * self.core - self.halo for i in range(-(-self.fx // self.core))]
+        oy = [i * self.core - self.halo for i in range(-(-self.fy // self.core))]
+        self.x0 = np.repeat(np.array(ox, dtype=np.int32), len(oy))
+        self.y0 = np.tile(np.array(oy, dtype=np.int32), len(ox))
+        self.n_tiles = len(self.x0)
+        self.eng = MultisliceEngine(self.tile, self.tile, self.n_slice, self.n_tiles, with_grad=False, device=device, engine='streaming')
+        self.ctx, self.lib, self.h = self.eng.ctx, self.eng.lib, self.eng.h
+        self.eng.set_physics(energy_ev, psize_cm, None, variant=variant, pi=pi, field_shape=(self.fy, self.fx))
+        self.eng.set_probe_none()
+        self.idx = DeviceBuffer.from_host(self.ctx, np.stack([np.zeros(self.n_tiles, dtype=np.int32), self.x0, self.y0]))
+        n = self.n_tiles * self.tile * self.tile
+        self.tiles_in = DeviceBuffer(self.ctx, n * 8, np.complex64, (self.n_tiles, self.tile, self.tile))
+        self.tiles_out = DeviceBuffer(self.ctx, n * 8, np.complex64, (self.n_tiles, self.tile, self.tile))
+        self.field = DeviceBuffer(self.ctx, self.fx * self.fy * 8, np.complex64, (self.fx, self.fy))
+
+    # ---- object --------------------------------------------------------------------------------
+    def set_object_slab(self, delta2d, beta2d):
+        """The same (FY, FX) slab in every slice (a thick zone plate): one set of rows, a table that maps every slice to it."""
+        rows = np.ascontiguousarray(np.stack([np.asarray(delta2d).T, np.asarray(beta2d).T], axis=-1).astype(np.float32))     # [x][y] pairs
+        vol = DeviceBuffer.from_host(self.ctx, rows)
+        tab = np.ascontiguousarray(np.tile(np.arange(self.fx, dtype=np.int32), (1, self.n_slice, 1)))             # [1][S][x] -> row x
+        self.eng.set_volume(vol, self.fx, self.fy, DeviceBuffer.from_host(self.ctx, tab), self.fx, 1)
+
+    def set_object(self, delta, beta):
+        """(FY, FX, S) object: rows [x][z][y] of pairs and the identity table row(z, x) = x * S + z."""
+        rows = util.volume_to_rows(delta, beta)                                                                   # [X][Z][Y][2]
+        vol = DeviceBuffer.from_host(self.ctx, rows)
+        x = np.arange(self.fx, dtype=np.int32)
+        z = np.arange(self.n_slice, dtype=np.int32)
+        tab = np.ascontiguousarray((x[None, :] * self.n_slice + z[:, None])[None].astype(np.int32))               # [1][S][X]
+        self.eng.set_volume(vol, self.fx * self.n_slice, self.fy, DeviceBuffer.from_host(self.ctx, tab), self.fx, 1)
+
+    # ---- forward -------------------------------------------------------------------------------
+    def segments(self):
+        return [(z0, min(self.seg, self.n_slice - z0)) for z0 in range(0, self.n_slice, self.seg)]
+
+    def forward_device(self):
+        """Propagate the device field in place through all slices (np_funcs.py:36-43: no step after the last slice unless
+        variant == 'tf_all')."""
+        lib, h, p = self.lib, self.h, self.idx.ptr
+        a, xo, yo = p, p + 4 * self.n_tiles, p + 8 * self.n_tiles
+        for z0, nz in self.segments():
+            last = z0 + nz == self.n_slice
+            self.ctx.check(lib.bdof_tiles_gather(h, self.field.ptr, self.fx, self.fy, self.tiles_in.ptr, self.n_tiles, self.tile, self.tile, xo, yo,
+                                                 self.taper))
+            self.ctx.check(lib.bdof_forward_range(h, self.n_tiles, a, xo, yo, z0, nz, self.tiles_in.ptr, self.tiles_out.ptr,
+                                                  int(not last or self.variant == 'tf_all')))
+            self.ctx.check(lib.bdof_tiles_scatter(h, self.tiles_out.ptr, self.field.ptr, self.fx, self.fy, self.n_tiles, self.tile, self.tile,
+                                                  xo, yo, self.halo, self.halo))
+
+    def forward(self, probe_real, probe_imag):
+        """Exit wave (FY, FX) complex64 of the probe (FY, FX) through the object."""
+        probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.fy, self.fx))
+        self.field.upload(np.ascontiguousarray(probe.T.astype(np.complex64)))
+        self.forward_device()
+        self.ctx.sync()
+        return np.ascontiguousarray(self.field.download().T)

@@ -95,6 +95,26 @@ int bdof_set_rotation_adjoint(bdof_ctx* ctx, const int* off, const int* order, i
  * hybrid fields for bdof_tape_to_real (needs with_grad). */
 int bdof_forward(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave, int keep_tape);
 
+/* Slices z0 .. z0+nz-1 only, from caller-supplied real-space fields: in_real [B][NX][NY] complex is the (scattered part of
+ * the) wave entering slice z0, one field per wavefield; out_real receives the wave after the range in real space —
+ * psi_{z0+nz} if prop_last (a transfer-function step follows the last slice of the range), else phi_{z0+nz-1}.  Fused
+ * streaming kernels only.  The building block of the tiled propagation below; np_funcs.py:36-43 restricted to a range. */
+int bdof_forward_range(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
+                       const void* in_real, void* out_real, int prop_last);
+
+/* Tiled ("pfft") Fresnel propagation (the reference's README.md:1-11; its scripts are on a branch absent from the checkout,
+ * BASELINE cfg4): a field [FX][FY] complex too large for one fused plan is cut into B overlapping tiles [TX][TY] with origins
+ * (x0[b], y0[b]) (device int32; periodic in the field, like the whole-field FFT propagator they replace); the tiles run
+ * through bdof_forward_range as a batch with the object windowed by the same origins; every few slices the cores (tile minus
+ * a halo of halo_x / halo_y pixels per side) are written back and the tiles re-cut, which refreshes the halos before the
+ * wrap-around of a tile's own periodic boundary has crossed them (it advances lambda dz / (2 dx^2) pixels per slice).  The
+ * outermost `taper` pixels of every gathered tile are ramped to zero (raised cosine): without the ramp the jump where a tile's
+ * left and right edge meet diffracts into it with a 1/distance tail. */
+int bdof_tiles_gather(bdof_ctx* ctx, const void* field, int FX, int FY, void* tiles, int B, int TX, int TY, const int* x0, const int* y0,
+                      int taper);
+int bdof_tiles_scatter(bdof_ctx* ctx, const void* tiles, void* field, int FX, int FY, int B, int TX, int TY, const int* x0, const int* y0,
+                       int halo_x, int halo_y);
+
 /* probe_array[i] of np_funcs.py:43 (wave after slice i), device out [B][NX][NY]; valid after a
  * bdof_forward(keep_tape=1) (bdof_loss_grad reuses the tape for its own purposes and invalidates it). */
 int bdof_tape_to_real(bdof_ctx* ctx, int i, int B, void* out);

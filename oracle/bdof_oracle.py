@@ -490,3 +490,73 @@ def cnn_loss_and_grad(grid_delta, grid_beta, probe_real, probe_imag, energy_ev, 
         g_beta[..., i] = -k * t.real
         Gp = np.conj(c) * Gphi
     return loss, g_delta, g_beta
+
+
+# ---------------------------------------------------------------------------
+# Tiled ("pfft") propagation                       /root/reference/README.md:1-11
+#   The reference's tiled propagator lives on a branch that is not in the checkout: PARITY UNPINNED by reference code.
+#   What is stated here is the algorithm of the paper's title — overlapping tiles, periodic tile FFTs, cores stitched back
+#   before the wrap-around crosses the halo — in float64, so that (a) its deviation from the whole-field propagator above
+#   (which IS golden-pinned) can be measured on the CPU, and (b) the device implementation can be checked against the same
+#   algorithm to float32 round-off.
+# ---------------------------------------------------------------------------
+def get_kernel_tile(dist_nm, lmbda_nm, voxel_nm, tile_shape, field_shape, pi=PI):
+    """H of the (FY, FX) field's propagator (get_kernel above, mesh quirk Q4 of the FIELD) at the FFT frequencies of a tile."""
+    def axis(t, n, vox):
+        u_max = 1. / (2. * vox)
+        f = (np.arange(t) - t // 2) / (t * vox)
+        return -u_max + (f * n * vox + n // 2) * 2. * u_max / (n - 1)
+    v = axis(tile_shape[0], field_shape[0], voxel_nm[1])
+    u = axis(tile_shape[1], field_shape[1], voxel_nm[0])
+    uu, vv = np.meshgrid(u, v)
+    return np.exp(1j * (2 * pi / lmbda_nm) * dist_nm) * np.exp(-1j * pi * lmbda_nm * dist_nm * (uu ** 2 + vv ** 2))
+
+
+def tile_origins(field_n, tile, halo):
+    core = tile - 2 * halo
+    return [i * core - halo for i in range(-(-field_n // core))]
+
+
+def tiled_multislice_propagate(grid_delta, grid_beta, probe, energy_ev, psize_cm, tile, halo, slices_per_exchange,
+                               taper=0, variant='numpy_skip_last', pi=PI):
+    """Exit wave (FY, FX) of `probe` (FY, FX) through the object (FY, FX, S) by tiled propagation.  Every
+    `slices_per_exchange` slices: cut periodic (tile x tile) windows at tile_origins, run the slices on each window with
+    its own periodic FFT and the field's transfer function, write the cores back.  The outermost `taper` pixels of every
+    window are ramped to zero first (raised cosine), so that the window's periodic boundary carries no jump."""
+    fy, fx, n_slice = grid_delta.shape
+    voxel_nm = np.array([psize_cm] * 3) * 1.e7
+    lmbda_nm = 1240. / energy_ev
+    delta_nm = voxel_nm[-1]
+    k = 2. * pi * delta_nm / lmbda_nm
+    h = np.fft.ifftshift(get_kernel_tile(delta_nm, lmbda_nm, voxel_nm, (tile, tile), (fy, fx), pi=pi))
+    field = np.array(probe, dtype=np.complex128)
+    w1 = np.ones(tile)
+    if taper > 0:
+        ramp = 0.5 - 0.5 * np.cos(np.pi * (np.arange(taper) + 0.5) / taper)
+        w1[:taper] = ramp
+        w1[tile - taper:] = ramp[::-1]
+    win = w1[:, None] * w1[None, :]
+    oy, ox = tile_origins(fy, tile, halo), tile_origins(fx, tile, halo)
+    core = tile - 2 * halo
+    for z0 in range(0, n_slice, slices_per_exchange):
+        nz = min(slices_per_exchange, n_slice - z0)
+        new = np.empty_like(field)
+        for y0 in oy:
+            iy = np.arange(y0, y0 + tile) % fy
+            for x0 in ox:
+                ix = np.arange(x0, x0 + tile) % fx
+                w = field[np.ix_(iy, ix)] * win
+                # the object is NOT periodic: outside the volume the tile sees vacuum (what the device window does)
+                inside = ((np.arange(y0, y0 + tile) >= 0) & (np.arange(y0, y0 + tile) < fy))[:, None] & \
+                         ((np.arange(x0, x0 + tile) >= 0) & (np.arange(x0, x0 + tile) < fx))[None, :]
+                for z in range(z0, z0 + nz):
+                    d = np.where(inside, grid_delta[np.ix_(iy, ix)][..., z], 0.0)
+                    b = np.where(inside, grid_beta[np.ix_(iy, ix)][..., z], 0.0)
+                    w = w * (np.exp(1j * k * d) * np.exp(-k * b))
+                    if z < n_slice - 1 or variant == 'tf_all':
+                        w = np.fft.ifft2(np.fft.fft2(w) * h)
+                cy = np.arange(y0 + halo, y0 + halo + core) % fy
+                cx = np.arange(x0 + halo, x0 + halo + core) % fx
+                new[np.ix_(cy, cx)] = w[halo:halo + core, halo:halo + core]
+        field = new
+    return field

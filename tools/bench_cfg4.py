@@ -1,6 +1,8 @@
-"""cfg4 timing (BASELINE configs[3]): a 512^2 probe in a 4k x 4k zero-padded field through a 1024-slice zone-plate object,
-whole-field FFT propagation on the rocFFT engine, forward model only (the tape + gradient of 1024 slices of 4096^2 would
-need 2 x 137 GB).  usage: python tools/bench_cfg4.py [n=4096] [slices=1024]"""
+"""cfg4 (BASELINE configs[3]): a 512^2 probe in a 4k x 4k zero-padded field through a 1024-slice zone-plate object, forward
+model.  Tiled propagation on the fused kernels (beyond_dof_amd.tiling) against the whole-field transform on the rocFFT engine:
+time per 1024 slices and the deviation of the exit waves, for several tile / halo choices (the error-vs-halo curve of DESIGN).
+usage: python tools/bench_cfg4.py [n=4096] [slices=1024] [json out]"""
+import json
 import os
 import sys
 import time
@@ -11,24 +13,31 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry  # noqa: E402
 
 entry.build()
-from beyond_dof_amd import _lib, util  # noqa: E402
+from beyond_dof_amd import _lib  # noqa: E402
 from beyond_dof_amd.engine import MultisliceEngine  # noqa: E402
+from beyond_dof_amd.tiling import TiledPropagator  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+out_json = sys.argv[3] if len(sys.argv) > 3 else None
 yy, xx = np.mgrid[:n, :n].astype(np.float32)
 r2 = (yy - n / 2) ** 2 + (xx - n / 2) ** 2
 # Fresnel zone plate, outermost zone 4 px wide at radius 256: zones at r_k^2 = k * r1^2 with r1^2 = 2 * 256 * 4
 zone = (np.floor(r2 / (2 * 256 * 4.0)).astype(np.int64) % 2 == 0) & (r2 < 256.0 ** 2)
 slab = np.where(zone, 5e-5, 0.0).astype(np.float32)
 del yy, xx, r2
-pr = np.zeros((n, n), dtype=np.float32)
-c0 = n // 2 - 256
-pr[c0:c0 + 512, c0:c0 + 512] = 1.0
+# the 512^2 probe in the zero-padded field, with 32-pixel raised-cosine edges: a hard-edged one would make the whole-field FFT
+# propagator ring across the entire field (alternating 0.04 / x^2 tails of its band-limited kernel), which tiles do not copy
+t = np.arange(n, dtype=np.float32)
+edge = np.clip((256. + 16. - np.abs(t - n / 2)) / 32., 0., 1.)
+soft = (0.5 - 0.5 * np.cos(np.pi * edge)).astype(np.float32)
+pr = np.ascontiguousarray(soft[:, None] * soft[None, :])
+res = {'field': n, 'slices': S, 'runs': []}
+
+# ---- whole field, rocFFT engine (the oracle of the tiling error on the device; float32) ---------------------------------
 eng = MultisliceEngine(n, n, S, 1, with_grad=False)
-eng.set_physics(5000., 1e-7, 1e-4)
+eng.set_physics(5000., 1e-7, None)
 eng.set_probe(pr, np.zeros_like(pr))
-# the object is the same 2-D slab in every slice: one (delta, beta) row set, a table that maps every slice to it
 rows = np.ascontiguousarray(np.stack([slab.T, 0.1 * slab.T], axis=-1).astype(np.float32))          # [x][y] pairs
 vol = _lib.DeviceBuffer.from_host(eng.ctx, rows)
 tab = np.tile(np.arange(n, dtype=np.int32), (1, S, 1))                                         # [1 angle][S][x] -> row x
@@ -38,7 +47,72 @@ for it in range(2):
     t0 = time.perf_counter()
     out = eng.forward(1, angle_idx=[0], to_host=False)
     eng.ctx.sync()
+    dt_whole = time.perf_counter() - t0
+whole = eng._wave_to_host(out, 1)[0]
+print('whole field %d^2 x %d slices (rocFFT engine): %.1f ms (%.0f slices/s)' % (n, S, dt_whole * 1e3, S / dt_whole))
+res['whole_field_ms'] = dt_whole * 1e3
+del eng, vol, out
+
+rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+for tile, halo in ((512, 32), (512, 64), (512, 96), (1024, 64), (1024, 128)):
+    if tile > n:
+        continue
+    tp = TiledPropagator((n, n), S, 5000., 1e-7, tile=tile, halo=halo)
+    tp.set_object_slab(slab, 0.1 * slab)
+    tp.field.upload(np.ascontiguousarray(pr.T.astype(np.complex64)))
+    tp.forward_device()
+    tp.ctx.sync()
+    tp.field.upload(np.ascontiguousarray(pr.T.astype(np.complex64)))
+    tp.ctx.sync()
+    t0 = time.perf_counter()
+    tp.forward_device()
+    tp.ctx.sync()
     dt = time.perf_counter() - t0
-w = eng._wave_to_host(out, 1)
-print('%d^2 field, %d slices, forward: %.1f ms (%.0f slices/s, %.1f GB/s at 40 B/px forward model), |wave|^2 sum %.6e' %
-      (n, S, dt * 1e3, S / dt, 40.0 * n * n * S / dt / 1e9, float((np.abs(w) ** 2).sum())))
+    w = np.ascontiguousarray(tp.field.download().T)
+    px = tp.n_tiles * tile * tile
+    run = {'tile': tile, 'halo': halo, 'taper': tp.taper, 'tiles': tp.n_tiles, 'slices_per_exchange': tp.seg, 'ms': dt * 1e3,
+           'overhead_px': px / float(n * n), 'GBps_40B_model': 40.0 * px * S / dt / 1e9,
+           'rel_err_wave_vs_whole_field': rel(w, whole), 'rel_err_intensity': rel(np.abs(w) ** 2, np.abs(whole) ** 2)}
+    res['runs'].append(run)
+    print('tiles %4d^2 halo %3d (taper %2d, %3d tiles, stitch every %3d slices): %7.1f ms = %.2fx whole field; wave err %.2e, intensity err %.2e, '
+          '%.0f GB/s at 40 B/px' % (tile, halo, tp.taper, tp.n_tiles, tp.seg, dt * 1e3, dt / dt_whole, run['rel_err_wave_vs_whole_field'],
+                                   run['rel_err_intensity'], run['GBps_40B_model']))
+    del tp
+if out_json:
+    json.dump(res, open(out_json, 'w'), indent=1)
+
+# ---- which of the two float32 results is closer to float64?  (whole-field restatement of np_funcs.py:36-43 with scipy's
+# threaded FFT, at a reduced slice count: 4096^2 complex128 transforms take seconds each on the host) ----------------------
+n_or = int(os.environ.get('CFG4_ORACLE_SLICES', '0'))
+if n_or > 0:
+    import scipy.fft as sfft
+    from beyond_dof_amd import util
+    S2 = n_or
+    h = np.fft.ifftshift(util.get_kernel(1.0, 0.248, [1., 1., 1.], (n, n)))
+    cmod = np.exp(1j * (2 * util.PI * 1.0 / 0.248) * slab.astype(np.float64)) * np.exp(-(2 * util.PI * 1.0 / 0.248) * 0.1 * slab.astype(np.float64))
+    w = pr.astype(np.complex64).astype(np.complex128)
+    t0 = time.perf_counter()
+    for z in range(S2):
+        w = w * cmod
+        if z < S2 - 1:
+            w = sfft.ifft2(sfft.fft2(w, workers=-1) * h, workers=-1)
+    print('float64 whole field, %d slices on the host: %.0f s' % (S2, time.perf_counter() - t0))
+    eng = MultisliceEngine(n, n, S2, 1, with_grad=False)
+    eng.set_physics(5000., 1e-7, None)
+    eng.set_probe(pr, np.zeros_like(pr))
+    vol = _lib.DeviceBuffer.from_host(eng.ctx, rows)
+    eng.set_volume(vol, n, n, _lib.DeviceBuffer.from_host(eng.ctx, np.ascontiguousarray(tab[:, :S2])), n, 1)
+    whole2 = eng.forward(1, angle_idx=[0])[0]
+    res['float64_check'] = {'slices': S2, 'whole_field_rocfft_vs_float64': rel(whole2, w), 'tiled': []}
+    print('  whole field (rocFFT, float32) vs float64: %.2e' % res['float64_check']['whole_field_rocfft_vs_float64'])
+    del eng, vol
+    for tile, halo in ((512, 32), (512, 64), (1024, 64)):
+        tp = TiledPropagator((n, n), S2, 5000., 1e-7, tile=tile, halo=halo)
+        tp.set_object_slab(slab, 0.1 * slab)
+        o = tp.forward(pr, np.zeros_like(pr))
+        e = rel(o, w)
+        res['float64_check']['tiled'].append({'tile': tile, 'halo': halo, 'vs_float64': e, 'vs_whole_field_float32': rel(o, whole2)})
+        print('  tiles %d^2 halo %d vs float64: %.2e   (vs the float32 whole field: %.2e)' % (tile, halo, e, rel(o, whole2)))
+        del tp
+    if out_json:
+        json.dump(res, open(out_json, 'w'), indent=1)
