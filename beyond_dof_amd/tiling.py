@@ -1,6 +1,6 @@
 """Tiled ("pfft") Fresnel multislice propagation — the feature the reference repository is named after
 (README.md:1-11, "Tiling-based Fresnel multislice propagation"; its scripts live on a branch that is not in the checkout,
-so the whole-field FFT propagator of np_funcs.py:15-65 on the same field is the oracle: parity unpinned by reference code).
+so it is checked against the whole-field FFT propagator of np_funcs.py:15-65 on the same field: parity unpinned by reference code).
 
 A (FY, FX) wavefield too large for one fused FFT plan (BASELINE cfg4: a 512^2 probe zero-padded into 4096^2, 1024 slices) is
 cut into overlapping T x T tiles, T a fused plan size.  The tiles run through libbdof's per-slice kernels as ONE batch
