@@ -132,3 +132,48 @@ def create_ptychography_data_batch_numpy(energy_ev, psize_cm, n_theta, phantom_p
                           overwrite=True, dtype='float32')
     h5io.write_dataset(path, 'exchange/data', dat)
     return dat
+
+
+def create_noisy_data(src_fname, dest_fname, n_ph_tx, grid_delta=None, n_sample_pixel=None, is_ptycho=None, rng=None,
+                      overwrite=False):
+    """Photon (Poisson) noise on a simulated dataset — tensorflow_recon/create_noisy_data.py:20-87 as a function.
+
+    n_ph_tx: total number of photons through the sample (the script's '1.75e6' ... strings); n_sample_pixel: voxels of
+    the phantom with delta > 1e-10 (:14, from grid_delta when not given).  Full field (:74-86): every projection's
+    intensity |prj|^2 is scaled to n_ph = n_ph_tx / n_sample_pixel photons per unit intensity, Poisson-sampled, scaled
+    back, and stored as its square root.  Ptychography (:45-72): the photons per diffraction pattern are
+    n_ph_tx * grid_delta.size / n_sample_pixel / n_positions, distributed over the pattern in proportion to its intensity.
+    The noisy AMPLITUDE goes to `exchange/data` as complex64 (phase is lost, as in the reference).  Returns the mean
+    signal-to-noise ratio var(I) / var(noise) the script prints (:88)."""
+    rng = rng or np.random
+    src = h5io.File(src_fname)['exchange/data']
+    if is_ptycho is None:
+        is_ptycho = 'ptycho' in src_fname or len(src.shape) == 4              # :29-31
+    if n_sample_pixel is None:
+        if grid_delta is None:
+            raise ValueError('give grid_delta (the phantom) or n_sample_pixel')
+        n_sample_pixel = int(np.count_nonzero(np.asarray(grid_delta) > 1e-10))
+    n_ph = float(n_ph_tx) / n_sample_pixel
+    _check_target(dest_fname, overwrite)
+    out = np.empty(src.shape, dtype=np.complex64)
+    snr = []
+    if is_ptycho:
+        if grid_delta is None:
+            raise ValueError('the ptychography branch needs grid_delta (photons per image scale with its size, :49-51)')
+        n_ex = n_ph * n_sample_pixel * (float(np.asarray(grid_delta).size) / n_sample_pixel) / src.shape[1]
+        for i in range(src.shape[0]):
+            block = np.asarray(src[i])
+            for j in range(src.shape[1]):
+                inten = np.abs(block[j]) ** 2
+                multiplier = n_ex / np.sum(inten)
+                noisy = rng.poisson(inten * multiplier) / multiplier
+                snr.append(np.var(inten) / np.var(noisy - inten))
+                out[i, j] = np.sqrt(noisy).astype(np.complex64)
+    else:
+        for i in range(src.shape[0]):
+            inten = np.abs(np.asarray(src[i])) ** 2
+            noisy = rng.poisson(inten * n_ph) / n_ph
+            snr.append(np.var(inten) / np.var(noisy - inten))
+            out[i] = np.sqrt(noisy).astype(np.complex64)
+    h5io.write_dataset(dest_fname, 'exchange/data', out)
+    return float(np.mean(snr))

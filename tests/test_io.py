@@ -81,3 +81,58 @@ def test_tiff_round_trips(tmp_path):
     tiffio.write_tiff_stack(vol, str(tmp_path / 'fin_sup_mask' / 'mask'), dtype='float32', overwrite=True)
     back = tiffio.read_tiff_stack(str(tmp_path / 'fin_sup_mask' / 'mask_00000.tiff'), range(3), 5)
     assert np.array_equal(back, vol.astype(np.float32))
+
+
+def test_create_noisy_data_fullfield_and_ptycho(tmp_path):
+    """Poisson noise writer (tensorflow_recon/create_noisy_data.py:45-87): photon bookkeeping and statistics."""
+    from beyond_dof_amd import h5io
+    from beyond_dof_amd.simulation import create_noisy_data
+    rng = np.random.RandomState(3)
+    grid_delta = np.zeros((8, 8, 8))
+    grid_delta[2:6, 2:6, 2:6] = 1e-6                                   # 64 sample voxels
+    prj = (1.0 + 0.1 * rng.rand(4, 16, 16)).astype(np.complex64) * np.exp(0.3j)
+    src = str(tmp_path / 'ff.h5')
+    h5io.write_dataset(src, 'exchange/data', prj)
+    dst = str(tmp_path / 'ff_noisy.h5')
+    snr = create_noisy_data(src, dst, '6.4e5', grid_delta=grid_delta, rng=np.random.RandomState(1))
+    out = np.asarray(h5io.read_dataset(dst))
+    assert out.shape == prj.shape and out.dtype == np.complex64 and np.all(out.imag == 0)
+    n_ph = 6.4e5 / 64                                                   # photons per unit intensity
+    counts = np.abs(out) ** 2 * n_ph
+    assert np.allclose(counts, np.round(counts), atol=1e-2)             # integer photon counts before the rescaling
+    inten = np.abs(prj) ** 2
+    z = (np.abs(out) ** 2 - inten) / np.sqrt(inten / n_ph)              # Poisson: variance = mean
+    assert abs(z.mean()) < 0.1 and abs(z.std() - 1) < 0.1
+    assert snr > 0
+    # ptychography: photons per diffraction pattern = n_ph_tx * grid.size / n_sample / n_pos, whatever its intensity scale
+    dp = (rng.rand(2, 5, 12, 12) * np.array([1, 10, 100, 1000, 1e4])[None, :, None, None]).astype(np.complex64)
+    srcp = str(tmp_path / 'data_ptycho.h5')
+    h5io.write_dataset(srcp, 'exchange/data', dp)
+    dstp = str(tmp_path / 'data_ptycho_n.h5')
+    create_noisy_data(srcp, dstp, 1e7, grid_delta=grid_delta, rng=np.random.RandomState(2))
+    outp = np.asarray(h5io.read_dataset(dstp))
+    n_ex = 1e7 * grid_delta.size / 64 / 5
+    for i in range(2):
+        for j in range(5):
+            inten = np.abs(dp[i, j]) ** 2
+            got = np.sum(np.abs(outp[i, j]) ** 2) * n_ex / np.sum(inten)
+            assert abs(got / n_ex - 1) < 5 / np.sqrt(n_ex)              # total counts of the pattern ~ Poisson(n_ex)
+    with pytest.raises(FileExistsError):
+        create_noisy_data(src, dst, 1e6, grid_delta=grid_delta)
+
+
+def test_bigtiff_round_trip(tmp_path):
+    """Volumes beyond 4 GiB are written as BigTIFF (64-bit offsets); the format itself is exercised here on a small stack."""
+    rng = np.random.RandomState(0)
+    vol = rng.rand(3, 7, 5).astype(np.float32)
+    f = tiffio.write_tiff(vol, str(tmp_path / 'big'), dtype='float32', overwrite=True, force_bigtiff=True)
+    raw = open(f, 'rb').read()
+    assert raw[:4] == b'II\x2b\x00'
+    assert np.array_equal(tiffio.read_tiff(f), vol)
+    f2 = tiffio.write_tiff(vol[0], str(tmp_path / 'big2'), dtype='float32', overwrite=True, force_bigtiff=True)
+    assert np.array_equal(tiffio.read_tiff(f2), vol[0])
+    try:
+        import tifffile                         # only present in some images: an independent reader when available
+        assert np.array_equal(tifffile.imread(f), vol)
+    except ImportError:
+        pass
