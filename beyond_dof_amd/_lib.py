@@ -31,6 +31,7 @@ _SIGNATURES = {
     'bdof_set_probe': (ctypes.c_int, [_vp, _vp, ctypes.c_double, ctypes.c_double]),
     'bdof_set_meas_mode': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_probe_stack_supported': (ctypes.c_int, [_vp]),
+    'bdof_set_probe_field': (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     'bdof_set_probe_stack': (ctypes.c_int, [_vp, _vp, _vp]),
     'bdof_set_object': (ctypes.c_int, [_vp, _vp, ctypes.c_longlong, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int]),
     'bdof_set_rotation_adjoint': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int]),
@@ -44,6 +45,8 @@ _SIGNATURES = {
     'bdof_forward_conv': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     'bdof_loss_grad_conv': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     'bdof_get_loss': (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double)]),
+    'bdof_enable_probe_grad': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'bdof_probe_grad': (ctypes.c_int, [_vp, _vp, ctypes.c_int]),
     'bdof_grot': (_vp, [_vp]),
     'bdof_rotation_adjoint': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_float]),
     'bdof_rotation_adjoint_rows': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float]),

@@ -44,6 +44,9 @@ struct bdof_ctx {
     cf *bufA = nullptr, *bufB = nullptr, *tape = nullptr;
     float2* grot = nullptr;
     double2 *gcar = nullptr, *gt0 = nullptr;     // adjoint carrier per wavefield (AdjCarrier, bdof_kernels.h)
+    cf* gpsi0 = nullptr;                         // [Bmax][NX][NY] G(psi_0) per wavefield (bdof_enable_probe_grad)
+    const cf* gpsi_src = nullptr;                // where the last bdof_loss_grad left it (gpsi0, or the generic engine's field)
+    int gpsi_B = 0;
     double *partial = nullptr, *loss_dev = nullptr;
     int npartial = 0;
     float k = 0.f;
@@ -374,7 +377,8 @@ static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* t
     ProfScope ps(c, BDOF_K_ROW_BWD);
     RowBwdArgs a{sub_field(c, gin), hist == 2 ? c->probe : sub_field(c, tape), sub_field(c, gout),
                  c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
-                 slice_carrier_field(c, z), adj_carrier_at(c, c->S - 1 - z), cshift_at(c, z), carrier_phi_at(c, z), tape_scale};
+                 slice_carrier_field(c, z), adj_carrier_at(c, c->S - 1 - z), cshift_at(c, z), carrier_phi_at(c, z), tape_scale,
+                 z == 0 && c->gpsi0 ? c->gpsi0 + (size_t)c->sub_b0 * c->NX * c->NY : nullptr};
     const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
@@ -685,7 +689,7 @@ static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, b
     ResArgs a{c->probe, c->hsT, c->hdetT, grad ? c->tape : nullptr, (size_t)c->Bmax * c->NX * c->NY, c->grot, c->obj, c->res_carrier,
               carrier_det(c), c->pstack, c->pdet, meas, (cf*)out_wave, c->partial, c->twR, B, c->S, c->det_mode,
               c->variant == BDOF_VARIANT_TF_ALL ? 1 : 0, grad ? 1 : 0, c->k, 2.f / ((float)B * (float)c->NX * (float)c->NY), c->meas_dev,
-              c->meas_dev ? meas_dref(c) : 0.f};
+              c->meas_dev ? meas_dref(c) : 0.f, grad ? c->gpsi0 : nullptr};
     const int grid = B < c->npartial ? B : c->npartial;
     int r = 0;
     switch (c->NX) {
@@ -761,7 +765,7 @@ static void free_generic(bdof_ctx* c) {
 
 static void free_workspace(bdof_ctx* c) {
     free_generic(c);
-    void* ptrs[] = {c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->partial, c->loss_dev};
+    void* ptrs[] = {c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->gpsi0, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
     c->pstack = c->pdet = c->pdetT = nullptr;
@@ -771,6 +775,7 @@ static void free_workspace(bdof_ctx* c) {
     c->twY = c->twX = c->hs = c->hdet = c->hcomb = c->probe = c->bufA = c->bufB = c->tape = nullptr;
     c->grot = nullptr;
     c->gcar = c->gt0 = nullptr;
+    c->gpsi0 = nullptr; c->gpsi_src = nullptr;
     c->partial = c->loss_dev = nullptr;
 }
 
@@ -981,6 +986,93 @@ int bdof_set_probe_stack(bdof_ctx* c, const float* stack, const float* det) {
     return 0;
 }
 
+// The carrier field of a localised probe (bdof_set_probe_stack) computed ON THE DEVICE in float64: S - 1 transfer-function steps
+// of one field with rocFFT's double-precision plans (np_funcs.py:42 without an object), each plane rounded once into the
+// float32 stack.  A probe that changes every Adam step (probe_type='optimizable') then costs ~4 small launches per slice
+// instead of 2 S host FFTs and a 1-GiB upload.
+int bdof_set_probe_field(bdof_ctx* c, const double* probe, const double* hT, const double* hdetT) {
+    if (!c || !probe || !hT) return BDOF_ERR_ARG;
+    if (!c->have_physics) return fail(c, BDOF_ERR_STATE, "bdof_set_physics has not been called");
+    if (c->det_mode == BDOF_DET_NEAR && !hdetT) return fail(c, BDOF_ERR_ARG, "hdetT required for BDOF_DET_NEAR");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (!g_rocfft_ready) { RFC(c, rocfft_setup()); g_rocfft_ready = true; }
+    const size_t n = (size_t)c->NX * c->NY, fld = sizeof(cf) * n, dbytes = sizeof(double2) * n;
+    rocfft_plan pf = nullptr, pi = nullptr;
+    rocfft_execution_info info = nullptr;
+    double2 *dp = nullptr, *dh = nullptr, *dhd = nullptr;
+    void* work = nullptr;
+    int rc = 0;
+    auto cleanup = [&]() {
+        if (pf) (void)rocfft_plan_destroy(pf);
+        if (pi) (void)rocfft_plan_destroy(pi);
+        if (info) (void)rocfft_execution_info_destroy(info);
+        for (void* q : {(void*)dp, (void*)dh, (void*)dhd, work}) if (q) (void)hipFree(q);
+    };
+#define PF_TRY(expr) do { rc = (expr); if (rc) { cleanup(); return rc; } } while (0)
+#define PF_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(c, (int)e_, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+#define PF_RF(call) do { rocfft_status s_ = (call); if (s_ != rocfft_status_success) { cleanup(); return fail(c, BDOF_ERR_STATE, std::string(#call) + ": rocfft status " + std::to_string((int)s_)); } } while (0)
+    const size_t lengths[2] = {(size_t)c->NY, (size_t)c->NX};      // fastest dimension first: fields are [x][y]
+    PF_RF(rocfft_plan_create(&pf, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_double, 2, lengths, 1, nullptr));
+    PF_RF(rocfft_plan_create(&pi, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_double, 2, lengths, 1, nullptr));
+    size_t w1 = 0, w2 = 0;
+    PF_RF(rocfft_plan_get_work_buffer_size(pf, &w1));
+    PF_RF(rocfft_plan_get_work_buffer_size(pi, &w2));
+    PF_RF(rocfft_execution_info_create(&info));
+    PF_RF(rocfft_execution_info_set_stream(info, (void*)c->stream));
+    if (std::max(w1, w2)) {
+        PF_HIP(hipMalloc(&work, std::max(w1, w2)));
+        PF_RF(rocfft_execution_info_set_work_buffer(info, work, std::max(w1, w2)));
+    }
+    PF_HIP(hipMalloc((void**)&dp, dbytes));
+    PF_HIP(hipMalloc((void**)&dh, dbytes));
+    PF_HIP(hipMemcpy(dp, probe, dbytes, hipMemcpyHostToDevice));
+    PF_HIP(hipMemcpy(dh, hT, dbytes, hipMemcpyHostToDevice));
+    if (hdetT) {
+        PF_HIP(hipMalloc((void**)&dhd, dbytes));
+        PF_HIP(hipMemcpy(dhd, hdetT, dbytes, hipMemcpyHostToDevice));
+    }
+    if (c->pstack) { (void)hipFree(c->pstack); c->pstack = nullptr; }
+    if (c->pdet) { (void)hipFree(c->pdet); c->pdet = nullptr; }
+    if (c->pdetT) { (void)hipFree(c->pdetT); c->pdetT = nullptr; }
+    PF_HIP(hipMalloc((void**)&c->pstack, fld * (size_t)c->S));
+    PF_HIP(hipMalloc((void**)&c->pdet, fld));
+    PF_HIP(hipMalloc((void**)&c->pdetT, fld));
+    const int grid = g_elem_grid(c, n);
+    void* buf[1] = {dp};
+    auto step = [&](const double2* h) -> int {
+        if (rocfft_execute(pf, buf, nullptr, info) != rocfft_status_success) return fail(c, BDOF_ERR_STATE, "rocfft_execute (double) failed");
+        hipLaunchKernelGGL(k_d_mul, dim3(grid), dim3(256), 0, c->stream, dp, h, n, 1.0 / (double)n);
+        if (rocfft_execute(pi, buf, nullptr, info) != rocfft_status_success) return fail(c, BDOF_ERR_STATE, "rocfft_execute (double) failed");
+        return 0;
+    };
+    for (int z = 0; z < c->S; ++z) {
+        hipLaunchKernelGGL(k_d_to_f, dim3(grid), dim3(256), 0, c->stream, dp, c->pstack + (size_t)z * n, c->NX, c->NY, 0);
+        if (z < c->S - 1) PF_TRY(step(dh));
+    }
+    if (c->det_mode == BDOF_DET_FAR) {
+        if (rocfft_execute(pf, buf, nullptr, info) != rocfft_status_success) { cleanup(); return fail(c, BDOF_ERR_STATE, "rocfft_execute (double) failed"); }
+    } else {
+        if (c->variant == BDOF_VARIANT_TF_ALL) PF_TRY(step(dh));
+        if (c->det_mode == BDOF_DET_NEAR) PF_TRY(step(dhd));
+    }
+    hipLaunchKernelGGL(k_d_to_f, dim3(grid), dim3(256), 0, c->stream, dp, c->pdet, c->NX, c->NY, 0);
+    hipLaunchKernelGGL(k_d_to_f, dim3(grid), dim3(256), 0, c->stream, dp, c->pdetT, c->NX, c->NY, 1);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipStreamSynchronize(c->stream));
+#undef PF_TRY
+#undef PF_HIP
+#undef PF_RF
+    cleanup();
+    // the wave is carried as p_z + eps_z with eps_0 = 0: no probe of its own, no scalar carrier
+    HIPC(c, hipMemsetAsync(c->probe, 0, fld, c->stream));
+    c->a0 = 0.0;
+    c->res_dirty = true;
+    c->mod_dirty = true;
+    c->have_probe = true;
+    return 0;
+}
+
 int bdof_set_object(bdof_ctx* c, const void* vol, long long n_rows, int volNY, const int* tab, int volNX, int n_angles) {
     if (!c || !vol || n_rows < 1) return BDOF_ERR_ARG;
     if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
@@ -1171,6 +1263,8 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     if ((r = ensure_modulation(c))) return r;
+    c->gpsi_src = c->gpsi0;
+    c->gpsi_B = B;
     if (use_resident(c, B)) {
         if ((r = resident_run(c, B, meas, out_wave, true))) return r;
         c->tape_valid = c->last_valid = false;
@@ -1179,6 +1273,7 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     if (c->generic) {
         if ((r = generic_loss_grad(c, B, meas, out_wave))) return r;
         c->tape_valid = c->last_valid = false;
+        c->gpsi_src = c->bufA;                  // the adjoint sweep ends with G(psi_0) in the field buffer, [b][x][y]
         HIPC(c, hipGetLastError());
         return 0;
     }
@@ -1401,6 +1496,7 @@ int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xo
     if (!meas) return BDOF_ERR_ARG;
     if (c->meas_dev) return fail(c, BDOF_ERR_STATE, "bdof_set_meas_mode(1) applies to the transfer-function path only");
     if (!c->with_grad) return fail(c, BDOF_ERR_STATE, "bdof_loss_grad_conv needs bdof_configure(with_grad=1)");
+    c->gpsi_src = nullptr;                   // the real-space propagator does not export the probe gradient
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     if ((r = ensure_modulation_k(c, c->k_conv))) return r;
@@ -1448,6 +1544,34 @@ int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xo
         if ((r = launch_conv<true>(c, a))) return r;
         gcur = gout;
     }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_enable_probe_grad(bdof_ctx* c, int enable) {
+    if (!c) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    HIPC(c, hipSetDevice(c->device));
+    if (enable && !c->gpsi0) {
+        if (!c->with_grad) return fail(c, BDOF_ERR_STATE, "the probe gradient needs bdof_configure(with_grad=1)");
+        HIPC(c, hipMalloc((void**)&c->gpsi0, sizeof(cf) * (size_t)c->Bmax * c->NX * c->NY));
+    } else if (!enable && c->gpsi0) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->gpsi0);
+        c->gpsi0 = nullptr;
+    }
+    c->gpsi_src = nullptr;
+    return 0;
+}
+
+int bdof_probe_grad(bdof_ctx* c, void* out, int accumulate) {
+    if (!c || !out) return BDOF_ERR_ARG;
+    if (!c->gpsi0) return fail(c, BDOF_ERR_STATE, "bdof_enable_probe_grad(1) has not been called");
+    if (!c->gpsi_src) return fail(c, BDOF_ERR_STATE, "no gradient sweep since the probe gradient was enabled (bdof_loss_grad first)");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->NX * c->NY;
+    hipLaunchKernelGGL(k_sum_fields, dim3((unsigned)std::min<size_t>((n + 255) / 256, (size_t)c->ncu * 8)), dim3(256), 0, c->stream, c->gpsi_src,
+                       (cf*)out, c->gpsi_B, n, accumulate);
     HIPC(c, hipGetLastError());
     return 0;
 }

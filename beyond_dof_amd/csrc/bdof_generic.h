@@ -144,8 +144,28 @@ __global__ __launch_bounds__(256) void k_g_bwd(GBwdArgs a) {
             adj_carrier_load(a.ac, b, gam, t0);
             t = cadd(cadd(t, cmulc(gam, e)), t0);
             Gn = cadd(Gn, cmulc(gam, csub(m1, a.ac.cbm1)));
+            // the sweep ends at slice 0: leave the FULL G(psi_0) = scattered part + conj(cbar) gamma for bdof_probe_grad
+            if (a.z == 0) Gn = cadd(Gn, cmulc(gam, make_float2(1.f + a.ac.cbm1.x, a.ac.cbm1.y)));
         }
         a.grot[(((size_t)b * a.obj.S + a.z) * a.NX + x) * a.NY + y] = make_float2(a.k * t.y, -a.k * t.x);
         a.g[idx] = Gn;
+    }
+}
+
+
+// ---- float64 helpers of bdof_set_probe_field: the carrier field of a localised probe, propagated on the device ------------
+__global__ __launch_bounds__(256) void k_d_mul(double2* __restrict__ f, const double2* __restrict__ h, size_t n, double scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double2 a = f[i], b = h[i];
+        f[i] = make_double2((a.x * b.x - a.y * b.y) * scale, (a.x * b.y + a.y * b.x) * scale);
+    }
+}
+// dst[i] = (float2) src[i]; transposed: dst[j * n0 + i] = src[i * n1 + j] for an [n0][n1] source
+__global__ __launch_bounds__(256) void k_d_to_f(const double2* __restrict__ src, cf* __restrict__ dst, int n0, int n1, int transposed) {
+    const size_t n = (size_t)n0 * n1;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const double2 v = src[idx];
+        const size_t o = transposed ? (idx % n1) * (size_t)n0 + idx / n1 : idx;
+        dst[o] = make_float2((float)v.x, (float)v.y);
     }
 }

@@ -572,6 +572,8 @@ struct RowBwdArgs {
     cf cshift;         // a_z (cbar - 1)
     cf carrier_phi;    // cbar a_z: constant part of phi_z
     float tape_scale;  // HIST 3
+    cf* gpsi0;         // nullable: G(psi_z) in real space, [B][NX][NY] — at z = 0 the gradient w.r.t. the probe per wavefield
+                       // (probe_real / probe_imag of tensorflow_recon/fullfield.py:311-327 as optimisation variables)
 };
 
 // HIST = 0: phi_z (scattered part) is read from the tape A_z wrote.  HIST = 1: the tape holds the per-slice history
@@ -634,6 +636,12 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
                 gdst[tid + m * C::T] = make_float2(a.k * t.y, -a.k * t.x);
                 g[m] = cmulc(g[m], make_float2(1.f + db[m].x, db[m].y));    // conj(c) G,  c = 1 + (c - 1)
                 if constexpr (GC) g[m] = cadd(g[m], cmulc(gam, csub(db[m], a.ac.cbm1)));   // + conj(c - cbar) gamma (conj(cbar) gamma rides on)
+            }
+            if (a.gpsi0) {
+                cf* pd = a.gpsi0 + off;
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+                    pd[tid + m * C::T] = GC ? cadd(g[m], cmulc(gam, make_float2(1.f + a.ac.cbm1.x, a.ac.cbm1.y))) : g[m];
             }
             if (a.gout) line_fft_partial<NY, -1>(g, tw, tid, lds);
         }
@@ -901,6 +909,16 @@ __global__ __launch_bounds__(256) void k_tiles_scatter(TileArgs a) {
         cf* dst = a.field + (size_t)wrap_idx(ox + x, a.FX) * a.FY;
         const cf* src = a.tiles + ((size_t)b * a.TX + x) * a.TY;
         for (int y = a.hy + blockIdx.x * blockDim.x + threadIdx.x; y < a.TY - a.hy; y += gridDim.x * blockDim.x) dst[wrap_idx(oy + y, a.FY)] = src[y];
+    }
+}
+
+// out[i] (+)= sum over b of src[b][i]: the probe gradient of the minibatch from the per-wavefield G(psi_0)
+__global__ __launch_bounds__(256) void k_sum_fields(const cf* __restrict__ src, cf* __restrict__ out, int B, size_t n, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float sx = 0.f, sy = 0.f;
+        for (int b = 0; b < B; ++b) { const cf v = src[(size_t)b * n + i]; sx += v.x; sy += v.y; }
+        if (accumulate) { sx += out[i].x; sy += out[i].y; }
+        out[i] = make_float2(sx, sy);
     }
 }
 

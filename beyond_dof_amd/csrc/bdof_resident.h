@@ -291,6 +291,7 @@ struct ResArgs {
     float k, seed_scale;
     int meas_dev;          // `meas` holds m - |carrier_det| (loss_seed_dev, bdof_kernels.h)
     float dref;
+    cf* gpsi0;             // nullable [B][N][N]: G(psi_0), the probe gradient per wavefield
 };
 
 // transfer-function multiply folded into the last pass of the forward transform: the thread writing element (kx, ky)
@@ -620,6 +621,12 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                 }
             }
             if (tid < N) rowbuf[((z + 1) % 3) * N + tid] = r2;           // slot of slice z - 2
+        }
+        if (a.gpsi0) {                                                   // the image now holds G(psi_0)
+            for (int e = tid; e < N * N; e += T) {
+                const int x = e / N, y = e - x * N;
+                a.gpsi0[b * fsz + e] = f[x * P + y];
+            }
         }
     }
     if (a.meas) {

@@ -19,7 +19,6 @@ def _idx_buf(ctx, values):
 
 
 RESIDENT_SIZES = (32, 36, 48, 64, 72, 80, 96, 128)      # square fields with an LDS-resident plan (csrc/bdof_resident.h)
-_GAIN_CACHE = {}      # free-space energy calibration per (geometry, physics, probe): see MultisliceEngine._free_space_gain
 
 
 class MultisliceEngine(object):
@@ -48,7 +47,6 @@ class MultisliceEngine(object):
                                                | (16 if self.recompute else 0)))
         self._engine_arg = 'generic' if force_generic else engine
         self._device = device
-        self.calibrate_energy = True      # see set_probe
         self.det_mode = _lib.DET_NONE
         self._keep = {}          # device buffers that must outlive the calls that registered them
         self._tables = None
@@ -78,6 +76,7 @@ class MultisliceEngine(object):
         self.variant = variant
         self.k = k
         self._physics_args = (energy_ev, psize_cm, free_prop_cm, variant, pi)
+        self._field_shape = field_shape
         # tf_all + far field: the last transfer-function step only multiplies the far field by the
         # unit-modulus H (F P phi = H . F phi); libbdof skips it and the host applies it to returned waves
         self._far_phase = None
@@ -88,39 +87,6 @@ class MultisliceEngine(object):
                                                  det, _VARIANT[variant]))
         if getattr(self, '_probe_args', None) is not None:
             self.set_probe(*self._probe_args)      # the carrier (field, calibration) of the probe depends on the physics
-
-    def _free_space_gain(self, probe_c64):
-        """Amplitude factor that undoes the energy drift of THIS probe through THIS stack in free space.  |H| = 1, so in
-        exact arithmetic propagation through an empty object conserves energy; in float32 it does not — sqrt(1/2) and
-        sqrt(3)/2 have no exact float32 value, the transfer-function entries around DC are nearly one number and share its
-        rounding error — and the defect is systematic: the same sign at every step (-1.2e-7 per slice at 72^2 with any plain
-        float32 FFT, rocFFT included).  It is measured once on a scratch context (the probe through S empty
-        slices, same engine, same variant) and divided out of the probe: the model is linear in the probe, so this
-        rescales every wave by one constant within 1e-4 of 1 and changes nothing else."""
-        import hashlib
-        key = (self.ny, self.nx, self.n_slice, self._engine_arg, repr(self._physics_args),
-               hashlib.sha1(np.ascontiguousarray(probe_c64).tobytes()).hexdigest())
-        if key in _GAIN_CACHE:
-            return _GAIN_CACHE[key]
-        _GAIN_CACHE[key] = gain = self._measure_free_space_gain(probe_c64)
-        return gain
-
-    def _measure_free_space_gain(self, probe_c64):
-        scratch = MultisliceEngine(self.ny, self.nx, self.n_slice, 1, with_grad=False, device=self._device, engine=self._engine_arg)
-        scratch.calibrate_energy = False
-        energy_ev, psize_cm, free_prop_cm, variant, pi = self._physics_args
-        scratch.set_physics(energy_ev, psize_cm, None if isinstance(free_prop_cm, str) else free_prop_cm, variant=variant, pi=pi)
-        scratch.set_probe(probe_c64.real, probe_c64.imag)
-        # empty object: one row of zeros and a rotation table that maps every (slice, x) to it
-        vol = DeviceBuffer.zeros(scratch.ctx, (1, self.ny, 2), np.float32)
-        tab = DeviceBuffer.zeros(scratch.ctx, (1, self.n_slice, self.nx), np.int32)
-        scratch.set_volume(vol, 1, self.ny, tab, self.nx, 1)
-        out = scratch.forward(1, angle_idx=[0])[0].astype(np.complex128)
-        e_in = float(np.sum(np.abs(probe_c64.astype(np.complex128)) ** 2))
-        e_out = float(np.sum(np.abs(out) ** 2))
-        if not (e_in > 0 and np.isfinite(e_out) and abs(e_out / e_in - 1) < 1e-3):
-            return 1.0                                             # nothing sensible to correct (empty probe, ...)
-        return float(np.sqrt(e_in / e_out))
 
     def _probe_stack(self, probe_c64):
         """The probe propagated through free space to the entrance of every slice and to the detector, in float64 on the
@@ -146,40 +112,68 @@ class MultisliceEngine(object):
             det = p
         return np.ascontiguousarray(stack), np.ascontiguousarray(det.T.astype(np.complex64))
 
+    def _probe_field_device(self, probe_c64):
+        """The same carrier field computed by the library on the device in float64 (bdof_set_probe_field): the host only forms
+        the two transfer functions (float64, transposed to [kx][ky])."""
+        energy_ev, psize_cm, free_prop_cm, variant, pi = self._physics_args
+        voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
+        lmbda_nm = 1240. / energy_ev
+        fs = getattr(self, '_field_shape', None)
+        kern = (lambda d: util.get_kernel_tile(d, lmbda_nm, voxel_nm, (self.ny, self.nx), fs, pi=pi)) if fs is not None else \
+            (lambda d: util.get_kernel(d, lmbda_nm, voxel_nm, (self.ny, self.nx), pi=pi))
+        hT = np.ascontiguousarray(np.fft.ifftshift(kern(voxel_nm[-1])).T.astype(np.complex128))
+        hdT = None
+        if self.det_mode == _lib.DET_NEAR:
+            hdT = np.ascontiguousarray(np.fft.ifftshift(kern(free_prop_cm * 1e7)).T.astype(np.complex128))
+        p = np.ascontiguousarray(probe_c64.T.astype(np.complex128))
+        self.ctx.check(self.lib.bdof_set_probe_field(self.h, p.ctypes.data, hT.ctypes.data, hdT.ctypes.data if hdT is not None else None))
+
     def set_probe(self, probe_real, probe_imag):
         self._probe_args = (np.array(probe_real, copy=True), np.array(probe_imag, copy=True))
         probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.ny, self.nx))
         probe = probe.astype(np.complex64)                         # the reference rounds to complex64 too (np_funcs.py:20)
         # Carrier splitting: the wave is held as carrier + eps and only eps runs through the float32 transforms.
         #  - a (nearly) uniform probe rides on its mean a0, propagated exactly as a scalar inside the library;
-        #  - a localised probe on the LDS-resident engine rides on its own free-space propagation, a carrier FIELD per slice
-        #    computed here in float64 (bdof_set_probe_stack): eps is the scattered wave alone;
-        #  - otherwise a0 = 0, and the systematic energy drift of the float32 chain is measured and divided out.
+        #  - a localised probe rides on its own free-space propagation, a carrier FIELD per slice, which the library computes
+        #    on the device in float64 (bdof_set_probe_field): eps is the scattered wave alone;
+        #  - otherwise (BDOF_NO_PROBE_STACK, the real-space propagator) a0 = 0 and the whole wave is float32.
         mean = complex(probe.astype(np.complex128).mean())
         a0 = mean if np.abs(probe - mean).max() <= 0.25 * abs(mean) else 0j
-        gain = 1.0
         self.probe_stack = False
         use_stack = (a0 == 0 and hasattr(self, '_physics_args') and not os.environ.get('BDOF_NO_PROBE_STACK')
                      and not getattr(self, '_conv_set', False)              # the real-space propagator has its own carrier
-                     and self.n_slice * self.nx * self.ny <= (1 << 28)      # 2 GiB of stack at most
+                     and self.n_slice * self.nx * self.ny <= (1 << 32)      # 32 GiB of stack at most
                      and self.lib.bdof_probe_stack_supported(self.h) == 1)
         if use_stack:
-            stack, det = self._probe_stack(probe)
-            zero = np.zeros((self.nx, self.ny), dtype=np.complex64)
-            self.ctx.check(self.lib.bdof_set_probe(self.h, zero.ctypes.data, 0.0, 0.0))
-            self.ctx.check(self.lib.bdof_set_probe_stack(self.h, stack.ctypes.data, det.ctypes.data))
+            if os.environ.get('BDOF_HOST_PROBE_STACK'):                     # cross-check: the float64 propagation on the host
+                stack, det = self._probe_stack(probe)
+                zero = np.zeros((self.nx, self.ny), dtype=np.complex64)
+                self.ctx.check(self.lib.bdof_set_probe(self.h, zero.ctypes.data, 0.0, 0.0))
+                self.ctx.check(self.lib.bdof_set_probe_stack(self.h, stack.ctypes.data, det.ctypes.data))
+            else:
+                self._probe_field_device(probe)
             self.probe_stack, self.probe_gain = True, 1.0
             self._set_meas_mode(0j)
             return
         if self.lib.bdof_probe_stack_supported(self.h) == 1:
             self.ctx.check(self.lib.bdof_set_probe_stack(self.h, None, None))
-        if a0 == 0 and self.calibrate_energy and self.n_slice > 1 and hasattr(self, '_physics_args') \
-                and not os.environ.get('BDOF_NO_ENERGY_CALIBRATION'):
-            gain = self._free_space_gain(probe)
-        self.probe_gain = gain
-        eps = np.ascontiguousarray(((probe.astype(np.complex128) - a0) * gain).T.astype(np.complex64))
+        self.probe_gain = 1.0
+        eps = np.ascontiguousarray((probe.astype(np.complex128) - a0).T.astype(np.complex64))
         self.ctx.check(self.lib.bdof_set_probe(self.h, eps.ctypes.data, a0.real, a0.imag))
         self._set_meas_mode(a0)
+
+    # ---- gradient w.r.t. the probe (probe_type='optimizable', tensorflow_recon/fullfield.py:311-327) -------------------
+    def enable_probe_grad(self, on=True):
+        self.ctx.check(self.lib.bdof_enable_probe_grad(self.h, int(bool(on))))
+        self._gprobe = DeviceBuffer.zeros(self.ctx, (self.nx, self.ny), np.complex64) if on else None
+
+    def probe_grad(self, accumulate=False, to_host=True):
+        """dL/d(probe_real) + i dL/d(probe_imag) of the last loss_grad, summed over its wavefields: (Y, X) complex."""
+        self.ctx.check(self.lib.bdof_probe_grad(self.h, self._gprobe.ptr, int(bool(accumulate))))
+        if not to_host:
+            return self._gprobe
+        self.ctx.sync()
+        return np.ascontiguousarray(self._gprobe.download().T)
 
     def set_probe_none(self):
         """No probe of the ctx's own: every wavefield starts from a caller-supplied field (bdof_forward_range), no carrier."""

@@ -166,6 +166,8 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
         solver.set_mask(mask)
         solver.set_measurements(np.abs(prj))
         solver.tune_tail()                       # N ranks: slab count of the exchange + Adam pipeline, by measurement; step() uses it
+        if probe_type == 'optimizable':          # the probe is a variable too (tensorflow_recon/fullfield.py:311-327,442-455)
+            solver.enable_probe_optimization(probe_real, probe_imag, probe_learning_rate, pupil_function)
 
         print_flush('Optimizer started.', 0, rank)
         if rank == 0:
@@ -214,6 +216,10 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
         if rank == 0:
             tiffio.write_tiff(obj_delta, os.path.join(output_folder, 'delta_ds_{}'.format(ds_level)), dtype='float32', overwrite=True)
             tiffio.write_tiff(obj_beta, os.path.join(output_folder, 'beta_ds_{}'.format(ds_level)), dtype='float32', overwrite=True)
+            if probe_type == 'optimizable':      # tensorflow_recon/fullfield.py:604-607 writes probe_mag / probe_phase
+                pr_f, pi_f = solver.get_probe()
+                tiffio.write_tiff(np.sqrt(pr_f ** 2 + pi_f ** 2), os.path.join(output_folder, 'probe_mag_ds_{}'.format(ds_level)), dtype='float32', overwrite=True)
+                tiffio.write_tiff(np.arctan2(pi_f, pr_f), os.path.join(output_folder, 'probe_phase_ds_{}'.format(ds_level)), dtype='float32', overwrite=True)
         obj_delta, obj_beta = obj_delta.astype(float), obj_beta.astype(float)
         first_level = False
         del solver

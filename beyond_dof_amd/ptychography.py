@@ -133,6 +133,8 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
                               coord_ls=coord_ls, propagator=propagator, kernel_size=kwargs.get('kernel_size', 17))
         solver.set_volume(obj_delta, obj_beta)
         solver.tune_tail()
+        if probe_type == 'optimizable':          # tensorflow_recon/ptychography.py: the probe is a variable with its own Adam
+            solver.enable_probe_optimization(probe_real, probe_imag, probe_learning_rate, pupil_function)
         print_flush('Optimizer started.', 0, rank)
         if rank == 0:
             create_summary(output_folder, locals(), preset='ptycho')

@@ -42,6 +42,7 @@ class _VolumeSolver(object):
         self._plan = None
         self.tuned = None
         self._acc = 0              # minibatches accumulated in self.g since the last update (n_batch_per_update)
+        self.probe = None          # enable_probe_optimization
         self.comm.attach(self.ctx)
 
     def _bind_volume(self):
@@ -208,6 +209,53 @@ class _VolumeSolver(object):
         n = self.mb * self.dim_z * self.eng.nx * self.eng.ny * 8
         self.ctx.check(lib.bdof_memset(h, lib.bdof_grot(h), 0, n))
 
+    # ---- optimisable probe (probe_type='optimizable', tensorflow_recon/fullfield.py:311-327,442-455) ---------------------
+    def enable_probe_optimization(self, probe_real, probe_imag, probe_learning_rate=1e-3, pupil_function=None):
+        """probe_real / probe_imag become optimisation variables with their own Adam (learning rate probe_learning_rate; its
+        step counter runs over the whole level, as a tf.train.AdamOptimizer's does).  Every step() then also takes the
+        gradient w.r.t. the probe (bdof_probe_grad: G(psi_0) summed over the minibatch), averages it over the ranks,
+        updates the probe on the host in float64 — it is one (Y, X) field — multiplies by the pupil function
+        (tensorflow_recon/fullfield.py:546-548) and hands it back to the engine, which re-derives its carrier (scalar, or
+        the carrier field propagated on the device in float64)."""
+        self.probe = (np.asarray(probe_real, dtype=np.float64) + 1j * np.asarray(probe_imag, dtype=np.float64)) * np.ones((self.eng.ny, self.eng.nx))
+        self.probe_lr = float(probe_learning_rate)
+        self.pupil = None if pupil_function is None else np.asarray(pupil_function, dtype=np.float64)
+        self.probe_m = np.zeros_like(self.probe)
+        self.probe_v = np.zeros_like(self.probe)
+        self.probe_t = 0
+        self._pacc = 0
+        self.eng.enable_probe_grad(True)
+        self.eng.set_probe(self.probe.real, self.probe.imag)
+
+    def _probe_collect(self):
+        """Add this minibatch's probe gradient to the device accumulator (call after every loss_grad)."""
+        if getattr(self, 'probe', None) is None:
+            return
+        self.eng.probe_grad(accumulate=self._pacc > 0, to_host=False)
+        self._pacc += 1
+
+    def _probe_apply(self, b1=0.9, b2=0.999, eps=1e-8):
+        """Adam on (probe_real, probe_imag) with the accumulated gradient (mean over accumulated minibatches and ranks)."""
+        if getattr(self, 'probe', None) is None or self._pacc == 0:
+            return
+        self.ctx.sync()
+        g = np.ascontiguousarray(self.eng._gprobe.download().T).astype(np.complex128) / self._pacc
+        self._pacc = 0
+        if self.comm.size > 1:
+            g = self.comm.allreduce_sum_host(g) / self.comm.size
+        self.probe_t += 1
+        self.probe_m = b1 * self.probe_m + (1 - b1) * g
+        self.probe_v = b2 * self.probe_v + (1 - b2) * (g.real ** 2 + 1j * g.imag ** 2)
+        mh = self.probe_m / (1 - b1 ** self.probe_t)
+        vh = self.probe_v / (1 - b2 ** self.probe_t)
+        self.probe = self.probe - self.probe_lr * (mh.real / (np.sqrt(vh.real) + eps) + 1j * mh.imag / (np.sqrt(vh.imag) + eps))
+        if self.pupil is not None:
+            self.probe = self.probe * self.pupil
+        self.eng.set_probe(self.probe.real, self.probe.imag)
+
+    def get_probe(self):
+        return self.probe.real.copy(), self.probe.imag.copy()
+
     def shrink_wrap(self, thresh=1e-15):
         """mask = mask * (obj_delta > 1e-15)   (cnn_propagator/fullfield.py:365-368, intended behaviour, quirk Q8)."""
         if self.mask is not None:
@@ -300,6 +348,7 @@ class FullfieldSolver(_VolumeSolver):
         minibatches is accumulated and applied (averaged) every n-th minibatch or at the last one of the epoch; the Adam
         bias-correction exponent then counts updates, not minibatches."""
         self._rot_loss_grad(angle_idx)
+        self._probe_collect()
         nb = max(1, int(n_batch_per_update))
         if nb > 1:
             self._produce(accumulate=self._acc > 0)(0, self.dim_x)
@@ -308,9 +357,11 @@ class FullfieldSolver(_VolumeSolver):
                 n_acc, self._acc = self._acc, 0
                 self._tail(lambda x0, nx: None, i_batch // nb, learning_rate, alpha_d, alpha_b, gamma, clip, use_mask, n_slabs,
                            sharded, n_acc=n_acc)
+                self._probe_apply()
         else:
             self._tail(self._produce(), i_batch, learning_rate, alpha_d, alpha_b, gamma, clip, use_mask, n_slabs, sharded)
-        return self._get_loss() if want_loss else None
+            self._probe_apply()
+        return self._get_loss() if want_loss else None          # the loss of THIS minibatch stays on the device until the next one
 
     def forward_angles(self, angle_idx):
         """Detector waves (len(idx), Y, X) of the current volume — the forward_pass of fullfield.py:79-91."""
@@ -395,8 +446,10 @@ class PtychoSolver(_VolumeSolver):
         """One Adam iteration of ptychography.py:301-310: loss_grad, Allreduce, /size, Adam, clip (no regulariser, no mask).
         The window/rotation adjoint produces the whole volume gradient in one pass; exchange and Adam are still slab-wise."""
         self._win_loss_grad(i_theta, pos_idx, prj_abs_batch)
+        self._probe_collect()
         self._produce_all()
         self._tail(lambda x0, nx: None, i_batch, learning_rate, clip=clip, use_mask=False, n_slabs=n_slabs, sharded=sharded)
+        self._probe_apply()
         return self._get_loss() if want_loss else None
 
     def forward(self, i_theta, pos_idx):

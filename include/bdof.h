@@ -77,6 +77,12 @@ int bdof_set_probe(bdof_ctx* ctx, const float* probe_eps, double a0_re, double a
 int bdof_probe_stack_supported(bdof_ctx* ctx);
 int bdof_set_probe_stack(bdof_ctx* ctx, const float* stack, const float* det);
 
+/* The same carrier field computed by the library, on the device, in float64: probe HOST [NX][NY] complex128; hT / hdetT HOST
+ * [kx][ky] complex128 = ifftshift(get_kernel(...)) transposed, NOT divided by NX*NY (hdetT: the detector distance, NULL unless
+ * det_mode == BDOF_DET_NEAR).  Replaces bdof_set_probe + bdof_set_probe_stack for a localised probe: no host FFTs, so a probe
+ * that changes every step (probe_type='optimizable', tensorflow_recon/fullfield.py:311-327) stays cheap. */
+int bdof_set_probe_field(bdof_ctx* ctx, const double* probe, const double* hT, const double* hdetT);
+
 /* Object.  vol: n_rows device rows of volNY (delta, beta) pairs.  Call again whenever that memory has been modified: the
  * library keeps a table of the modulation factors exp(i k delta - k beta) - 1 of these rows and rebuilds it lazily.
  *  tab == NULL: row(b,z,x) = (b*S+z)*NX+x, i.e. the caller
@@ -126,6 +132,12 @@ int bdof_tape_to_real(bdof_ctx* ctx, int i, int B, void* out);
  * windowed (delta,beta) is left in the ctx (bdof_grot). out_wave may be NULL. */
 int bdof_loss_grad(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, void* out_wave);
 int bdof_get_loss(bdof_ctx* ctx, double* loss);
+/* Gradient w.r.t. the probe: with bdof_enable_probe_grad(1) every bdof_loss_grad also keeps G(psi_0) = dL/dRe psi_0 + i dL/dIm psi_0
+ * of each wavefield; bdof_probe_grad sums it over the batch into out (device [NX][NY] complex, accumulate != 0: added to it).
+ * The probe is shared by the wavefields of a minibatch, so this is the gradient of the loss w.r.t. (probe_real, probe_imag) —
+ * the trainable probe of tensorflow_recon/fullfield.py:311-327,442-455 (probe_type='optimizable'). */
+int bdof_enable_probe_grad(bdof_ctx* ctx, int enable);
+int bdof_probe_grad(bdof_ctx* ctx, void* out, int accumulate);
 /* mode 1: the `meas` arrays of bdof_loss_grad hold |measured| - |a0| instead of |measured| (a0: the plane-wave part handed
  * to bdof_set_probe; every transfer-function step has unit modulus at DC, so |a0| is the carrier's modulus at the detector
  * too).  The residual is then formed as (|a + e| - |a|) - (m - |a|) with |a + e| - |a| evaluated without cancellation —

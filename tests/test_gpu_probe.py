@@ -1,0 +1,138 @@
+"""Optimisable probe (probe_type='optimizable', tensorflow_recon/fullfield.py:311-327,442-455): the gradient w.r.t. the probe
+from every engine against the oracle (pinned by torch autograd, tests/test_oracle_adjoint.py), the carrier field propagated on
+the device in float64 against the host propagation, and a few Adam steps on the probe."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bdof_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+CASES = [((64, 128, 12), 'streaming', 'plane'), ((64, 128, 12), 'streaming', 'gauss'), ((64, 64, 10), 'generic', 'gauss'),
+         ((72, 72, 10), 'auto', 'gauss'), ((64, 64, 10), 'resident', 'gauss'), ((60, 100, 6), 'auto', 'plane')]
+
+
+@pytest.mark.parametrize('shape,engine,probe', CASES)
+@pytest.mark.parametrize('fp', [None, 1e-4, 'inf'])
+def test_probe_gradient_vs_oracle(shape, engine, probe, fp):
+    import __graft_entry__ as entry
+    entry.build()
+    from beyond_dof_amd import util
+    from beyond_dof_amd.engine import MultisliceEngine
+    Y, X, S = shape
+    B = 3
+    rng = np.random.default_rng(Y + S)
+    delta = rng.uniform(0, 2e-5, size=(B, Y, X, S))
+    beta = 0.1 * delta
+    if probe == 'plane':
+        pr, pi = 1 + 0.05 * rng.normal(size=(Y, X)), 0.05 * rng.normal(size=(Y, X))      # nearly uniform: scalar carrier
+    else:
+        pr, pi = util.gaussian_probe((Y, X), Y / 6., Y / 6., 0.5)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, fp, delta.shape, return_probe_array=False)
+    meas = (np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))).astype(np.float32)
+    eng = MultisliceEngine(Y, X, S, B, with_grad=True, engine=engine)
+    eng.set_physics(5000., 1e-7, fp)
+    eng.set_probe(pr, pi)
+    eng.enable_probe_grad(True)
+    eng.set_object_batch(delta, beta)
+    loss = eng.loss_grad(B, meas)
+    gp = eng.probe_grad()
+    rl, rgd, rgb, g0 = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas.astype(np.float64), fp, return_probe_grad=True)
+    assert abs(loss - rl) <= 2e-5 * abs(rl)
+    want = g0.sum(axis=0)
+    assert rel(gp, want) <= 2e-4, rel(gp, want)
+    gp2 = eng.probe_grad(accumulate=True)                       # accumulation over minibatches (n_batch_per_update)
+    assert rel(gp2, 2 * want) <= 2e-4
+
+
+def test_device_probe_field_equals_host_propagation():
+    """bdof_set_probe_field (float64 on the device, rocFFT double plans) against the host's numpy propagation of the same probe
+    (BDOF_HOST_PROBE_STACK=1): the per-slice history through an empty object IS the carrier field."""
+    code = ('import sys, numpy as np; sys.path.insert(0, {0!r})\n'
+            'from beyond_dof_amd import util\n'
+            'from beyond_dof_amd.engine import MultisliceEngine\n'
+            'out = []\n'
+            'for fp, variant in ((None, "numpy_skip_last"), (1e-4, "tf_all"), ("inf", "numpy_skip_last")):\n'
+            '    eng = MultisliceEngine(64, 128, 9, 1, with_grad=True, engine="streaming")\n'
+            '    eng.set_physics(5000., 1e-7, fp, variant=variant)\n'
+            '    pr, pi = util.gaussian_probe((64, 128), 9., 9., 0.5)\n'
+            '    eng.set_probe(pr, pi)\n'
+            '    eng.set_object_batch(np.zeros((1, 64, 128, 9)), np.zeros((1, 64, 128, 9)))\n'
+            '    out.append(eng.forward(1, keep_tape=(variant == "numpy_skip_last")))\n'
+            '    if variant == "numpy_skip_last": out.append(eng.probe_array(1))\n'
+            'np.savez(sys.argv[1], *out)\n').format(ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        res = []
+        for host in ('', '1'):
+            f = os.path.join(d, 'o{}.npz'.format(host))
+            env = dict(os.environ)
+            env.pop('BDOF_HOST_PROBE_STACK', None)
+            if host:
+                env['BDOF_HOST_PROBE_STACK'] = '1'
+            r = subprocess.run([sys.executable, '-c', code, f], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+            assert r.returncode == 0, r.stdout.decode()[-2000:]
+            res.append(np.load(f))
+    for k in res[0].files:
+        assert rel(res[0][k], res[1][k]) <= 2e-7, (k, rel(res[0][k], res[1][k]))
+
+
+def test_probe_optimization_steps_follow_the_oracle():
+    """Three steps of FullfieldSolver with an optimisable probe (object AND probe updated) against the same loop on the
+    oracle: object by cnn_propagator/util.py:280-291, probe by a standard Adam on (probe_real, probe_imag)."""
+    from beyond_dof_amd.solver import FullfieldSolver
+    rng = np.random.default_rng(2)
+    n, n_theta, mb, fp = 64, 6, 2, 1e-4
+    od = rng.uniform(0, 2e-6, size=(n, n, n))
+    ob = 0.1 * od
+    coords = orc.rotation_lookup([n, n, n], n_theta)
+    idx = np.array([1, 4])
+    pr0 = 1 + 0.02 * rng.normal(size=(n, n))
+    pi0 = 0.02 * rng.normal(size=(n, n))
+    rot = np.stack([orc.apply_rotation(np.stack([od, ob], axis=3), coords[j]) for j in idx])
+    true_pr, true_pi = np.ones((n, n)), np.zeros((n, n))
+    ref, _ = orc.multislice_propagate_batch_numpy(rot[..., 0], rot[..., 1], true_pr, true_pi, 5000., 1e-7, fp, rot[..., 0].shape,
+                                                  return_probe_array=False)
+    prj = np.zeros((n_theta, n, n))
+    prj[idx] = np.abs(ref).astype(np.float32)
+    s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=fp, coord_ls=coords, probe_real=pr0, probe_imag=pi0)
+    s.set_volume(od, ob)
+    s.set_measurements(prj)
+    plr = 1e-3
+    s.enable_probe_optimization(pr0, pi0, plr)
+    x = np.array([od, ob])
+    m = v = None
+    p = (pr0 + 1j * pi0).astype(np.complex128)
+    pm, pv = np.zeros_like(p), np.zeros_like(p)
+    losses = []
+    for it in range(3):
+        losses.append(s.step(it, idx, 1e-7, want_loss=True))
+        rot = np.stack([orc.apply_rotation(np.stack([x[0], x[1]], axis=3), coords[j]) for j in idx])
+        rl, gd, gb, g0 = orc.multislice_loss_and_grad(rot[..., 0], rot[..., 1], p.real, p.imag, 5000., 1e-7, prj[idx], fp, return_probe_grad=True)
+        assert abs(losses[-1] - rl) <= 1e-4 * abs(rl), (it, losses[-1], rl)
+        g = np.array([sum(orc.apply_rotation_adjoint(np.stack([gd[b], gb[b]], axis=3), coords[j])[..., c] for b, j in enumerate(idx))
+                      for c in range(2)])
+        x, m, v = orc.apply_gradient_adam(x, g, it, m, v, step_size=1e-7)
+        x = np.clip(x, 0, None)
+        gp = g0.sum(axis=0)
+        t = it + 1
+        pm = 0.9 * pm + 0.1 * gp
+        pv = 0.999 * pv + 0.001 * (gp.real ** 2 + 1j * gp.imag ** 2)
+        mh, vh = pm / (1 - 0.9 ** t), pv / (1 - 0.999 ** t)
+        p = p - plr * (mh.real / (np.sqrt(vh.real) + 1e-8) + 1j * mh.imag / (np.sqrt(vh.imag) + 1e-8))
+    got_r, got_i = s.get_probe()
+    step = np.abs((got_r + 1j * got_i) - (pr0 + 1j * pi0))
+    assert step.max() > 0.5 * plr                                  # the probe really moved
+    assert np.mean(np.abs((got_r + 1j * got_i) - p) > 0.05 * plr) < 5e-3      # and took the oracle's (sign-like) Adam steps
+    assert losses[-1] < losses[0]

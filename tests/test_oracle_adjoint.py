@@ -51,7 +51,7 @@ def test_gradient_finite_difference(fp, variant):
 def test_gradient_vs_torch_autograd(fp):
     delta, beta, pr, pi, meas = _setup(seed=3)
     B, Y, X, S = delta.shape
-    loss, gd, gb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, fp)
+    loss, gd, gb, g0 = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, fp, return_probe_grad=True)
     voxel = np.array([1e-7] * 3) * 1e7
     lmbda = 1240. / 5000.
     h = torch.from_numpy(np.fft.ifftshift(orc.get_kernel(voxel[-1], lmbda, voxel, (Y, X, S))))
@@ -59,7 +59,10 @@ def test_gradient_vs_torch_autograd(fp):
     td = torch.tensor(delta, requires_grad=True)
     tb = torch.tensor(beta, requires_grad=True)
     # the reference rounds the probe to complex64 (np_funcs.py:20-21)
-    psi = torch.tensor((pr + 1j * pi).astype(np.complex64).astype(np.complex128)).expand(B, Y, X)
+    p64 = (pr + 1j * pi).astype(np.complex64).astype(np.complex128)
+    tpr = torch.tensor(p64.real, requires_grad=True)          # the probe as a variable too (tensorflow_recon/fullfield.py:322-323)
+    tpi = torch.tensor(p64.imag, requires_grad=True)
+    psi = torch.complex(tpr, tpi).expand(B, Y, X)
     for i in range(S):
         psi = psi * torch.exp(1j * k * td[..., i]) * torch.exp(-k * tb[..., i])
         if i < S - 1:
@@ -74,6 +77,10 @@ def test_gradient_vs_torch_autograd(fp):
     assert abs(tl.item() - loss) < 1e-13 * max(1.0, abs(loss))
     np.testing.assert_allclose(gd, td.grad.numpy(), rtol=0, atol=1e-12 * np.abs(gd).max())
     np.testing.assert_allclose(gb, tb.grad.numpy(), rtol=0, atol=1e-12 * np.abs(gb).max())
+    # G(psi_0) summed over the batch = dL/d(probe_real) + i dL/d(probe_imag)
+    gp = g0.sum(axis=0)
+    np.testing.assert_allclose(gp.real, tpr.grad.numpy(), rtol=0, atol=1e-12 * np.abs(gp).max())
+    np.testing.assert_allclose(gp.imag, tpi.grad.numpy(), rtol=0, atol=1e-12 * np.abs(gp).max())
 
 
 def test_rotation_adjoint_dot_product():
