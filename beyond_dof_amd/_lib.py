@@ -55,6 +55,7 @@ _SIGNATURES = {
                        + [ctypes.c_float] * 8 + [ctypes.c_int, ctypes.c_int]),
     'bdof_adam_step_slab': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
                             + [ctypes.c_float] * 8 + [ctypes.c_int] * 4),
+    'bdof_regularizer_value': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     'bdof_mask_shrink': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_float]),
     'bdof_gather_fields': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_size_t]),
     'bdof_set_streams': (ctypes.c_int, [_vp, ctypes.c_int]),

@@ -1687,6 +1687,23 @@ int bdof_adam_step(bdof_ctx* c, const void* x_old, void* x_new, const void* g, v
                                i_batch, clip, 0, NXv);
 }
 
+int bdof_regularizer_value(bdof_ctx* c, const void* x, int NXv, int NZv, int NYv, double* sums) {
+    if (!c || !x || !sums) return BDOF_ERR_ARG;
+    if (NXv < 1 || NZv < 1 || NYv < 1) return fail(c, BDOF_ERR_ARG, "bad volume shape");
+    if (!c->partial) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t n = (size_t)NXv * NZv * NYv;
+    const int grid = (int)std::min<size_t>((n + 255) / 256, (size_t)(2 * c->npartial / 3));
+    hipLaunchKernelGGL(k_reg_value, dim3(grid), dim3(256), 0, c->stream, (const float2*)x, NXv, NZv, NYv, c->partial);
+    HIPC(c, hipGetLastError());
+    std::vector<double> p(3 * (size_t)grid);
+    HIPC(c, hipMemcpyAsync(p.data(), c->partial, sizeof(double) * p.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    sums[0] = sums[1] = sums[2] = 0.0;
+    for (int b = 0; b < grid; ++b) for (int j = 0; j < 3; ++j) sums[j] += p[3 * (size_t)b + j];
+    return 0;
+}
+
 void* bdof_stream(bdof_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int bdof_mask_shrink(bdof_ctx* c, const void* x, float* mask, size_t n, float thresh) {

@@ -933,6 +933,34 @@ __global__ __launch_bounds__(256) void k_gather_fields(float4* __restrict__ dst,
     }
 }
 
+// Value of the regulariser  alpha_d sum|delta| + alpha_b sum|beta| + gamma TV(delta)  (cnn_propagator/fullfield.py:109-118,
+// total_variation_3d util.py:61-70: periodic, anisotropic, sum over the three axes of |roll(x, 1) - x|).  Per-workgroup float64
+// partials [3 * gridDim.x]: sum|delta|, sum|beta|, TV.
+__global__ __launch_bounds__(256) void k_reg_value(const float2* __restrict__ x, int NXv, int NZv, int NYv, double* __restrict__ partial) {
+    const size_t n = (size_t)NXv * NZv * NYv;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = idx % NYv;
+        const size_t r = idx / NYv;
+        const int z = r % NZv;
+        const int xx = r / NZv;
+        const float2 v = x[idx];
+        s0 += fabsf(v.x);
+        s1 += fabsf(v.y);
+        const size_t sz = NYv, sx = (size_t)NZv * NYv;
+        const float ym = x[idx - y + (y + NYv - 1) % NYv].x;
+        const float zm = x[idx - z * sz + ((z + NZv - 1) % NZv) * sz].x;
+        const float xm = x[idx - xx * sx + ((xx + NXv - 1) % NXv) * sx].x;
+        s2 += (double)fabsf(ym - v.x) + (double)fabsf(zm - v.x) + (double)fabsf(xm - v.x);
+    }
+    __shared__ double w[3][4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_down(s0, off, 64); s1 += __shfl_down(s1, off, 64); s2 += __shfl_down(s2, off, 64); }
+    if ((threadIdx.x & 63) == 0) { w[0][threadIdx.x >> 6] = s0; w[1][threadIdx.x >> 6] = s1; w[2][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 3) partial[3 * blockIdx.x + threadIdx.x] = w[threadIdx.x][0] + w[threadIdx.x][1] + w[threadIdx.x][2] + w[threadIdx.x][3];
+}
+
 // shrink-wrap of the finite-support mask: mask *= (delta > thresh)      cnn_propagator/fullfield.py:365-368
 __global__ __launch_bounds__(256) void k_mask_shrink(const float2* x, float* mask, size_t n, float thresh) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)

@@ -328,8 +328,13 @@ template <int N, int T, class Epi> __device__ __forceinline__ void res_epi_prefe
 }
 
 // F^-1 (h .) F   (CONJ: the adjoint step, conj(h)); `epi` rides on the last pass of the inverse transform
-template <int N, int T, bool CONJ, class Epi>
-__device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid, Epi& epi) {
+struct MidNone { __device__ __forceinline__ void operator()() {} };
+
+// `mid` runs before the LAST line set of the step (the inverse transform along y): where the non-fused plans issue the global
+// loads of the next slice.  Issued before the whole step their 4 * EPT registers were live across all eight passes — on top
+// of a radix-9 butterfly that is 80 spilled VGPRs for 72^2 — while two passes (~4 us) already cover the HBM latency.
+template <int N, int T, bool CONJ, class Epi, class Mid>
+__device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid, Epi& epi, Mid&& mid) {
     EpiH<N, T, CONJ> eh;
     eh.hT = hT;
     if constexpr (ResWave<N>::L > 0) {
@@ -341,17 +346,30 @@ __device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int 
         res_wlines<N, -1, false>(f, tw, tid, eh);
         res_wlines<N, +1, false>(f, tw, tid, none);
         res_sync();
-        res_wlines<N, +1, true>(f, tw, tid, none);
+        {   // the last line set, its two passes written out so that `mid` sits before the lighter (radix R1) one
+            typedef ResPlan<N> Pl;
+            constexpr int L = ResWave<N>::L, LPW = ResWave<N>::LPW;
+            res_wpass<N, Pl::R0, 1, +1, true, L, LPW>(f, tw, tid, none);
+            mid();
+            res_wpass<N, Pl::R1, Pl::R0, +1, true, L, LPW>(f, tw, tid, none);
+        }
         res_sync();
     } else {
         res_fft2<N, T, -1>(f, tw, tid, eh);
         res_epi_prefetch<N, T>(tid, epi);
-        res_fft2<N, T, +1>(f, tw, tid, epi);
+        EpiNone none;
+        res_lines<N, T, +1, true>(f, tw, tid, none);
+        mid();
+        res_lines<N, T, +1, false>(f, tw, tid, epi);
     }
+}
+template <int N, int T, bool CONJ, class Epi>
+__device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid, Epi& epi) {
+    res_prop<N, T, CONJ>(f, hT, tw, tid, epi, MidNone());
 }
 template <int N, int T, bool CONJ> __device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid) {
     EpiNone none;
-    res_prop<N, T, CONJ>(f, hT, tw, tid, none);
+    res_prop<N, T, CONJ>(f, hT, tw, tid, none, MidNone());
 }
 
 // Global loads of a slice are issued one propagation step ahead of their use (software pipeline): the modulation factors
@@ -541,13 +559,18 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                 if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;      // read two propagation steps from now
             }
         } else {
+            EpiNone none;
             for (int z = 0; z < a.S; ++z) {
                 const long long r2 = Pipe::row_of(a, b, z + 2, tid);
                 Point::modulate(f, tape0 ? tape0 + (size_t)z * a.tape_stride : nullptr, a.carrier[z], a.carrier[a.S + z],
                                 a.pstack ? a.pstack + (size_t)z * fsz : nullptr, m, tid);
-                if (z + 1 < a.S) Pipe::load_factors(a, rowbuf + ((z + 1) % 3) * N, y0, tid, m);      // in flight during the step
                 if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;
-                if (z + 1 < a.S || (a.tf_all && !far)) res_prop<N, T, false>(f, a.hsT, tw, tid);
+                if (z + 1 < a.S) {
+                    // the next slice's factors: in flight during the last two passes of the step
+                    res_prop<N, T, false>(f, a.hsT, tw, tid, none, [&]() { Pipe::load_factors(a, rowbuf + ((z + 1) % 3) * N, y0, tid, m); });
+                } else if (a.tf_all && !far) {
+                    res_prop<N, T, false>(f, a.hsT, tw, tid);
+                }
             }
         }
         if (a.det_mode == BDOF_DET_NEAR) res_prop<N, T, false>(f, a.hdetT, tw, tid);
@@ -613,12 +636,19 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     Point::adjoint(f, t, m, cadd(a.carrier[z], a.carrier[a.S + z]), a.pstack ? a.pstack + (size_t)z * fsz : nullptr, a.k, gdst, tid);
                 }
             } else {
-                if (prop_after) res_prop<N, T, true>(f, a.hsT, tw, tid);
-                Point::adjoint(f, t, m, cadd(a.carrier[z], a.carrier[a.S + z]), a.pstack ? a.pstack + (size_t)z * fsz : nullptr, a.k, gdst, tid);
-                if (z > 0) {                                           // in flight during the next adjoint step
-                    Pipe::load_factors(a, rowbuf + ((z - 1) % 3) * N, y0, tid, m);
-                    Pipe::load_field(tape0 + (size_t)(z - 1) * a.tape_stride, tid, t);
+                if (prop_after) {
+                    EpiNone none;
+                    if (z < a.S - 1) {
+                        // this slice's factors and tape: in flight during the last two passes of the adjoint step
+                        res_prop<N, T, true>(f, a.hsT, tw, tid, none, [&]() {
+                            Pipe::load_factors(a, rowbuf + (z % 3) * N, y0, tid, m);
+                            Pipe::load_field(tape, tid, t);
+                        });
+                    } else {
+                        res_prop<N, T, true>(f, a.hsT, tw, tid);       // slice S - 1 was loaded before the detector step
+                    }
                 }
+                Point::adjoint(f, t, m, cadd(a.carrier[z], a.carrier[a.S + z]), a.pstack ? a.pstack + (size_t)z * fsz : nullptr, a.k, gdst, tid);
             }
             if (tid < N) rowbuf[((z + 1) % 3) * N + tid] = r2;           // slot of slice z - 2
         }

@@ -201,8 +201,9 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
             if size > 1:
                 this_loss = float(comm.allreduce_sum_host(np.array([this_loss]))[0]) / size
             i_epoch += 1
-            print_flush('Epoch {} (rank {}); loss (data term) = {}; Delta-t = {} s; current time = {}.'.format(
-                i_epoch, rank, this_loss, time.time() - t0, time.time() - t_zero), 0, rank)
+            reg_loss = solver.regularizer(reg_d, reg_b, gamma)       # the reference's epoch line is calculate_loss: data + regulariser
+            print_flush('Epoch {} (rank {}); loss = {} (data term {}); Delta-t = {} s; current time = {}.'.format(
+                i_epoch, rank, this_loss + reg_loss, this_loss, time.time() - t0, time.time() - t_zero), 0, rank)
             if this_n_epochs == 'auto':
                 if last_loss is not None and last_loss > 0 and (last_loss - this_loss) / last_loss < crit_conv_rate:
                     cont = False

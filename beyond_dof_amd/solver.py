@@ -83,6 +83,12 @@ class _VolumeSolver(object):
         self.ctx.sync()
         return util.rows_to_volume(self.g.download())
 
+    def regularizer(self, alpha_d=0.0, alpha_b=0.0, gamma=0.0):
+        """alpha_d sum|delta| + alpha_b sum|beta| + gamma TV(delta) of the current volume (fullfield.py:109-118), on the device."""
+        sums = (ctypes.c_double * 3)()
+        self.ctx.check(self.ctx.lib.bdof_regularizer_value(self.ctx.handle, self.x[self.cur].ptr, self.dim_x, self.dim_z, self.dim_y, sums))
+        return alpha_d * sums[0] + alpha_b * sums[1] + gamma * sums[2]
+
     # ---- the tail of the step ----------------------------------------------------------------
     def _reduces(self):
         return self.comm.size > 1 or getattr(self.comm, 'always_reduce', False)

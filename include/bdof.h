@@ -187,6 +187,11 @@ int bdof_adam_step_slab(bdof_ctx* ctx, const void* x_old, void* x_new, const voi
  * this_prj_batch = prj[this_ind_batch] (cnn_propagator/fullfield.py:344) on the device-resident stack of amplitudes. */
 int bdof_gather_fields(bdof_ctx* ctx, void* dst, const void* src, const int* idx, int B, size_t bytes_per_field);
 
+/* Value of the regulariser terms of the loss (cnn_propagator/fullfield.py:109-118; total_variation_3d, util.py:61-70) on a
+ * volume [NXv][NZv][NYv] of pairs: sums[0] = sum|delta|, sums[1] = sum|beta|, sums[2] = TV(delta) (periodic, anisotropic).
+ * The caller weights them (alpha_d, alpha_b, gamma).  Synchronous (three numbers come back). */
+int bdof_regularizer_value(bdof_ctx* ctx, const void* x, int NXv, int NZv, int NYv, double* sums);
+
 /* Shrink-wrap (cnn_propagator/fullfield.py:365-368): mask[i] *= (delta[i] > thresh) over n voxels. */
 int bdof_mask_shrink(bdof_ctx* ctx, const void* x, float* mask, size_t n, float thresh);
 

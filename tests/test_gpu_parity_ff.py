@@ -112,3 +112,15 @@ def test_reconstructed_delta_after_three_adam_steps(fp, n_theta, mb, bound_d, bo
     assert rel(d, x[0]) <= bound_d, rel(d, x[0])
     assert np.abs(d - x[0]).max() <= bound_step * lr
     assert rel(b, x[1]) <= 1e-3, rel(b, x[1])
+
+
+def test_regularizer_value_on_device():
+    """alpha_d sum|delta| + alpha_b sum|beta| + gamma TV(delta) (cnn_propagator/fullfield.py:109-118) against the oracle's
+    restatement (pinned by golden vector G5)."""
+    n = 64
+    od, ob, coords, idx, prj, _, one, zero, rng = _case(n, 4, 2, 1e-4)
+    s = _solver(n, 4, 2, 1e-4, coords, od, ob, prj)
+    d32, b32 = od.astype(np.float32).astype(np.float64), ob.astype(np.float32).astype(np.float64)
+    want = orc.regularizer(d32, b32, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)
+    got = s.regularizer(1.5e-8, 1.5e-9, 1e-11)
+    assert abs(got - want) <= 1e-6 * abs(want), (got, want)
