@@ -1,0 +1,45 @@
+"""Worker of tests/test_gpu_dist.py: one rank of a two-rank ptychography step (probe positions sharded over the ranks,
+cnn_propagator/ptychography.py:292-306) sharing ONE GPU; gloo carries the collective."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def problem():
+    from beyond_dof_amd import util
+    rng = np.random.default_rng(4)
+    n, n_theta, psz = 64, 4, (32, 32)
+    pos = np.array([(y, x) for y in (12, 30, 50) for x in (10, 28, 44, 58)])
+    init_d = np.clip(rng.normal(8.7e-7, 1e-7, size=(n, n, n)), 0, None)
+    meas = np.abs(rng.normal(1.0, 0.1, size=(n_theta, len(pos)) + psz)) * 20
+    pr, pi = util.gaussian_probe(psz, 5., 5., 0.5)
+    return n, n_theta, psz, pos, init_d, meas, pr, pi
+
+
+def main(out_dir, sharded):
+    from beyond_dof_amd.comm import get_comm
+    from beyond_dof_amd.solver import PtychoSolver
+    from beyond_dof_amd import util
+    comm = get_comm()
+    n, n_theta, psz, pos, init_d, meas, pr, pi = problem()
+    mb = len(pos) // comm.size
+    s = PtychoSolver((n, n, n), psz, pos, n_theta, mb, 5000., 1e-7, pr, pi, comm=comm, device=0,
+                     coord_ls=util.rotation_lookup([n, n, n], n_theta))
+    s.set_volume(init_d, 0.1 * init_d)
+    s.bcast_volume(0)
+    s.reset_moments()
+    for i, i_theta in enumerate((1, 3)):
+        mine = np.arange(comm.rank * mb, (comm.rank + 1) * mb)
+        s.step(i, i_theta, mine, meas[i_theta, mine], 1e-7, n_slabs=4, sharded=sharded)
+    d, b = s.get_volume()
+    np.savez(os.path.join(out_dir, 'pty{}_{}.npz'.format(comm.rank, int(sharded))), d=d, b=b)
+    comm.Barrier()
+    comm.close()
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], bool(int(sys.argv[2])))

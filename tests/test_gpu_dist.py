@@ -83,6 +83,41 @@ def test_two_ranks_on_one_gpu_match_the_union_minibatch(tmp_path):
     assert rel(r0['d'], d) <= 2e-3
 
 
+def test_two_rank_ptychography_matches_the_union_minibatch(tmp_path):
+    """Probe positions sharded over two ranks (cnn_propagator/ptychography.py:292-306): window/rotation adjoint, exchange and
+    Adam through PtychoSolver.step in both forms of the exchange, against one rank holding all positions."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import _dist_ptycho_worker as w
+    vols = {}
+    for sharded in (False, True):
+        port = _free_port()
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank),
+                       BDOF_COMM_BACKEND='gloo')
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_dist_ptycho_worker.py'), str(tmp_path), str(int(sharded))],
+                                          env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), '\n'.join(o[-3000:] for o in outs)
+        r0, r1 = [np.load(str(tmp_path / 'pty{}_{}.npz'.format(r, int(sharded)))) for r in range(2)]
+        assert np.array_equal(r0['d'], r1['d']) and np.array_equal(r0['b'], r1['b'])
+        vols[sharded] = r0
+    assert np.array_equal(vols[False]['d'], vols[True]['d']) and np.array_equal(vols[False]['b'], vols[True]['b'])
+    from beyond_dof_amd import util
+    from beyond_dof_amd.solver import PtychoSolver
+    n, n_theta, psz, pos, init_d, meas, pr, pi = w.problem()
+    s = PtychoSolver((n, n, n), psz, pos, n_theta, len(pos), 5000., 1e-7, pr, pi, coord_ls=util.rotation_lookup([n, n, n], n_theta))
+    s.set_volume(init_d, 0.1 * init_d)
+    s.reset_moments()
+    for i, i_theta in enumerate((1, 3)):
+        s.step(i, i_theta, np.arange(len(pos)), meas[i_theta], 1e-7)
+    d, b = s.get_volume()
+    lr = 1e-7
+    # the union loss is the mean over 12 patterns, each rank's over its 6, summed and divided by size: the same gradient
+    assert np.mean(np.abs(d - vols[True]['d']) > 0.05 * lr) < 2e-3
+    assert np.linalg.norm(d - vols[True]['d']) <= 2e-3 * np.linalg.norm(d)
+
+
 def test_bench_py_two_rank_rehearsal(tmp_path):
     """Plain `python bench.py --gpus 2`: the parent starts the two ranks itself (no launcher, no RANK / WORLD_SIZE in its
     environment), sharded schedule, tuned exchange, max-over-ranks timing, exactly one JSON line from rank 0.  The two

@@ -89,6 +89,46 @@ def test_reconstruct_fullfield_end_to_end(tmp_path, monkeypatch):
     assert os.path.exists(os.path.join('case', 'out2', 'intermediate', 'current.tiff'))
 
 
+def test_reconstruct_fullfield_optimizable_probe_and_accumulation(tmp_path, monkeypatch):
+    """probe_type='optimizable' with probe_learning_rate and pupil_function, and n_batch_per_update accumulation
+    (tensorflow_recon/fullfield.py:311-327,413-425,442-455) through the entry point: files out, probe moved, loss down."""
+    import __graft_entry__ as entry
+    entry.build()
+    from beyond_dof_amd import h5io, tiffio
+    from beyond_dof_amd.fullfield import reconstruct_fullfield
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(3)
+    n, n_theta, mb, fp = 64, 8, 2, 1e-4
+    true_d, true_b = _phantom(n, rng)
+    coords = orc.rotation_lookup([n, n, n], n_theta)
+    one, zero = np.ones((n, n)), np.zeros((n, n))
+    rot = np.stack([orc.apply_rotation(np.stack([true_d, true_b], axis=3), c) for c in coords])
+    prj, _ = orc.multislice_propagate_batch_numpy(rot[..., 0], rot[..., 1], one, zero, 5000., 1e-7, fp, rot[..., 0].shape,
+                                                  return_probe_array=False)
+    os.makedirs('case')
+    h5io.write_dataset('case/data.h5', 'exchange/data', prj.astype(np.complex64))
+    init_d = np.clip(rng.normal(8.7e-7, 1e-7, size=(n, n, n)), 0, None)
+    init_b = np.clip(rng.normal(5.1e-8, 1e-8, size=(n, n, n)), 0, None)
+    mag0 = 1 + 0.05 * rng.normal(size=(n, n))
+    pupil = np.ones((n, n))
+    pupil[:2] = 0
+    common = dict(theta_st=0, theta_end=2 * np.pi, learning_rate=1e-7, minibatch_size=mb, energy_ev=5000, psize_cm=1e-7, free_prop_cm=fp,
+                  save_path='case', initial_guess=[init_d, init_b], shrink_cycle=None, seed=7, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)
+    d, b = reconstruct_fullfield('data.h5', n_epochs=2, output_folder='out_p', probe_type='optimizable', probe_initial=[mag0, np.zeros((n, n))],
+                                 probe_learning_rate=2e-3, pupil_function=pupil, **common)
+    mag = tiffio.read_tiff(os.path.join('case', 'out_p', 'probe_mag_ds_1.tiff'))
+    assert mag.shape == (n, n) and np.all(mag[:2] == 0)                       # pupil enforced
+    assert np.abs(mag[2:] - mag0[2:]).max() > 1e-3                            # the probe moved ...
+    assert np.abs(mag[2:] - 1).mean() < np.abs(mag0[2:] - 1).mean()           # ... towards the true (unit) probe
+    assert os.path.exists(os.path.join('case', 'out_p', 'probe_phase_ds_1.tiff'))
+    # accumulation: 4 minibatches per epoch, applied every 2 -> the same as minibatches of twice the size (mean of means)
+    d1, b1 = reconstruct_fullfield('data.h5', n_epochs=1, output_folder='out_a', n_batch_per_update=2, accumulate_gradients=True,
+                                   random_theta=False, **common)
+    common2 = dict(common, minibatch_size=2 * mb)
+    d2, b2 = reconstruct_fullfield('data.h5', n_epochs=1, output_folder='out_b', random_theta=False, **common2)
+    assert np.mean(np.abs(d1 - d2) > 0.05 * 1e-7) < 2e-3 and np.linalg.norm(d1 - d2) <= 1e-3 * np.linalg.norm(d2)
+
+
 class _LoopbackComm(object):
     """One rank that still runs the exchange branch of the solver's tail (slab loop, sharded Adam, all-gather calls) with
     collectives that are the identity — what they are on a single rank."""
