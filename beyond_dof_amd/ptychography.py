@@ -3,9 +3,10 @@ GPU.  Same keyword surface (unknown keywords ignored), `exchange/data` HDF5 of s
 lazily per minibatch, same outputs.
 
 Differences: by default the FFT propagator instead of the truncated real-space convolution
-(propagator='conv' selects the latter for power-of-two probes); probe sizes that are powers of two (64 ... 1024) run on
-the fused kernels, any other size (the reference drivers' 72 x 72) on the rocFFT engine; Q9 dynamic dropping is a no-op in the reference and is not run; the intermediate TIFF
-is behind save_intermediate; n_epochs='auto' stops at max_nepochs.
+(propagator='conv' selects the latter for power-of-two probes); small square probes (32 ... 128 pixels, the reference
+drivers' 72 x 72 among them) run on the LDS-resident kernel, powers of two from 64 to 1024 on the fused streaming kernels, any
+other size on the rocFFT engine; probe_type='optimizable' optimises the probe as the TF twin does; Q9 dynamic dropping is a
+no-op in the reference and is not run; the intermediate TIFF is behind save_intermediate; n_epochs='auto' stops at max_nepochs.
 """
 import os
 import time

@@ -178,9 +178,10 @@ def test_cfg5_full_size_properties(engine_mod):
     exit_wave = eng.forward(B)
     energy = np.sum(np.abs(exit_wave.astype(np.complex128)) ** 2, axis=(1, 2))
     # plain float32 transform chains drift in energy systematically (rocFFT: -1.25e-7 per slice at 72^2, 3.3e-5 after 255
-    # steps, tools/gpu_check_energy.py); here the irrational butterfly constants alternate their rounding direction and
-    # set_probe() divides the measured free-space drift of the probe out (engine.py: _free_space_gain): what is left with
-    # an object in the beam is a few 1e-7 on average over the 400 wavefields, below 4e-6 for each of them at full depth.
+    # steps, tools/gpu_check_energy.py); here the irrational butterfly constants are hi + lo pairs and the probe's own
+    # free-space propagation is carried as a float64-computed field (bdof_set_probe_field), so only the scattered wave runs
+    # through float32: what is left with an object in the beam is a few 1e-7 on average over the 400 wavefields, below
+    # 4e-6 for each of them at full depth.
     drift = energy / e0 - 1
     assert np.max(np.abs(drift)) <= 4e-6 and abs(np.mean(drift)) <= 1.5e-6
     far = _engine(engine_mod, n, B, S, 'inf', 'numpy_skip_last', delta, beta, pr, pi, 'resident')
