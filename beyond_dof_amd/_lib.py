@@ -7,7 +7,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libbdof.so')
+LIB_PATH = os.environ.get('BDOF_LIB') or os.path.join(_HERE, 'libbdof.so')      # BDOF_LIB: a differently built copy (kernel experiments)
 
 DET_NONE, DET_NEAR, DET_FAR = 0, 1, 2
 VARIANT_NUMPY_SKIP_LAST, VARIANT_TF_ALL = 0, 1

@@ -18,6 +18,8 @@
 template <int N> struct RowCfg {
     static constexpr int T = N / 8;                          // lanes per row
     static constexpr int RPP = BDOF_THREADS / T;             // rows per pass
+    // 16 rows: the transposed stores are then 128-byte segments.  8-row tiles (64-byte segments, 39 KB of LDS, three
+    // workgroups per CU at 80 VGPRs) were measured in round 2: A 35 -> 55 us, B 26 -> 33 us, A' 50 -> 103 us per launch.
     static constexpr int TILE = RPP > 16 ? RPP : 16;         // rows per tile = transposed segment length
     static constexpr int PASSES = TILE / RPP;
     static constexpr int NPAD = N + N / 16;
