@@ -39,6 +39,11 @@ _SIGNATURES = {
     'bdof_forward_range': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     'bdof_tiles_gather': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     'bdof_tiles_scatter': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int]),
+    'bdof_adjoint_range': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    'bdof_tiles_scatter_adjoint': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int]),
+    'bdof_tiles_gather_adjoint': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
+    'bdof_tiles_grad_add': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int]),
+    'bdof_field_loss_seed': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     'bdof_tape_to_real': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     'bdof_loss_grad': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     'bdof_set_conv': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_double] * 5),

@@ -373,12 +373,20 @@ static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf*
 
 // A'_z: L1 (g) + phi tape -> L2 (g)
 // hist: 0 = `tape` is the phi tape of slice z; 1 = `tape` is psi_hat_z of the history tape; 2 = slice 0 of the history mode
-static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout, int hist = 0, float tape_scale = 1.f) {
+struct GradTarget {            // where A'_z leaves the gradient rows / G(psi_z): the ctx's own buffers unless a range sweep says otherwise
+    float2* grot = nullptr;    // [B][S_][NX][NY]
+    int S_ = 0, z_ = 0;
+    cf* gpsi = nullptr;        // real-space G(psi_z), [B][NX][NY]
+};
+static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout, int hist = 0, float tape_scale = 1.f,
+                           const GradTarget* gt = nullptr) {
     ProfScope ps(c, BDOF_K_ROW_BWD);
+    float2* grot = gt && gt->grot ? gt->grot + (size_t)c->sub_b0 * gt->S_ * c->NX * c->NY : c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY;
     RowBwdArgs a{sub_field(c, gin), hist == 2 ? c->probe : sub_field(c, tape), sub_field(c, gout),
-                 c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
+                 grot, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
                  slice_carrier_field(c, z), adj_carrier_at(c, c->S - 1 - z), cshift_at(c, z), carrier_phi_at(c, z), tape_scale,
-                 z == 0 && c->gpsi0 ? c->gpsi0 + (size_t)c->sub_b0 * c->NX * c->NY : nullptr};
+                 gt && gt->gpsi ? sub_field(c, gt->gpsi) : (z == 0 && c->gpsi0 ? c->gpsi0 + (size_t)c->sub_b0 * c->NX * c->NY : nullptr),
+                 gt && gt->grot ? gt->S_ : c->S, gt && gt->grot ? gt->z_ : z};
     const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
@@ -876,7 +884,9 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
         const bool small_tape = c->recompute && !(c->resident && ((with_grad & 8) != 0 || std::getenv("BDOF_FORCE_RESIDENT")));
         c->recompute = small_tape;
         HIPC(c, hipMalloc((void**)&c->tape, sizeof(cf) * fld * (size_t)(small_tape ? std::min(S, 3) : S)));
-        HIPC(c, hipMalloc((void**)&c->grot, sizeof(float2) * fld * (size_t)S));
+        // flag 32: the caller sweeps slice ranges into gradient buffers of its own (bdof_adjoint_range, the tiled path), where
+        // [Bmax][S] rows would not fit — 260 GB for 121 tiles of 512^2 x 1024 slices
+        if ((with_grad & 32) == 0) HIPC(c, hipMalloc((void**)&c->grot, sizeof(float2) * fld * (size_t)S));
         HIPC(c, hipMalloc((void**)&c->gcar, sizeof(double2) * (size_t)Bmax));
         HIPC(c, hipMalloc((void**)&c->gt0, sizeof(double2) * (size_t)Bmax));
     }
@@ -1202,6 +1212,78 @@ int bdof_forward_range(bdof_ctx* c, int B, const int* angle_of_b, const int* xof
     return 0;
 }
 
+// Adjoint of bdof_forward_range(prop_last = 1) in the tape-free form: the forward wave is marched back from the range's end
+// state beside the adjoint field.  end_real: psi_{z0+nz} (what bdof_forward_range returned), g_end_real: G(psi_{z0+nz});
+// g_start_real receives G(psi_{z0}); the gradient rows of the range go to grot_range [B][nz][NX][NY] (pairs).
+int bdof_adjoint_range(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
+                       const void* end_real, const void* g_end_real, void* g_start_real, void* grot_range) {
+    int r = check_ready(c, B);
+    if (r) return r;
+    if (!end_real || !g_end_real || !g_start_real || !grot_range) return BDOF_ERR_ARG;
+    if (z0 < 0 || nz < 1 || z0 + nz > c->S) return fail(c, BDOF_ERR_ARG, "slice range outside [0, S)");
+    if (c->generic) return fail(c, BDOF_ERR_SIZE, "bdof_adjoint_range runs on the fused streaming kernels");
+    if (!c->with_grad || !c->tape) return fail(c, BDOF_ERR_STATE, "bdof_adjoint_range needs bdof_configure(with_grad=1)");
+    if (c->S < 2) return fail(c, BDOF_ERR_SIZE, "bdof_adjoint_range needs at least two tape fields (S >= 2)");
+    if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
+    HIPC(c, hipSetDevice(c->device));
+    set_batch_views(c, angle_of_b, xoff, yoff);
+    if ((r = ensure_modulation(c))) return r;
+    const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
+    cf* const rc1 = c->tape;                       // marched-back phi_hat_z (L1)
+    cf* const rc2 = c->tape + fld;                 // R eps(psi_z) (L2)
+    Group groups[BDOF_MAX_GROUPS];
+    const int ng = batch_groups(c, B, c->NX, 16, groups);
+    if ((r = fork_streams(c, ng))) return r;
+    const int zt = z0 + nz - 1;
+    for (int gi = 0; gi < ng; ++gi) {
+        const int Bg = groups[gi].B;
+        use_group(c, groups[gi]);
+        // phi_{zt} = P^H psi_{zt+1} and G(phi_{zt}) = P^H G(psi_{zt+1}): real space -> R (transposed) -> adjoint step
+        RealToHybArgs ra{sub_field(c, (const cf*)end_real), sub_field(c, c->bufA), Bg, c->NX, c->twY};
+        DISPATCH_N(c->NY, { hipLaunchKernelGGL((k_row_real_to_hyb<N_>), dim3(rows_grid<N_>(c, Bg, c->NX)), dim3(BDOF_THREADS), 0, c->sub_stream, ra); });
+        launch_row_prop(c, Bg, c->bufA, rc1, c->hs, 1.f, 1);
+        RealToHybArgs rg{sub_field(c, (const cf*)g_end_real), sub_field(c, c->bufA), Bg, c->NX, c->twY};
+        DISPATCH_N(c->NY, { hipLaunchKernelGGL((k_row_real_to_hyb<N_>), dim3(rows_grid<N_>(c, Bg, c->NX)), dim3(BDOF_THREADS), 0, c->sub_stream, rg); });
+        launch_row_prop(c, Bg, c->bufA, c->bufB, c->hs, 1.f, 1);
+    }
+    for (int z = zt; z >= z0; --z) {
+        for (int gi = 0; gi < ng; ++gi) {
+            const int Bg = groups[gi].B;
+            use_group(c, groups[gi]);
+            GradTarget gt;
+            gt.grot = (float2*)grot_range; gt.S_ = nz; gt.z_ = z - z0;
+            gt.gpsi = z == z0 ? (cf*)g_start_real : nullptr;
+            launch_row_bwd(c, Bg, z, c->bufB, rc1, z > z0 ? c->bufA : nullptr, 3, 1.f, &gt);
+            if (z > z0) {
+                launch_row_prop(c, Bg, c->bufA, c->bufB, c->hs, 1.f, 1);
+                launch_row_unmod(c, Bg, z, rc1, rc2, false, 1.f);
+                launch_row_prop(c, Bg, rc2, rc1, c->hs, 1.f, 1);
+            }
+        }
+    }
+    if ((r = join_streams(c, ng))) return r;
+    c->tape_valid = c->last_valid = false;
+    c->gpsi_src = nullptr;
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// loss = mean((|field| - meas)^2) over n = FX * FY pixels (left on the device, bdof_get_loss) and, in place of the field,
+// the adjoint seed 2 (|d| - m) d / |d| / n — the detector-less (free_prop_cm None) loss of a whole field
+int bdof_field_loss_seed(bdof_ctx* c, void* field, const float* meas, int FX, int FY) {
+    if (!c || !field || !meas || FX < 1 || FY < 1) return BDOF_ERR_ARG;
+    if (!c->partial) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t n = (size_t)FX * FY;
+    const int egrid = g_elem_grid(c, n);
+    GLossArgs la{(cf*)field, nullptr, meas, c->partial, 1, FX, FY, 0, make_float2(0.f, 0.f), (float)(2.0 / (double)n), nullptr, 0, 0.f,
+                 nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+    hipLaunchKernelGGL(k_g_loss, dim3(egrid), dim3(256), 0, c->stream, la);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, egrid, 1.0 / (double)n, c->loss_dev);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
 static int tiles_check(bdof_ctx* c, const void* field, const void* tiles, int B, int FX, int FY, int TX, int TY, const int* x0, const int* y0) {
     if (!c || !field || !tiles || !x0 || !y0) return BDOF_ERR_ARG;
     if (B < 1 || FX < 1 || FY < 1 || TX < 1 || TY < 1) return fail(c, BDOF_ERR_ARG, "bad tile / field shape");
@@ -1215,7 +1297,7 @@ int bdof_tiles_gather(bdof_ctx* c, const void* field, int FX, int FY, void* tile
     HIPC(c, hipSetDevice(c->device));
     if (taper < 0 || 2 * taper > TX || 2 * taper > TY) return fail(c, BDOF_ERR_ARG, "taper must fit the tile");
     TileArgs a{(cf*)field, (cf*)tiles, x0, y0, B, FX, FY, TX, TY, 0, 0, taper};
-    hipLaunchKernelGGL(k_tiles_gather, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_tiles_gather, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a, 0);
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -1228,6 +1310,44 @@ int bdof_tiles_scatter(bdof_ctx* c, const void* tiles, void* field, int FX, int 
     HIPC(c, hipSetDevice(c->device));
     TileArgs a{(cf*)field, (cf*)tiles, x0, y0, B, FX, FY, TX, TY, halo_x, halo_y, 0};
     hipLaunchKernelGGL(k_tiles_scatter, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// adjoint of bdof_tiles_scatter: tiles = the field on every tile's core, zero elsewhere
+int bdof_tiles_scatter_adjoint(bdof_ctx* c, const void* field, int FX, int FY, void* tiles, int B, int TX, int TY, const int* x0, const int* y0,
+                               int halo_x, int halo_y) {
+    int r = tiles_check(c, field, tiles, B, FX, FY, TX, TY, x0, y0);
+    if (r) return r;
+    if (halo_x < 0 || halo_y < 0 || 2 * halo_x >= TX || 2 * halo_y >= TY) return fail(c, BDOF_ERR_ARG, "halo must leave a core");
+    HIPC(c, hipSetDevice(c->device));
+    TileArgs a{(cf*)field, (cf*)tiles, x0, y0, B, FX, FY, TX, TY, halo_x, halo_y, 0};
+    hipLaunchKernelGGL(k_tiles_gather, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a, 1);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// adjoint of bdof_tiles_gather: field = sum of the tiles' pixels, weighted with the taper, at the positions they were cut from
+int bdof_tiles_gather_adjoint(bdof_ctx* c, const void* tiles, void* field, int FX, int FY, int B, int TX, int TY, const int* x0, const int* y0,
+                              int taper) {
+    int r = tiles_check(c, field, tiles, B, FX, FY, TX, TY, x0, y0);
+    if (r) return r;
+    if (taper < 0 || 2 * taper > TX || 2 * taper > TY) return fail(c, BDOF_ERR_ARG, "taper must fit the tile");
+    HIPC(c, hipSetDevice(c->device));
+    TileArgs a{(cf*)field, (cf*)tiles, x0, y0, B, FX, FY, TX, TY, 0, 0, taper};
+    hipLaunchKernelGGL(k_tiles_gather_adjoint, dim3(std::min(FX, c->ncu * 8)), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// object gradient of a slice range of tiles, added into the volume gradient rows (see k_tiles_grad_add)
+int bdof_tiles_grad_add(bdof_ctx* c, const void* grot_range, void* gvol, int B, int TX, int TY, const int* x0, const int* y0, int z0, int nz) {
+    if (!c || !grot_range || !gvol || !x0 || !y0 || B < 1) return BDOF_ERR_ARG;
+    if (!c->obj.tab) return fail(c, BDOF_ERR_STATE, "bdof_set_object with a table has not been called");
+    if (z0 < 0 || nz < 1 || z0 + nz > c->S) return fail(c, BDOF_ERR_ARG, "slice range outside [0, S)");
+    HIPC(c, hipSetDevice(c->device));
+    TileGradArgs a{(const float2*)grot_range, (float2*)gvol, c->obj.tab, x0, y0, B, TX, TY, c->obj.volNX, c->obj.volNY, z0, nz, 1};
+    hipLaunchKernelGGL(k_tiles_grad_add, dim3(std::min(c->obj.volNX, c->ncu * 8)), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;
 }
@@ -1258,7 +1378,7 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     if (!meas) return BDOF_ERR_ARG;
     if (c->meas_dev && (c->det_mode == BDOF_DET_FAR || c->pstack))
         return fail(c, BDOF_ERR_STATE, "bdof_set_meas_mode(1) needs a real-space detector and a scalar carrier");
-    if (!c->with_grad) return fail(c, BDOF_ERR_STATE, "bdof_loss_grad needs bdof_configure(with_grad=1)");
+    if (!c->with_grad || !c->grot) return fail(c, BDOF_ERR_STATE, "bdof_loss_grad needs bdof_configure(with_grad=1) with the gradient workspace (not flag 32)");
     if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);

@@ -576,6 +576,8 @@ struct RowBwdArgs {
     float tape_scale;  // HIST 3
     cf* gpsi0;         // nullable: G(psi_z) in real space, [B][NX][NY] — at z = 0 the gradient w.r.t. the probe per wavefield
                        // (probe_real / probe_imag of tensorflow_recon/fullfield.py:311-327 as optimisation variables)
+    int grot_S, grot_z;  // gradient rows go to grot[b][grot_z][x][y] of a [B][grot_S][NX][NY] buffer (= obj.S, z unless the
+                         // sweep covers a slice range with a buffer of its own, bdof_adjoint_range)
 };
 
 // HIST = 0: phi_z (scattered part) is read from the tape A_z wrote.  HIST = 1: the tape holds the per-slice history
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
                 for (int m = 0; m < 8; ++m) p[m] = PF ? modulate_eps(p[m], pc[m], db[m]) : modulate_eps_s(p[m], a.carrier, db[m], a.cshift);
             }
             line_fft<NY, +1>(g, tw, tid, lds);
-            float2* gdst = a.grot + (((size_t)b * a.obj.S + a.z) * a.NX + x) * NY;
+            float2* gdst = a.grot + (((size_t)b * a.grot_S + a.grot_z) * a.NX + x) * NY;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const cf phi = cadd(p[m], PF ? pc[m] : a.carrier_phi);
@@ -893,24 +895,157 @@ __device__ __forceinline__ float taper_weight(int i, int n, int taper) {
 }
 __device__ __forceinline__ int wrap_idx(int i, int n) { i %= n; return i < 0 ? i + n : i; }
 
-__global__ __launch_bounds__(256) void k_tiles_gather(TileArgs a) {
+// mode 0: tile = field (periodic) x taper window.  mode 1: tile = field on the tile's CORE, zero on the halo and beyond the
+// field's edge — the adjoint of k_tiles_scatter (which writes cores, without wrapping).
+__global__ __launch_bounds__(256) void k_tiles_gather(TileArgs a, int mode) {
     const int b = blockIdx.z;
     const int ox = a.x0[b], oy = a.y0[b];
     for (int x = blockIdx.y; x < a.TX; x += gridDim.y) {
-        const cf* src = a.field + (size_t)wrap_idx(ox + x, a.FX) * a.FY;
         cf* dst = a.tiles + ((size_t)b * a.TX + x) * a.TY;
+        if (mode == 1) {
+            const int xg = ox + x;
+            const bool xin = x >= a.hx && x < a.TX - a.hx && xg >= 0 && xg < a.FX;
+            const cf* src = a.field + (size_t)(xin ? xg : 0) * a.FY;
+            for (int y = blockIdx.x * blockDim.x + threadIdx.x; y < a.TY; y += gridDim.x * blockDim.x) {
+                const int yg = oy + y;
+                const bool in = xin && y >= a.hy && y < a.TY - a.hy && yg >= 0 && yg < a.FY;
+                dst[y] = in ? src[yg] : make_float2(0.f, 0.f);
+            }
+            continue;
+        }
+        const cf* src = a.field + (size_t)wrap_idx(ox + x, a.FX) * a.FY;
         const float wx = taper_weight(x, a.TX, a.taper);
         for (int y = blockIdx.x * blockDim.x + threadIdx.x; y < a.TY; y += gridDim.x * blockDim.x)
             dst[y] = cscale(src[wrap_idx(oy + y, a.FY)], wx * taper_weight(y, a.TY, a.taper));
     }
 }
+// cores back into the field; a core pixel beyond the field's edge is dropped (cores tile the field from 0, the last ones
+// overhang), so every field pixel has exactly one writer
 __global__ __launch_bounds__(256) void k_tiles_scatter(TileArgs a) {
     const int b = blockIdx.z;
     const int ox = a.x0[b], oy = a.y0[b];
     for (int x = a.hx + blockIdx.y; x < a.TX - a.hx; x += gridDim.y) {
-        cf* dst = a.field + (size_t)wrap_idx(ox + x, a.FX) * a.FY;
+        const int xg = ox + x;
+        if (xg < 0 || xg >= a.FX) continue;
+        cf* dst = a.field + (size_t)xg * a.FY;
         const cf* src = a.tiles + ((size_t)b * a.TX + x) * a.TY;
-        for (int y = a.hy + blockIdx.x * blockDim.x + threadIdx.x; y < a.TY - a.hy; y += gridDim.x * blockDim.x) dst[wrap_idx(oy + y, a.FY)] = src[y];
+        for (int y = a.hy + blockIdx.x * blockDim.x + threadIdx.x; y < a.TY - a.hy; y += gridDim.x * blockDim.x) {
+            const int yg = oy + y;
+            if (yg >= 0 && yg < a.FY) dst[yg] = src[y];
+        }
+    }
+}
+// Adjoint of the tapered periodic gather: field[xg][yg] = sum over the tiles b and tile pixels (x, y) that were cut from
+// (xg, yg) — periodically — of w(x) w(y) tiles[b][x][y].  One workgroup per field row; it first lists the (tile, x) pairs
+// that map onto its row, then every thread sums its columns over the list in a fixed order (deterministic, no atomics).
+#define BDOF_TILE_MAXLIST 1024
+__global__ __launch_bounds__(256) void k_tiles_gather_adjoint(TileArgs a) {
+    __shared__ int lb[BDOF_TILE_MAXLIST], lx[BDOF_TILE_MAXLIST];
+    __shared__ int nlist;
+    for (int xg = blockIdx.x; xg < a.FX; xg += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int n = 0;
+            for (int b = 0; b < a.B; ++b) {
+                // tile rows x with (x0[b] + x) mod FX == xg
+                int x = wrap_idx(xg - a.x0[b], a.FX);
+                for (; x < a.TX && n < BDOF_TILE_MAXLIST; x += a.FX) { lb[n] = b; lx[n] = x; ++n; }
+            }
+            nlist = n;
+        }
+        __syncthreads();
+        const int n = nlist;
+        for (int yg = threadIdx.x; yg < a.FY; yg += blockDim.x) {
+            float sx = 0.f, sy = 0.f;
+            for (int e = 0; e < n; ++e) {
+                const int b = lb[e], x = lx[e];
+                const float wx = taper_weight(x, a.TX, a.taper);
+                for (int y = wrap_idx(yg - a.y0[b], a.FY); y < a.TY; y += a.FY) {
+                    const float w = wx * taper_weight(y, a.TY, a.taper);
+                    const cf v = a.tiles[((size_t)b * a.TX + x) * a.TY + y];
+                    sx = fmaf(w, v.x, sx);
+                    sy = fmaf(w, v.y, sy);
+                }
+            }
+            a.field[(size_t)xg * a.FY + yg] = make_float2(sx, sy);
+        }
+    }
+}
+// Object gradient of a slice range of the tiled propagation: the window-frame gradient rows grot[b][z - z0][x][y] of every
+// tile are added into the volume gradient rows gvol[tab[z][xg]][yg], xg = x0[b] + x, yg = y0[b] + y (the object is not
+// periodic: tile pixels beyond the volume saw vacuum and contribute nothing).  One workgroup per volume column xg; a thread
+// owns (xg, yg) for all z of the range, so rows shared by several slices (a slab repeated over z) accumulate in a register.
+// Requires tab[z][.] to be injective in xg for every z (no rotation), which is what the tiled path runs.
+struct TileGradArgs {
+    const float2* grot;     // [B][nz][TX][TY]
+    float2* gvol;           // [rows][volNY]
+    const int* tab;         // [S][volNX] of the (single) angle
+    const int* x0;
+    const int* y0;
+    int B, TX, TY, volNX, volNY, z0, nz, accumulate;
+};
+__global__ __launch_bounds__(256) void k_tiles_grad_add(TileGradArgs a) {
+    __shared__ int lb[BDOF_TILE_MAXLIST];
+    __shared__ int nlist;
+    for (int xg = blockIdx.x; xg < a.volNX; xg += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int n = 0;
+            for (int b = 0; b < a.B && n < BDOF_TILE_MAXLIST; ++b) {
+                const int x = xg - a.x0[b];
+                if (x >= 0 && x < a.TX) lb[n++] = b;
+            }
+            nlist = n;
+        }
+        __syncthreads();
+        const int n = nlist;
+        for (int yg = threadIdx.x; yg < a.volNY; yg += blockDim.x) {
+            // the tiles that cover (xg, yg): found once, outside the slice loop (a handful: (T / core)^2)
+            constexpr int MAXM = 9;
+            size_t moff[MAXM];
+            int nm = 0, spill_from = n;
+            for (int e = 0; e < n; ++e) {
+                const int b = lb[e];
+                const int y = yg - a.y0[b];
+                if (y < 0 || y >= a.TY) continue;
+                if (nm == MAXM) { spill_from = e; break; }
+                moff[nm++] = (((size_t)b * a.nz) * a.TX + (xg - a.x0[b])) * a.TY + y;
+            }
+            const size_t zstride = (size_t)a.TX * a.TY;
+            int cur = -1;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int zr = 0; zr < a.nz; ++zr) {
+                const int dest = a.tab[(size_t)(a.z0 + zr) * a.volNX + xg];
+                if (dest != cur) {
+                    if (cur >= 0) {
+                        float2* d = a.gvol + (size_t)cur * a.volNY + yg;
+                        *d = make_float2(d->x + acc.x, d->y + acc.y);
+                    }
+                    cur = dest;
+                    acc = make_float2(0.f, 0.f);
+                }
+#pragma unroll
+                for (int m = 0; m < MAXM; ++m) {
+                    if (m < nm) {
+                        const float2 g = a.grot[moff[m] + zr * zstride];
+                        acc.x += g.x;
+                        acc.y += g.y;
+                    }
+                }
+                for (int e = spill_from; e < n; ++e) {          // more than MAXM covering tiles (very large halos)
+                    const int b = lb[e];
+                    const int y = yg - a.y0[b];
+                    if (y < 0 || y >= a.TY) continue;
+                    const float2 g = a.grot[(((size_t)b * a.nz + zr) * a.TX + (xg - a.x0[b])) * a.TY + y];
+                    acc.x += g.x;
+                    acc.y += g.y;
+                }
+            }
+            if (cur >= 0) {
+                float2* d = a.gvol + (size_t)cur * a.volNY + yg;
+                *d = make_float2(d->x + acc.x, d->y + acc.y);
+            }
+        }
     }
 }
 

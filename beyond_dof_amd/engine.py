@@ -25,7 +25,7 @@ class MultisliceEngine(object):
     """One wavefield geometry (NY x NX x S) on one GPU."""
 
     def __init__(self, ny, nx, n_slice, batch_max, with_grad=True, device=0, stream=None, force_generic=False, engine='auto',
-                 recompute=None):
+                 recompute=None, no_grot=False):
         """Engines (include/bdof.h, bdof_configure): powers of two in 64..1024 run on the fused streaming kernels; small
         square fields (32..128, e.g. the 72 x 72 ptychography probe) on the LDS-resident kernel when there is no fused plan
         or the batch is large; every other size on the generic engine (rocFFT).  engine='generic' (= force_generic=True),
@@ -44,7 +44,7 @@ class MultisliceEngine(object):
         self.ctx.check(self.lib.bdof_configure(self.h, self.ny, self.nx, self.n_slice, self.batch_max,
                                                int(bool(with_grad)) | (2 if (force_generic or os.environ.get('BDOF_FORCE_GENERIC')) else 0)
                                                | (4 if engine == 'streaming' else 0) | (8 if engine == 'resident' else 0)
-                                               | (16 if self.recompute else 0)))
+                                               | (16 if self.recompute else 0) | (32 if no_grot else 0)))
         self._engine_arg = 'generic' if force_generic else engine
         self._device = device
         self.det_mode = _lib.DET_NONE

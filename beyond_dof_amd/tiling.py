@@ -19,7 +19,7 @@ from .engine import MultisliceEngine
 
 class TiledPropagator(object):
     def __init__(self, field_shape, n_slice, energy_ev, psize_cm, tile=512, halo=64, slices_per_exchange=None, safety=0.5,
-                 taper=None, variant='numpy_skip_last', device=0, pi=util.PI):
+                 taper=None, variant='numpy_skip_last', device=0, pi=util.PI, with_grad=False):
         """field_shape (FY, FX); tile: fused plan size (64 ... 1024); halo: pixels per side that are recomputed, not kept; its
         outer `taper` pixels (default halo / 2) are ramped to zero so that the tile's periodic boundary has no jump.
         slices_per_exchange: slices between two stitches; default safety * (halo - taper) / (lambda dz / (2 dx^2))."""
@@ -42,7 +42,12 @@ class TiledPropagator(object):
         self.x0 = np.repeat(np.array(ox, dtype=np.int32), len(oy))
         self.y0 = np.tile(np.array(oy, dtype=np.int32), len(ox))
         self.n_tiles = len(self.x0)
-        self.eng = MultisliceEngine(self.tile, self.tile, self.n_slice, self.n_tiles, with_grad=False, device=device, engine='streaming')
+        # gradient: tape-free range sweeps with a per-range gradient buffer (bdof_adjoint_range); the ctx holds no [B][S] workspace
+        self.with_grad = bool(with_grad)
+        if self.with_grad and variant != 'tf_all':
+            raise ValueError("the tiled gradient is written for variant='tf_all' (a transfer-function step after every slice)")
+        self.eng = MultisliceEngine(self.tile, self.tile, self.n_slice, self.n_tiles, with_grad=self.with_grad, device=device,
+                                    engine='streaming', recompute=self.with_grad, no_grot=self.with_grad)
         self.ctx, self.lib, self.h = self.eng.ctx, self.eng.lib, self.eng.h
         self.eng.set_physics(energy_ev, psize_cm, None, variant=variant, pi=pi, field_shape=(self.fy, self.fx))
         self.eng.set_probe_none()
@@ -94,3 +99,51 @@ class TiledPropagator(object):
         self.forward_device()
         self.ctx.sync()
         return np.ascontiguousarray(self.field.download().T)
+
+    # ---- loss + gradient -----------------------------------------------------------------------
+    def loss_and_grad_device(self, meas_dev):
+        """The device part of loss_and_grad: self.field holds the probe [x][y] on entry and G(probe) on exit; meas_dev: device
+        float [x][y]; returns (loss, device buffer of the volume gradient in the object's row layout)."""
+        if not self.with_grad:
+            raise RuntimeError('TiledPropagator(with_grad=True) needed')
+        import ctypes
+        lib, h, p = self.lib, self.h, self.idx.ptr
+        a, xo, yo = p, p + 4 * self.n_tiles, p + 8 * self.n_tiles
+        T, B = self.tile, self.n_tiles
+        segs = self.segments()
+        if getattr(self, '_ends', None) is None or len(self._ends) != len(segs):
+            self._ends = [DeviceBuffer(self.ctx, B * T * T * 8, np.complex64, (B, T, T)) for _ in segs]
+            self._grot = DeviceBuffer(self.ctx, B * max(nz for _, nz in segs) * T * T * 8, np.float32)
+            self._gvol = DeviceBuffer.zeros(self.ctx, self.eng._keep['obj'].shape, np.float32)
+        for (z0, nz), end in zip(segs, self._ends):
+            self.ctx.check(lib.bdof_tiles_gather(h, self.field.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.taper))
+            self.ctx.check(lib.bdof_forward_range(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, end.ptr, 1))
+            self.ctx.check(lib.bdof_tiles_scatter(h, end.ptr, self.field.ptr, self.fx, self.fy, B, T, T, xo, yo, self.halo, self.halo))
+        self.ctx.check(lib.bdof_field_loss_seed(h, self.field.ptr, _lib._ptr(meas_dev), self.fx, self.fy))
+        gvol = self._gvol
+        self.ctx.check(lib.bdof_memset(h, gvol.ptr, 0, gvol.nbytes))
+        for (z0, nz), end in reversed(list(zip(segs, self._ends))):
+            self.ctx.check(lib.bdof_tiles_scatter_adjoint(h, self.field.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.halo, self.halo))
+            self.ctx.check(lib.bdof_adjoint_range(h, B, a, xo, yo, z0, nz, end.ptr, self.tiles_in.ptr, self.tiles_out.ptr, self._grot.ptr))
+            self.ctx.check(lib.bdof_tiles_grad_add(h, self._grot.ptr, gvol.ptr, B, T, T, xo, yo, z0, nz))
+            self.ctx.check(lib.bdof_tiles_gather_adjoint(h, self.tiles_out.ptr, self.field.ptr, self.fx, self.fy, B, T, T, xo, yo, self.taper))
+        loss = ctypes.c_double(0)
+        self.ctx.check(lib.bdof_get_loss(h, ctypes.byref(loss)))
+        return loss.value, gvol
+
+    def loss_and_grad(self, probe_real, probe_imag, meas_abs):
+        """loss = mean((|exit wave| - meas_abs)^2) over the field (fullfield.py:106, no detector step) and its gradient w.r.t.
+        the object, through the tiled forward model — the exact adjoint of what forward() computes, range by range, last
+        range first: adjoint of the stitch (cores) -> bdof_adjoint_range (the forward wave is marched back from the range's
+        end state, no tape) -> gradient rows added into the volume gradient -> adjoint of the tapered cut.  Returns
+        (loss, g_delta, g_beta) in the shape the object was given in, and leaves G(probe) in self.field."""
+        probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.fy, self.fx))
+        self.field.upload(np.ascontiguousarray(probe.T.astype(np.complex64)))
+        meas = DeviceBuffer.from_host(self.ctx, np.ascontiguousarray(np.asarray(meas_abs, dtype=np.float32).T))
+        loss, gvol = self.loss_and_grad_device(meas)
+        self.ctx.sync()
+        g = gvol.download()
+        if g.ndim == 3:                                            # slab rows [x][y][2]
+            return loss, np.ascontiguousarray(g[..., 0].T), np.ascontiguousarray(g[..., 1].T)
+        gd, gb = util.rows_to_volume(g)
+        return loss, gd, gb

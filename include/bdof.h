@@ -46,7 +46,9 @@ int bdof_device_count(void);
  *     (cnn_propagator/reconstruct_ptycho.py:106); chosen when no fused plan exists or the batch has >= CUs/4 wavefields;
  *   - generic-size engine (rocFFT + point-wise kernels): every other size.
  * with_grad bits: 0 allocate the tape (S fields per wavefield) and the rotated-frame gradient; 1 force the generic-size
- * engine (cross-checks); 2 never use the resident engine; 3 use it for every batch size.
+ * engine (cross-checks); 2 never use the resident engine; 3 use it for every batch size; 4 (value 16) tape-free adjoint of the
+ * streaming engine: 3 tape fields instead of S, the forward wave is marched back beside the adjoint field;
+ * 5 (value 32) no rotated-frame gradient workspace (range sweeps with caller-owned buffers, bdof_adjoint_range).
  * Replaces the per-call allocations of multislice_propagate_batch_numpy
  * (cnn_propagator/np_funcs.py:20,43) and of autograd's tape (cnn_propagator/fullfield.py:329). */
 int bdof_configure(bdof_ctx* ctx, int NY, int NX, int S, int Bmax, int with_grad);
@@ -120,6 +122,24 @@ int bdof_tiles_gather(bdof_ctx* ctx, const void* field, int FX, int FY, void* ti
                       int taper);
 int bdof_tiles_scatter(bdof_ctx* ctx, const void* tiles, void* field, int FX, int FY, int B, int TX, int TY, const int* x0, const int* y0,
                        int halo_x, int halo_y);
+
+/* Gradient of the tiled path (tape-free, range by range, last range first).  bdof_adjoint_range is the adjoint of
+ * bdof_forward_range(prop_last = 1): end_real = the psi_{z0+nz} that call returned, g_end_real = G(psi_{z0+nz}) (both device
+ * [B][NX][NY] complex); g_start_real receives G(psi_{z0}); the gradient rows of the range's slices go to grot_range, device
+ * [B][nz][NX][NY] pairs (a ctx configured with with_grad | 16 | 32 has no [B][S] gradient workspace of its own: 260 GB for
+ * 121 tiles of 512^2 x 1024 slices).  The forward wave is marched back from end_real beside the adjoint field.
+ * bdof_tiles_scatter_adjoint / bdof_tiles_gather_adjoint: adjoints of the two stitching steps; bdof_tiles_grad_add: the
+ * range's gradient rows added into the volume gradient gvol (rows of volNY pairs, the object's own layout) through the table
+ * of bdof_set_object — which must be injective in x for every slice (no rotation: the tiled path runs one pre-rotated object).
+ * bdof_field_loss_seed: loss mean((|field| - meas)^2) (bdof_get_loss) and, in place, its seed — fullfield.py:106 on a field. */
+int bdof_adjoint_range(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
+                       const void* end_real, const void* g_end_real, void* g_start_real, void* grot_range);
+int bdof_tiles_scatter_adjoint(bdof_ctx* ctx, const void* field, int FX, int FY, void* tiles, int B, int TX, int TY, const int* x0,
+                               const int* y0, int halo_x, int halo_y);
+int bdof_tiles_gather_adjoint(bdof_ctx* ctx, const void* tiles, void* field, int FX, int FY, int B, int TX, int TY, const int* x0,
+                              const int* y0, int taper);
+int bdof_tiles_grad_add(bdof_ctx* ctx, const void* grot_range, void* gvol, int B, int TX, int TY, const int* x0, const int* y0, int z0, int nz);
+int bdof_field_loss_seed(bdof_ctx* ctx, void* field, const float* meas, int FX, int FY);
 
 /* probe_array[i] of np_funcs.py:43 (wave after slice i), device out [B][NX][NY]; valid after a
  * bdof_forward(keep_tape=1) (bdof_loss_grad reuses the tape for its own purposes and invalidates it). */

@@ -555,8 +555,8 @@ def tiled_multislice_propagate(grid_delta, grid_beta, probe, energy_ev, psize_cm
                     w = w * (np.exp(1j * k * d) * np.exp(-k * b))
                     if z < n_slice - 1 or variant == 'tf_all':
                         w = np.fft.ifft2(np.fft.fft2(w) * h)
-                cy = np.arange(y0 + halo, y0 + halo + core) % fy
-                cx = np.arange(x0 + halo, x0 + halo + core) % fx
-                new[np.ix_(cy, cx)] = w[halo:halo + core, halo:halo + core]
+                # cores tile the field from 0; the part of a last core that overhangs the field's edge is dropped
+                ny_c, nx_c = min(core, fy - (y0 + halo)), min(core, fx - (x0 + halo))
+                new[y0 + halo:y0 + halo + ny_c, x0 + halo:x0 + halo + nx_c] = w[halo:halo + ny_c, halo:halo + nx_c]
         field = new
     return field

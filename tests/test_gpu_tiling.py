@@ -68,3 +68,90 @@ def test_tiled_slab_object_and_default_interval():
     ref, _ = orc.multislice_propagate_batch_numpy(delta[None], 0.1 * delta[None], probe, np.zeros_like(probe), 5000., 1e-7, None,
                                                   (1,) + delta.shape, return_probe_array=False)
     assert rel(out, ref[0]) <= 2e-5, rel(out, ref[0])
+
+
+def _torch_tiled_loss_grad(delta, beta, probe, meas, tile, halo, seg, taper):
+    """The tiled algorithm (oracle.tiled_multislice_propagate, variant tf_all) in torch float64 on the CPU, differentiated by
+    autograd: pins the device's hand-derived tiled adjoint."""
+    import torch
+    fy, fx, S = delta.shape
+    voxel = np.array([1., 1., 1.])
+    lmbda = 1240. / 5000.
+    k = 2. * orc.PI * voxel[-1] / lmbda
+    h = torch.from_numpy(np.fft.ifftshift(orc.get_kernel_tile(voxel[-1], lmbda, voxel, (tile, tile), (fy, fx))))
+    w1 = np.ones(tile)
+    ramp = 0.5 - 0.5 * np.cos(np.pi * (np.arange(taper) + 0.5) / taper)
+    w1[:taper], w1[tile - taper:] = ramp, ramp[::-1]
+    win = torch.from_numpy(w1[:, None] * w1[None, :])
+    td = torch.tensor(delta, requires_grad=True)
+    tb = torch.tensor(beta, requires_grad=True)
+    field = torch.tensor(probe.astype(np.complex64).astype(np.complex128))
+    core = tile - 2 * halo
+    oy, ox = orc.tile_origins(fy, tile, halo), orc.tile_origins(fx, tile, halo)
+    for z0 in range(0, S, seg):
+        nz = min(seg, S - z0)
+        new = torch.zeros_like(field)
+        for y0 in oy:
+            ry = np.arange(y0, y0 + tile)
+            iy = torch.from_numpy(ry % fy)
+            for x0 in ox:
+                rx = np.arange(x0, x0 + tile)
+                ix = torch.from_numpy(rx % fx)
+                w = field[iy][:, ix] * win
+                inside = torch.from_numpy((((ry >= 0) & (ry < fy))[:, None] & ((rx >= 0) & (rx < fx))[None, :]).astype(np.float64))
+                for z in range(z0, z0 + nz):
+                    d = td[:, :, z][iy][:, ix] * inside
+                    b = tb[:, :, z][iy][:, ix] * inside
+                    w = w * torch.exp(1j * k * d) * torch.exp(-k * b)
+                    w = torch.fft.ifft2(torch.fft.fft2(w) * h)
+                ny_c, nx_c = min(core, fy - (y0 + halo)), min(core, fx - (x0 + halo))
+                pad = torch.zeros_like(field)
+                pad[y0 + halo:y0 + halo + ny_c, x0 + halo:x0 + halo + nx_c] = w[halo:halo + ny_c, halo:halo + nx_c]
+                new = new + pad
+        field = new
+    loss = torch.mean((torch.abs(field) - torch.from_numpy(meas)) ** 2)
+    loss.backward()
+    return loss.item(), td.grad.numpy(), tb.grad.numpy(), field.detach().numpy()
+
+
+def test_tiled_gradient_vs_autograd_of_the_algorithm():
+    """TiledPropagator.loss_and_grad (stitch adjoints + tape-free range sweeps + overlap-add of the tiles' gradient rows)
+    against torch autograd of the same tiled forward in float64, and against the whole-field oracle's gradient."""
+    from beyond_dof_amd.tiling import TiledPropagator
+    n, S, tile, halo, seg = 128, 12, 64, 16, 5
+    delta, beta, probe = _problem(n, S, seed=3)
+    rng = np.random.default_rng(1)
+    tp = TiledPropagator((n, n), S, 5000., 1e-7, tile=tile, halo=halo, slices_per_exchange=seg, variant='tf_all', with_grad=True)
+    assert tp.n_tiles == 16 and tp.segments() == [(0, 5), (5, 5), (10, 2)]
+    tp.set_object(delta, beta)
+    out = tp.forward(probe, np.zeros_like(probe))
+    meas = (np.abs(out) * (1 + 0.05 * rng.normal(size=out.shape))).astype(np.float32).astype(np.float64)
+    loss, gd, gb = tp.loss_and_grad(probe, np.zeros_like(probe), meas)
+    rl, rgd, rgb, rfield = _torch_tiled_loss_grad(delta, beta, probe, meas, tile, halo, seg, tp.taper)
+    assert rel(out, rfield) <= 2e-6
+    assert abs(loss - rl) <= 1e-5 * abs(rl)
+    assert rel(gd, rgd) <= 2e-4 and rel(gb, rgb) <= 2e-4, (rel(gd, rgd), rel(gb, rgb))
+    # the whole-field model's gradient (np_funcs forward + hand-derived adjoint): the tiling error of a 16-pixel halo on top
+    wl, wgd, wgb = orc.multislice_loss_and_grad(delta[None], beta[None], probe, np.zeros_like(probe), 5000., 1e-7, meas[None], None, 'tf_all')
+    assert abs(loss - wl) <= 1e-3 * abs(wl)
+    assert rel(gd, wgd[0]) <= 2e-2, rel(gd, wgd[0])
+
+
+def test_tiled_gradient_slab_object():
+    """The same slab in every slice: the gradient rows of all slices and all tiles accumulate into one (FY, FX) pair of maps."""
+    from beyond_dof_amd.tiling import TiledPropagator
+    n, S, tile, halo, seg = 128, 6, 64, 16, 4
+    rng = np.random.default_rng(7)
+    slab = np.zeros((n, n))
+    slab[32:96, 32:96] = rng.uniform(0, 5e-5, size=(64, 64))
+    yy, xx = np.mgrid[:n, :n]
+    probe = np.exp(-((yy - n / 2.) ** 2 + (xx - n / 2.) ** 2) / (2 * (n / 6.) ** 2))
+    tp = TiledPropagator((n, n), S, 5000., 1e-7, tile=tile, halo=halo, slices_per_exchange=seg, variant='tf_all', with_grad=True)
+    tp.set_object_slab(slab, 0.1 * slab)
+    out = tp.forward(probe, np.zeros_like(probe))
+    meas = (np.abs(out) * (1 + 0.05 * rng.normal(size=out.shape))).astype(np.float32).astype(np.float64)
+    loss, gd, gb = tp.loss_and_grad(probe, np.zeros_like(probe), meas)
+    delta = np.repeat(slab[:, :, None], S, axis=2)
+    rl, rgd, rgb, _ = _torch_tiled_loss_grad(delta, 0.1 * delta, probe, meas, tile, halo, seg, tp.taper)
+    assert abs(loss - rl) <= 1e-5 * abs(rl)
+    assert rel(gd, rgd.sum(axis=2)) <= 2e-4 and rel(gb, rgb.sum(axis=2)) <= 2e-4
