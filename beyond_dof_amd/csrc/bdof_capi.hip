@@ -1787,10 +1787,14 @@ int bdof_adam_step_slab(bdof_ctx* c, const void* x_old, void* x_new, const void*
     if (nx == 0) return 0;
     HIPC(c, hipSetDevice(c->device));
     ProfScope ps(c, BDOF_K_ADAM);
-    const double bc1 = 1.0 - std::pow((double)b1, (double)(i_batch + 1));
-    const double bc2 = 1.0 - std::pow((double)b2, (double)(i_batch + 1));
+    // b1, b2 arrive as float32 (0.999f = 0.99900001287...); the reference's are Python floats.  The decimal the caller meant is
+    // recovered (7 significant digits) so that 1 - b and the bias corrections are those of the float64 reference.
+    const double b1d = std::round((double)b1 * 1e7) / 1e7, b2d = std::round((double)b2 * 1e7) / 1e7;
+    const double bc1 = 1.0 - std::pow(b1d, (double)(i_batch + 1));
+    const double bc2 = 1.0 - std::pow(b2d, (double)(i_batch + 1));
     AdamArgs a{(const float2*)x_old, (float2*)x_new, (const float2*)g, (float2*)m, (float2*)v, mask, NXv, NZv, NYv,
-               g_scale, alpha_d, alpha_b, gamma, lr, b1, b2, eps, (float)(1.0 / bc1), (float)(1.0 / bc2), clip, x0, x0 + nx};
+               g_scale, alpha_d, alpha_b, gamma, lr, (float)b1d, (float)b2d, eps, (float)(1.0 / bc1), (float)(1.0 / bc2),
+               (float)(1.0 - b1d), (float)(1.0 - b2d), clip, x0, x0 + nx};
     const size_t n = (size_t)nx * NZv * NYv;
     size_t need = (n + 255) / 256;
     int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;

@@ -821,6 +821,7 @@ struct AdamArgs {
     float g_scale;         // 1/size                       cnn_propagator/fullfield.py:351
     float alpha_d, alpha_b, gamma;
     float lr, b1, b2, eps, inv_bc1, inv_bc2;   // inv_bc = 1 / (1 - b^(i_batch+1))
+    float om_b1, om_b2;                        // 1 - b1, 1 - b2 formed in float64 on the host (1 - 0.999f is 1.3e-5 off 1e-3)
     int clip;              // max(x, 0)
     int x0, x1;            // slab of the volume updated by this launch: x in [x0, x1)  (the stencil reads beyond it)
 };
@@ -857,10 +858,10 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
             gd += a.gamma * (sgn(c - ym) - sgn(yp - c) + sgn(c - zm) - sgn(zp - c) + sgn(c - xm) - sgn(xp - c));
         }
         float2 m = a.m[idx], v = a.v[idx];
-        m.x = (1.f - a.b1) * gd + a.b1 * m.x;
-        m.y = (1.f - a.b1) * gb + a.b1 * m.y;
-        v.x = (1.f - a.b2) * gd * gd + a.b2 * v.x;
-        v.y = (1.f - a.b2) * gb * gb + a.b2 * v.y;
+        m.x = a.om_b1 * gd + a.b1 * m.x;
+        m.y = a.om_b1 * gb + a.b1 * m.y;
+        v.x = a.om_b2 * gd * gd + a.b2 * v.x;
+        v.y = a.om_b2 * gb * gb + a.b2 * v.y;
         a.m[idx] = m;
         a.v[idx] = v;
         float nd = xv.x - a.lr * (m.x * a.inv_bc1) / (sqrtf(v.x * a.inv_bc2) + a.eps);
