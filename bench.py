@@ -204,6 +204,8 @@ def main():
     ap.add_argument('--cpu-slices', type=int, default=192)
     ap.add_argument('--no-profile', action='store_true', help='skip the roofline pass')
     ap.add_argument('--recompute', action='store_true', help='tape-free adjoint (bdof_configure flag 16): psi_z is marched back')
+    ap.add_argument('--rotation', default='nearest', choices=['nearest', 'bilinear'],
+                    help="'bilinear': the TF twin's tf_rotate instead of the cnn variant's fused nearest-neighbour tables, for comparison")
     ap.add_argument('--propagator', default='fft', choices=['fft', 'conv'],
                     help="'conv': the reference entry points' truncated real-space kernel (17 taps), for comparison")
     args = ap.parse_args()
@@ -239,7 +241,8 @@ def main():
 
     t_setup = time.time()
     solver = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, comm=comm, device=device,
-                             propagator=args.propagator, recompute=args.recompute)
+                             propagator=args.propagator, recompute=args.recompute, rotation=args.rotation,
+                             theta=-np.linspace(0, 2 * np.pi, n_theta) if args.rotation == 'bilinear' else None)
     true_d, true_b = make_phantom(n)
     solver.set_volume(true_d, true_b)
     meas = np.zeros((n_theta, n, n), dtype=np.float32)
@@ -275,7 +278,7 @@ def main():
         elapsed = float(comm.allreduce_max_host(np.array([elapsed]))[0])
     groups = solver.eng.batch_groups(mb)
     S = n
-    roof = None if args.no_profile or args.propagator != 'fft' else roofline_pass(solver, my_batches[0], hyper, n, mb, S)
+    roof = None if args.no_profile or args.propagator != 'fft' or args.rotation != 'nearest' else roofline_pass(solver, my_batches[0], hyper, n, mb, S)
     loss = solver.loss_and_grad(my_batches[0], want_loss=True)
     comm.Barrier()
 
@@ -297,7 +300,7 @@ def main():
                           'exchange': ('none (1 rank)' if world == 1 and not getattr(comm, 'always_reduce', False) else
                                        '{} ({} slab(s), {})'.format(comm.backend, n_slabs, 'reduce-scatter + sharded Adam + all-gather'
                                                                     if sharded else 'all-reduce')),
-                          'allreduce_slabs': n_slabs, 'sharded_adam': bool(sharded), 'propagator': args.propagator,
+                          'allreduce_slabs': n_slabs, 'sharded_adam': bool(sharded), 'propagator': args.propagator, 'rotation': args.rotation,
                           'adjoint': 'recompute (tape-free)' if args.recompute else 'tape',
                           'hbm_used_GiB': solver.ctx.mem_used() / 2.0 ** 30},
                'roofline': roof}

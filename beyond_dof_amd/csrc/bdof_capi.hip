@@ -1811,6 +1811,33 @@ int bdof_adam_step(bdof_ctx* c, const void* x_old, void* x_new, const void* g, v
                                i_batch, clip, 0, NXv);
 }
 
+int bdof_rotate_bilinear(bdof_ctx* c, const void* vol, int NXv, int NZv, int NYv, const double* prm, int B, void* out_rows) {
+    if (!c || !vol || !prm || !out_rows || B < 1) return BDOF_ERR_ARG;
+    if (NXv < 1 || NZv < 1 || NYv < 2 || NYv % 2) return fail(c, BDOF_ERR_SIZE, "bdof_rotate_bilinear needs an even NY");
+    HIPC(c, hipSetDevice(c->device));
+    RotBilinArgs a{(const float2*)vol, (float2*)out_rows, nullptr, (const double4*)prm, B, NXv, NZv, NYv, 0, 0, 0, 1.f};
+    const size_t nrows = (size_t)B * NZv * NXv;
+    const int grid = (int)std::min<size_t>((nrows + 3) / 4, (size_t)c->ncu * 16);
+    hipLaunchKernelGGL(k_rot_bilinear, dim3(grid), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_rotate_bilinear_adjoint(bdof_ctx* c, const void* grot, int NXv, int NZv, int NYv, const double* prm, int B, void* gvol, int row0,
+                                 int n_rows, int accumulate, float scale) {
+    if (!c || !grot || !prm || !gvol || B < 1) return BDOF_ERR_ARG;
+    if (NXv < 1 || NZv < 1 || NYv < 2 || NYv % 2) return fail(c, BDOF_ERR_SIZE, "bdof_rotate_bilinear_adjoint needs an even NY");
+    if (row0 < 0 || n_rows < 0 || (long long)row0 + n_rows > (long long)NXv * NZv) return fail(c, BDOF_ERR_ARG, "destination rows outside the volume");
+    if (n_rows == 0) return 0;
+    HIPC(c, hipSetDevice(c->device));
+    ProfScope ps(c, BDOF_K_ROT_ADJ);
+    RotBilinArgs a{nullptr, (float2*)grot, (float2*)gvol, (const double4*)prm, B, NXv, NZv, NYv, row0, row0 + n_rows, accumulate, scale};
+    const int grid = std::min((n_rows + 3) / 4, c->ncu * 16);
+    hipLaunchKernelGGL(k_rot_bilinear_adjoint, dim3(grid), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
 int bdof_regularizer_value(bdof_ctx* c, const void* x, int NXv, int NZv, int NYv, double* sums) {
     if (!c || !x || !sums) return BDOF_ERR_ARG;
     if (NXv < 1 || NZv < 1 || NYv < 1) return fail(c, BDOF_ERR_ARG, "bad volume shape");

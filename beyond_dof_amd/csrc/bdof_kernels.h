@@ -1071,6 +1071,113 @@ __global__ __launch_bounds__(256) void k_gather_fields(float4* __restrict__ dst,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bilinear rotation of the object (the TF twin's tf_rotate(..., interpolation='BILINEAR'), tensorflow_recon/fullfield.py:96):
+// tf.contrib.image.rotate treats the (Y, X, Z, 2) object as NHWC images of height X and width Z and maps every OUTPUT pixel
+// (h, w) to the input point (h', w') = (sin w + cos h + y_off, cos w - sin h + x_off), sampled bilinearly with zeros outside.
+// In the [X][Z][Y] row layout a rotated row (x, z) is a weighted sum of at most four volume rows — still whole contiguous
+// rows.  prm[b] = (cos, sin, x_off, y_off) in float64 (coordinates are formed per ROW, so float64 costs nothing).
+// Output rows [b][z][x][y]: the layout of already rotated objects (bdof_set_object without a table).
+// ---------------------------------------------------------------------------------------------
+struct RotBilinArgs {
+    const float2* vol;      // [NXv][NZv][NYv]
+    float2* rot;            // forward: out [B][NZv][NXv][NYv] ; adjoint: in, the rotated-frame gradient
+    float2* gvol;           // adjoint: out [NXv][NZv][NYv]
+    const double4* prm;     // [B]
+    int B, NXv, NZv, NYv;
+    int d0, d1, accumulate; // adjoint: destination rows [d0, d1)
+    float scale;
+};
+// source point and the four (row index, weight) pairs of output row (h = x, w = z); rows outside the volume get weight 0
+__device__ __forceinline__ void bilin_taps(const double4 p, int h, int w, int H, int W, int (&row)[4], float (&wt)[4]) {
+    const double sw = p.x * w - p.y * h + p.z, sh = p.y * w + p.x * h + p.w;
+    const double fw = floor(sw), fh = floor(sh);
+    const int w0 = (int)fw, h0 = (int)fh;
+    const float aw = (float)(sw - fw), ah = (float)(sh - fh);
+    const int hs[4] = {h0, h0, h0 + 1, h0 + 1}, ws[4] = {w0, w0 + 1, w0, w0 + 1};
+    const float cw[4] = {(1.f - ah) * (1.f - aw), (1.f - ah) * aw, ah * (1.f - aw), ah * aw};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const bool in = hs[i] >= 0 && hs[i] < H && ws[i] >= 0 && ws[i] < W;
+        row[i] = in ? hs[i] * W + ws[i] : 0;
+        wt[i] = in ? cw[i] : 0.f;
+    }
+}
+// one wave per output row (4 rows per workgroup)
+__global__ __launch_bounds__(256) void k_rot_bilinear(RotBilinArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t nrows = (size_t)a.B * a.NZv * a.NXv;
+    const int nv = a.NYv / 2;                      // float4 = two (delta, beta) pairs
+    for (size_t o = (size_t)blockIdx.x * 4 + wave; o < nrows; o += (size_t)gridDim.x * 4) {
+        const int x = o % a.NXv;
+        const size_t r = o / a.NXv;
+        const int z = r % a.NZv, b = r / a.NZv;
+        int row[4];
+        float wt[4];
+        bilin_taps(a.prm[b], x, z, a.NXv, a.NZv, row, wt);
+        float4* dst = reinterpret_cast<float4*>(a.rot + o * a.NYv);
+        for (int v = lane; v < nv; v += 64) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (wt[i] != 0.f) {
+                    const float4 s = reinterpret_cast<const float4*>(a.vol + (size_t)row[i] * a.NYv)[v];
+                    acc.x = fmaf(wt[i], s.x, acc.x); acc.y = fmaf(wt[i], s.y, acc.y);
+                    acc.z = fmaf(wt[i], s.z, acc.z); acc.w = fmaf(wt[i], s.w, acc.w);
+                }
+            }
+            dst[v] = acc;
+        }
+    }
+}
+// Adjoint, as a gather (deterministic, no atomics): volume row d = (x', z') collects w * rotated-frame rows (x, z) whose
+// source point lies within one pixel of it.  A rotation preserves distances, so those (x, z) lie within sqrt(2) of the
+// inverse-rotated (x', z'): the 4 x 4 lattice points around it are examined, the weight of each comes from the FORWARD map
+// (the same numbers the forward kernel used).
+__global__ __launch_bounds__(256) void k_rot_bilinear_adjoint(RotBilinArgs a) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nv = a.NYv / 2;
+    const int H = a.NXv, W = a.NZv;
+    for (int d = a.d0 + blockIdx.x * 4 + wave; d < a.d1; d += gridDim.x * 4) {
+        const int hp = d / W, wp = d - hp * W;            // (x', z')
+        float4* drow = reinterpret_cast<float4*>(a.gvol + (size_t)d * a.NYv);
+        for (int v0 = 0; v0 < nv; v0 += 64) {
+            const int v = v0 + lane;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int b = 0; b < a.B; ++b) {
+                const double4 p = a.prm[b];
+                // inverse of (h', w') = (s w + c h + yo, c w - s h + xo):  w = c (w' - xo) + s (h' - yo),  h = -s (w' - xo) + c (h' - yo)
+                const double dw = wp - p.z, dh = hp - p.w;
+                const double wi = p.x * dw + p.y * dh, hi = -p.y * dw + p.x * dh;
+                const int w0 = (int)floor(wi) - 1, h0 = (int)floor(hi) - 1;
+                for (int jh = 0; jh < 4; ++jh) {
+                    const int h = h0 + jh;
+                    if (h < 0 || h >= H) continue;
+                    for (int jw = 0; jw < 4; ++jw) {
+                        const int w = w0 + jw;
+                        if (w < 0 || w >= W) continue;
+                        const double sw = p.x * w - p.y * h + p.z, sh = p.y * w + p.x * h + p.w;
+                        const double fw = floor(sw), fh = floor(sh);
+                        const int iw = wp - (int)fw, ih = hp - (int)fh;     // which of the 2 x 2 taps of (h, w) is (h', w'): 0 or 1
+                        if (iw < 0 || iw > 1 || ih < 0 || ih > 1) continue;
+                        const float aw = (float)(sw - fw), ah = (float)(sh - fh);
+                        const float wgt = (ih ? ah : 1.f - ah) * (iw ? aw : 1.f - aw);
+                        if (wgt == 0.f || v >= nv) continue;
+                        const float4 s = reinterpret_cast<const float4*>(a.rot + (((size_t)b * W + w) * H + h) * a.NYv)[v];
+                        acc.x = fmaf(wgt, s.x, acc.x); acc.y = fmaf(wgt, s.y, acc.y);
+                        acc.z = fmaf(wgt, s.z, acc.z); acc.w = fmaf(wgt, s.w, acc.w);
+                    }
+                }
+            }
+            if (v < nv) {
+                float4 o = make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
+                if (a.accumulate) f4acc(o, drow[v]);
+                drow[v] = o;
+            }
+        }
+    }
+}
+
 // Value of the regulariser  alpha_d sum|delta| + alpha_b sum|beta| + gamma TV(delta)  (cnn_propagator/fullfield.py:109-118,
 // total_variation_3d util.py:61-70: periodic, anisotropic, sum over the three axes of |roll(x, 1) - x|).  Per-workgroup float64
 // partials [3 * gridDim.x]: sum|delta|, sum|beta|, TV.

@@ -74,6 +74,9 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
     # gradient accumulation over n_batch_per_update minibatches exists only in the TF twin (tensorflow_recon/fullfield.py:
     # 413-425); the cnn variant accepts the keyword and ignores it (default 5!), so it is opt-in here
     accumulate = bool(kwargs.get('accumulate_gradients', False))
+    # 'nearest': the cnn variant's lookup tables over linspace(0, 2 pi) (quirk Q5); 'bilinear': the TF twin's tf_rotate with the true
+    # angles theta = -linspace(theta_st, theta_end) (tensorflow_recon/fullfield.py:96,216)
+    rotation = kwargs.get('rotation', 'nearest')
 
     print_flush('Reading data...', 0, rank)
     t0 = time.time()
@@ -157,11 +160,12 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
         else:
             raise ValueError("Invalid wavefront type. Choose from 'plane', 'fixed', 'optimizable'.")
 
-        coord_ls = util.rotation_lookup_files([dim_y, dim_x, dim_x], n_theta, comm)
+        coord_ls = None if rotation == 'bilinear' else util.rotation_lookup_files([dim_y, dim_x, dim_x], n_theta, comm)
 
         solver = FullfieldSolver(dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm * ds_level,
                                  free_prop_cm=free_prop_cm, probe_real=probe_real, probe_imag=probe_imag, variant=variant,
-                                 comm=comm, device=comm.local_rank, coord_ls=coord_ls, propagator=propagator, kernel_size=kernel_size)
+                                 comm=comm, device=comm.local_rank, coord_ls=coord_ls, propagator=propagator, kernel_size=kernel_size,
+                                 rotation=rotation, theta=theta)
         solver.set_volume(obj_delta, obj_beta)
         solver.set_mask(mask)
         solver.set_measurements(np.abs(prj))

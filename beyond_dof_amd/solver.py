@@ -271,10 +271,19 @@ class _VolumeSolver(object):
 class FullfieldSolver(_VolumeSolver):
     def __init__(self, dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm, free_prop_cm=None,
                  probe_real=None, probe_imag=None, variant='numpy_skip_last', comm=None, device=0, stream=None,
-                 coord_ls=None, propagator='fft', kernel_size=17, recompute=None):
+                 coord_ls=None, propagator='fft', kernel_size=17, recompute=None, rotation='nearest', theta=None):
         """propagator='fft': the transfer-function step of np_funcs.py (north-star path); 'conv': the truncated real-space
-        kernel of propagation.py, what cnn_propagator/fullfield.py:87,102 calls (kernel_size taps per axis)."""
+        kernel of propagation.py, what cnn_propagator/fullfield.py:87,102 calls (kernel_size taps per axis).
+        rotation='nearest': the cnn variant's lookup tables, fused into the kernels (cnn_propagator/util.py:294-402);
+        'bilinear': the TF twin's tf_rotate(obj, theta[i], 'BILINEAR') (tensorflow_recon/fullfield.py:96) with the true angles
+        `theta` (radians, one per projection): the minibatch's rotated objects are materialised per step
+        (bdof_rotate_bilinear), its adjoint is a gather (bdof_rotate_bilinear_adjoint)."""
         self.conv = propagator == 'conv'
+        self.bilinear = rotation == 'bilinear'
+        if rotation not in ('nearest', 'bilinear'):
+            raise ValueError("rotation must be 'nearest' or 'bilinear'")
+        if self.bilinear and theta is None:
+            raise ValueError("rotation='bilinear' needs the projection angles theta")
         self.dim_y, self.dim_x, self.dim_z = int(dim_y), int(dim_x), int(dim_z)
         self.n_theta, self.mb = int(n_theta), int(minibatch_size)
         self.comm = comm or PseudoComm()
@@ -287,20 +296,47 @@ class FullfieldSolver(_VolumeSolver):
         if probe_real is None:
             probe_real, probe_imag = np.ones((dim_y, dim_x)), np.zeros((dim_y, dim_x))   # 'plane', fullfield.py:276-278
         self.eng.set_probe(probe_real, probe_imag)
-        # rotation lookup tables (cnn_propagator/util.py:294-347), uploaded once
-        if coord_ls is None:
-            coord_ls = util.rotation_lookup([dim_y, dim_x, dim_z], n_theta)
-        tab, off, order = util.device_rotation_tables(coord_ls, self.dim_x, self.dim_z)
-        self.tab = DeviceBuffer.from_host(self.ctx, tab)
-        self.off = DeviceBuffer.from_host(self.ctx, off)
-        self.order = DeviceBuffer.from_host(self.ctx, order)
+        if self.bilinear:
+            # per-angle projective transform of tf.contrib.image.rotate for images of height X and width Z, in float64
+            th = np.asarray(theta, dtype=np.float64)
+            assert len(th) == self.n_theta
+            H, W = self.dim_x, self.dim_z
+            c, sn = np.cos(th), np.sin(th)
+            self.rot_prm = np.stack([c, sn, ((W - 1) - (c * (W - 1) - sn * (H - 1))) / 2.0, ((H - 1) - (sn * (W - 1) + c * (H - 1))) / 2.0], axis=1)
+            self.prm_buf = DeviceBuffer(self.ctx, self.mb * 32, np.float64, (self.mb, 4))
+            self.rot_rows = DeviceBuffer(self.ctx, self.mb * self.dim_z * self.dim_x * self.dim_y * 8, np.float32,
+                                         (self.mb, self.dim_z, self.dim_x, self.dim_y, 2))
+            self.tab = self.off = self.order = None
+        else:
+            # rotation lookup tables (cnn_propagator/util.py:294-347), uploaded once
+            if coord_ls is None:
+                coord_ls = util.rotation_lookup([dim_y, dim_x, dim_z], n_theta)
+            tab, off, order = util.device_rotation_tables(coord_ls, self.dim_x, self.dim_z)
+            self.tab = DeviceBuffer.from_host(self.ctx, tab)
+            self.off = DeviceBuffer.from_host(self.ctx, off)
+            self.order = DeviceBuffer.from_host(self.ctx, order)
         self._init_volume()
         self.meas = None
         self.meas_stage = DeviceBuffer(self.ctx, self.mb * self.dim_x * self.dim_y * 4, np.float32,
                                        (self.mb, self.dim_x, self.dim_y))
         self.angle_buf = DeviceBuffer(self.ctx, self.mb * 4, np.int32, (self.mb,))
         self._bind_volume()
-        self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
+        if not self.bilinear:
+            self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
+
+    def _bind_volume(self):
+        if self.bilinear:
+            return                   # the engine's object is the minibatch's rotated copy, rebuilt at every step (_rotate_batch)
+        self.eng.set_volume(self.x[self.cur], self.dim_x * self.dim_z, self.dim_y, self.tab, self.dim_x, self.n_theta)
+
+    def _rotate_batch(self, idx, B):
+        """Bilinear rotation of the current volume to the B angles idx -> rot_rows, bound as a batch of rotated objects."""
+        lib, h = self.ctx.lib, self.ctx.handle
+        prm = np.zeros((self.mb, 4))
+        prm[:B] = self.rot_prm[np.asarray(idx)]
+        self.prm_buf.upload(prm)
+        self.ctx.check(lib.bdof_rotate_bilinear(h, self.x[self.cur].ptr, self.dim_x, self.dim_z, self.dim_y, self.prm_buf.ptr, B, self.rot_rows.ptr))
+        self.eng.set_volume(self.rot_rows, B * self.dim_z * self.dim_x, self.dim_y, None, 0, 0)
 
     def set_measurements(self, prj_abs):
         """|prj| for every angle, (n_theta, Y, X) (loss uses np.abs(this_prj_batch), fullfield.py:106)."""
@@ -321,14 +357,20 @@ class FullfieldSolver(_VolumeSolver):
         lib, h = self.ctx.lib, self.ctx.handle
         self._stage_batch(angle_idx)
         fn = lib.bdof_loss_grad_conv if self.conv else lib.bdof_loss_grad
-        self.ctx.check(fn(h, self.mb, self.angle_buf.ptr, None, None, self.meas_stage.ptr, None))
+        if self.bilinear:
+            self._rotate_batch(angle_idx, self.mb)
+        self.ctx.check(fn(h, self.mb, None if self.bilinear else self.angle_buf.ptr, None, None, self.meas_stage.ptr, None))
 
     def _produce(self, accumulate=False):
         lib, h = self.ctx.lib, self.ctx.handle
 
         def produce(x0, nx):
-            self.ctx.check(lib.bdof_rotation_adjoint_rows(h, self.mb, self.angle_buf.ptr, self.g.ptr, x0 * self.dim_z,
-                                                          nx * self.dim_z, int(accumulate), 1.0))
+            if self.bilinear:
+                self.ctx.check(lib.bdof_rotate_bilinear_adjoint(h, lib.bdof_grot(h), self.dim_x, self.dim_z, self.dim_y, self.prm_buf.ptr,
+                                                                self.mb, self.g.ptr, x0 * self.dim_z, nx * self.dim_z, int(accumulate), 1.0))
+            else:
+                self.ctx.check(lib.bdof_rotation_adjoint_rows(h, self.mb, self.angle_buf.ptr, self.g.ptr, x0 * self.dim_z,
+                                                              nx * self.dim_z, int(accumulate), 1.0))
         return produce
 
     def loss_and_grad(self, angle_idx, want_loss=True):
@@ -344,6 +386,9 @@ class FullfieldSolver(_VolumeSolver):
 
     def _dry_tail(self, n_slabs, sharded):
         self.angle_buf.upload(np.arange(self.mb, dtype=np.int32) % self.n_theta)
+        if self.bilinear:
+            prm = self.rot_prm[np.arange(self.mb) % self.n_theta]
+            self.prm_buf.upload(np.ascontiguousarray(prm))
         self._tail(self._produce(), 0, 0.0, n_slabs=n_slabs, sharded=sharded, flip=False)
 
     def step(self, i_batch, angle_idx, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, want_loss=False, n_slabs=None,
@@ -375,7 +420,11 @@ class FullfieldSolver(_VolumeSolver):
         out = []
         for i in range(0, len(idx), self.mb):
             chunk = idx[i:i + self.mb]
-            out.append(self.eng.forward(len(chunk), angle_idx=chunk, conv=self.conv))
+            if self.bilinear:
+                self._rotate_batch(chunk, len(chunk))
+                out.append(self.eng.forward(len(chunk), conv=self.conv))
+            else:
+                out.append(self.eng.forward(len(chunk), angle_idx=chunk, conv=self.conv))
         return np.concatenate(out, axis=0)
 
 

@@ -186,6 +186,17 @@ int bdof_rotation_adjoint(bdof_ctx* ctx, int B, const int* angle_of_b, void* gvo
 int bdof_rotation_adjoint_rows(bdof_ctx* ctx, int B, const int* angle_of_b, void* gvol, int row0, int n_rows, int accumulate,
                                float scale);
 
+/* Bilinear rotation — the TF twin's tf_rotate(obj, theta, interpolation='BILINEAR') (tensorflow_recon/fullfield.py:96; the cnn
+ * variant's nearest-neighbour tables are the fused path of bdof_set_object).  vol: device [NXv][NZv][NYv] pairs; prm: DEVICE
+ * float64 [B][4] = (cos, sin, x_off, y_off) of tf.contrib.image.angles_to_projective_transforms for images of height NXv and
+ * width NZv: output pixel (h, w) = (x, z) samples the input at (sin w + cos h + y_off, cos w - sin h + x_off), zeros outside.
+ * out_rows: device [B][NZv][NXv][NYv] pairs — hand it to bdof_set_object(out_rows, B*NZv*NXv, NYv, NULL, 0, 0) as a batch of
+ * already rotated objects.  The adjoint takes the rotated-frame gradient bdof_grot() back to volume rows [row0, row0+n_rows)
+ * of gvol (deterministic gather; same slab interface as bdof_rotation_adjoint_rows). */
+int bdof_rotate_bilinear(bdof_ctx* ctx, const void* vol, int NXv, int NZv, int NYv, const double* prm, int B, void* out_rows);
+int bdof_rotate_bilinear_adjoint(bdof_ctx* ctx, const void* grot, int NXv, int NZv, int NYv, const double* prm, int B, void* gvol, int row0,
+                                 int n_rows, int accumulate, float scale);
+
 /* Ptychography: adjoint of rotate + zero-pad + per-position window (cnn_propagator/ptychography.py:32-34,42-73) for a
  * batch whose elements all use rotation angle `angle` and windows at (xoff[b], yoff[b]); gvol: device [n_dest][volNY] pairs. */
 int bdof_window_rotation_adjoint(bdof_ctx* ctx, int B, int angle, const int* xoff, const int* yoff, void* gvol,

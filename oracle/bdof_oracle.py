@@ -560,3 +560,53 @@ def tiled_multislice_propagate(grid_delta, grid_beta, probe, energy_ev, psize_cm
                 new[y0 + halo:y0 + halo + ny_c, x0 + halo:x0 + halo + nx_c] = w[halo:halo + ny_c, halo:halo + nx_c]
         field = new
     return field
+
+
+# ---------------------------------------------------------------------------
+# Bilinear rotation of the TF twin                  tensorflow_recon/fullfield.py:96
+#   tf_rotate = tf.contrib.image.rotate (TensorFlow 1.x, un-vendored and absent here: no version is pinned anywhere in the
+#   reference; PARITY UNPINNED by execution).  Restated from its published definition: the (Y, X, Z, C) object is a batch of
+#   NHWC images of height H = X and width W = Z; angles_to_projective_transforms gives, for angle t,
+#       x_offset = ((W-1) - (cos t (W-1) - sin t (H-1))) / 2 ,  y_offset = ((H-1) - (sin t (W-1) + cos t (H-1))) / 2
+#   and the OUTPUT pixel (h, w) takes the input at (h', w') = (sin t w + cos t h + y_offset, cos t w - sin t h + x_offset),
+#   bilinearly, every tap outside the image reading 0.  Cross-checked against scipy.ndimage.map_coordinates(order=1).
+# ---------------------------------------------------------------------------
+def rotate_bilinear_params(theta, height, width):
+    c, s = np.cos(theta), np.sin(theta)
+    x_off = ((width - 1) - (c * (width - 1) - s * (height - 1))) / 2.0
+    y_off = ((height - 1) - (s * (width - 1) + c * (height - 1))) / 2.0
+    return c, s, x_off, y_off
+
+
+def _bilinear_taps(theta, height, width):
+    c, s, x_off, y_off = rotate_bilinear_params(theta, height, width)
+    hh, ww = np.mgrid[:height, :width].astype(np.float64)
+    sw = c * ww - s * hh + x_off
+    sh = s * ww + c * hh + y_off
+    fw, fh = np.floor(sw), np.floor(sh)
+    aw, ah = sw - fw, sh - fh
+    taps = []
+    for dh, dw, wt in ((0, 0, (1 - ah) * (1 - aw)), (0, 1, (1 - ah) * aw), (1, 0, ah * (1 - aw)), (1, 1, ah * aw)):
+        h2, w2 = fh.astype(int) + dh, fw.astype(int) + dw
+        inside = (h2 >= 0) & (h2 < height) & (w2 >= 0) & (w2 < width)
+        taps.append((np.where(inside, h2, 0), np.where(inside, w2, 0), np.where(inside, wt, 0.0)))
+    return taps
+
+
+def rotate_bilinear(obj, theta):
+    """obj (Y, X, Z, C) -> rotated (Y, X, Z, C)."""
+    Y, H, W = obj.shape[:3]
+    out = np.zeros_like(obj, dtype=np.float64)
+    for h2, w2, wt in _bilinear_taps(theta, H, W):
+        out += wt[None, :, :, None] * obj[:, h2, w2]
+    return out
+
+
+def rotate_bilinear_adjoint(g_rot, theta):
+    """Adjoint of rotate_bilinear: scatter-add of the rotated-frame gradient with the same weights."""
+    Y, H, W = g_rot.shape[:3]
+    out = np.zeros_like(g_rot, dtype=np.float64)
+    for h2, w2, wt in _bilinear_taps(theta, H, W):
+        contrib = wt[None, :, :, None] * g_rot
+        np.add.at(out, (slice(None), h2, w2), contrib)
+    return out
