@@ -1990,6 +1990,8 @@ int bdof_comm_unique_id(void* id, size_t bytes) {
 
 const char* bdof_comm_last_error(const bdof_comm* m) { return m ? m->err.c_str() : g_rccl.err.c_str(); }
 
+void bdof_comm_destroy(bdof_comm* m);
+
 int bdof_comm_create(bdof_comm** out, int device, int nranks, int rank, const void* id, size_t bytes) {
     if (!out || !id || bytes < sizeof(ncclUniqueId) || nranks < 1 || rank < 0 || rank >= nranks) return BDOF_ERR_ARG;
     *out = nullptr;
@@ -2000,13 +2002,14 @@ int bdof_comm_create(bdof_comm** out, int device, int nranks, int rank, const vo
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming);
     for (int i = 0; e == hipSuccess && i < BDOF_COMM_TICKETS; ++i) e = hipEventCreateWithFlags(&m->ticket[i], hipEventDisableTiming);
-    if (e != hipSuccess) { g_rccl.err = std::string("bdof_comm_create: ") + hipGetErrorString(e); delete m; return (int)e; }
+    if (e != hipSuccess) { g_rccl.err = std::string("bdof_comm_create: ") + hipGetErrorString(e); bdof_comm_destroy(m); return (int)e; }
     ncclUniqueId u;
     std::memcpy(&u, id, sizeof(u));
     ncclResult_t r = g_rccl.CommInitRank(&m->comm, nranks, u, rank);
     if (r != ncclSuccess) {
         g_rccl.err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r);
-        delete m;
+        m->comm = nullptr;
+        bdof_comm_destroy(m);                  // releases the stream and the events created above
         return 1000 + (int)r;
     }
     *out = m;
