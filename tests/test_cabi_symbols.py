@@ -62,3 +62,19 @@ def test_c_example_compiles_and_links(tmp_path):
                            '-L', os.path.join(root, 'beyond_dof_amd'), '-lbdof', '-Wl,-rpath,' + os.path.join(root, 'beyond_dof_amd')])
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert r.returncode == 1 and b'usage' in r.stderr
+
+
+def test_bench_self_launch_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` on a host without a GPU: the parent starts two ranks, they rendezvous, find no device and raise
+    (no CPU fallback); the parent reports the failure promptly, prints no JSON line and leaves no rank behind."""
+    import subprocess
+    import sys
+    lib = _lib.load()
+    if lib.bdof_device_count() > 0:
+        pytest.skip('a GPU is present')
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '64', '--angles-per-gpu', '2', '--n-theta', '4',
+                        '--steps', '1', '--warmup', '0', '--no-cpu-baseline'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0
+    assert b'no CPU fallback' in r.stderr
+    assert r.stdout.strip() == b''
