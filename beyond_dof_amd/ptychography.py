@@ -134,6 +134,15 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
                               coord_ls=coord_ls, propagator=propagator, kernel_size=kwargs.get('kernel_size', 17))
         solver.set_volume(obj_delta, obj_beta)
         solver.tune_tail()
+        # the diffraction amplitudes stay on the device when they fit (ptychography.py:295 reads them from the file per step)
+        resident = int(np.prod(prj.shape)) * 4 <= int(kwargs.get('resident_data_bytes', 16 << 30))
+        if resident:
+            dat = np.abs(np.asarray(prj[...]))
+            dat = dat[prj_theta_ind]
+            if ds_level > 1:
+                dat = dat[:, :, ::ds_level, ::ds_level]
+            solver.set_measurements(dat)
+            del dat
         if probe_type == 'optimizable':          # tensorflow_recon/ptychography.py: the probe is a variable with its own Adam
             solver.enable_probe_optimization(probe_real, probe_imag, probe_learning_rate, pupil_function)
         print_flush('Optimizer started.', 0, rank)
@@ -154,9 +163,11 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
                 this_ind_batch = ind_list_rand[i_batch]
                 this_i_theta = this_ind_batch[rank * minibatch_size, 0]
                 this_ind_rank = np.sort(this_ind_batch[rank * minibatch_size:(rank + 1) * minibatch_size, 1])
-                this_prj_batch = np.abs(prj[int(prj_theta_ind[this_i_theta]), this_ind_rank.tolist()])
-                if ds_level > 1:
-                    this_prj_batch = this_prj_batch[:, ::ds_level, ::ds_level]
+                this_prj_batch = None
+                if not resident:
+                    this_prj_batch = np.abs(prj[int(prj_theta_ind[this_i_theta]), this_ind_rank.tolist()])
+                    if ds_level > 1:
+                        this_prj_batch = this_prj_batch[:, ::ds_level, ::ds_level]
                 # loss_grad -> Allreduce -> /size -> Adam -> clip (ptychography.py:301-310): one pipelined device step
                 solver.step(i_batch, this_i_theta, this_ind_rank, this_prj_batch, learning_rate)
                 if save_intermediate and rank == 0:

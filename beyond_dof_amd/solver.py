@@ -460,20 +460,37 @@ class PtychoSolver(_VolumeSolver):
         self.order = DeviceBuffer.from_host(self.ctx, order)
         self._init_volume()
         self.meas_stage = DeviceBuffer(self.ctx, self.mb * self.py * self.px * 4, np.float32, (self.mb, self.py, self.px))
-        self.idx_buf = DeviceBuffer(self.ctx, 3 * self.mb * 4, np.int32, (3, self.mb))
+        self.idx_buf = DeviceBuffer(self.ctx, 4 * self.mb * 4, np.int32, (4, self.mb))
         self._bind_volume()
         self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
         self._last = None
 
+    def set_measurements(self, prj_abs_all):
+        """All diffraction amplitudes |prj| (n_theta, n_pos, py, px) resident on the device (a cfg5-sized dataset is 0.75 GB):
+        the minibatch is then picked out by one gather launch instead of an HDF5 read + upload per step
+        (this_prj_batch = prj[this_i_theta, this_ind_batch], ptychography.py:295)."""
+        a = np.asarray(prj_abs_all)
+        self.n_pos_all = a.shape[1]
+        self.meas_all = DeviceBuffer.from_host(self.ctx, self.eng.meas_layout(a.reshape((-1,) + a.shape[2:])))
+
     def _stage(self, i_theta, pos_idx, prj_abs_batch):
         pos = self.probe_pos[np.asarray(pos_idx)]
-        idx = np.empty((3, self.mb), dtype=np.int32)
+        idx = np.empty((4, self.mb), dtype=np.int32)
         idx[0] = i_theta
         idx[1] = pos[:, 1] - self.half[1]            # window origin in x (axis 1), ptychography.py:68-70
         idx[2] = pos[:, 0] - self.half[0]            # window origin in y (axis 0)
-        self.idx_buf.upload(idx)
-        self.meas_stage.upload(self.eng.meas_layout(prj_abs_batch))
+        idx[3] = 0
         p = self.idx_buf.ptr
+        if prj_abs_batch is None:
+            if getattr(self, 'meas_all', None) is None:
+                raise ValueError('no measurements: pass prj_abs_batch or call set_measurements first')
+            idx[3] = int(i_theta) * self.n_pos_all + np.asarray(pos_idx)
+            self.idx_buf.upload(idx)
+            self.ctx.check(self.ctx.lib.bdof_gather_fields(self.ctx.handle, self.meas_stage.ptr, self.meas_all.ptr, p + 12 * self.mb, self.mb,
+                                                           self.py * self.px * 4))
+        else:
+            self.idx_buf.upload(idx)
+            self.meas_stage.upload(self.eng.meas_layout(prj_abs_batch))
         return p, p + 4 * self.mb, p + 8 * self.mb
 
     def _win_loss_grad(self, i_theta, pos_idx, prj_abs_batch):
@@ -488,8 +505,9 @@ class PtychoSolver(_VolumeSolver):
         i_theta, xo, yo = self._last
         self.ctx.check(lib.bdof_window_rotation_adjoint(h, self.mb, i_theta, xo, yo, self.g.ptr, 0, 1.0))
 
-    def loss_and_grad(self, i_theta, pos_idx, prj_abs_batch, want_loss=True):
-        """prj_abs_batch: |this_prj_batch| (mb, py, px) for probe positions pos_idx at angle i_theta."""
+    def loss_and_grad(self, i_theta, pos_idx, prj_abs_batch=None, want_loss=True):
+        """prj_abs_batch: |this_prj_batch| (mb, py, px) for probe positions pos_idx at angle i_theta (None: from the resident
+        stack of set_measurements)."""
         self._win_loss_grad(i_theta, pos_idx, prj_abs_batch)
         self._produce_all()
         return self._get_loss() if want_loss else None
@@ -497,7 +515,7 @@ class PtychoSolver(_VolumeSolver):
     def _dry_tail(self, n_slabs, sharded):
         self._tail(lambda x0, nx: None, 0, 0.0, n_slabs=n_slabs, sharded=sharded, flip=False, use_mask=False)
 
-    def step(self, i_batch, i_theta, pos_idx, prj_abs_batch, learning_rate, want_loss=False, n_slabs=None, sharded=None, clip=True):
+    def step(self, i_batch, i_theta, pos_idx, prj_abs_batch=None, learning_rate=1.0, want_loss=False, n_slabs=None, sharded=None, clip=True):
         """One Adam iteration of ptychography.py:301-310: loss_grad, Allreduce, /size, Adam, clip (no regulariser, no mask).
         The window/rotation adjoint produces the whole volume gradient in one pass; exchange and Adam are still slab-wise."""
         self._win_loss_grad(i_theta, pos_idx, prj_abs_batch)

@@ -116,3 +116,22 @@ def test_reconstruct_ptychography_end_to_end(tmp_path, monkeypatch):
     # schedule shape: every theta's list is padded to a multiple of the minibatch (quirk Q10)
     sched = epoch_schedule(3, 12, 5, np.random.RandomState(0))
     assert len(sched) == 3 * 15 and all(len(set(sched[i * 15:(i + 1) * 15, 0])) == 1 for i in range(3))
+
+
+def test_resident_measurements_equal_per_step_upload():
+    """PtychoSolver.set_measurements + step(prj_abs_batch=None): the minibatch picked out of the device-resident stack by one
+    gather launch gives the very same volume as uploading it per step."""
+    from beyond_dof_amd.solver import PtychoSolver
+    rng, n, n_theta, psz, pos, od, ob, coords, prr, pii = _setup((64, 64))
+    meas = np.abs(rng.normal(1.0, 0.1, size=(n_theta, len(pos)) + psz)) * 30
+    vols = []
+    for resident in (False, True):
+        s = PtychoSolver((n, n, n), psz, pos, n_theta, 6, 5000., 1e-7, prr, pii, coord_ls=coords)
+        s.set_volume(od, ob)
+        if resident:
+            s.set_measurements(meas)
+        s.reset_moments()
+        for i, (i_theta, sel) in enumerate(((2, np.array([0, 3, 5, 6, 10, 11])), (4, np.array([1, 2, 4, 7, 8, 9])))):
+            s.step(i, i_theta, sel, None if resident else meas[i_theta, sel], 1e-7)
+        vols.append(s.get_volume())
+    assert np.array_equal(vols[0][0], vols[1][0]) and np.array_equal(vols[0][1], vols[1][1])

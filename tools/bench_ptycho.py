@@ -27,15 +27,15 @@ coords = util.rotation_lookup([n, n, n], n_theta)
 s = PtychoSolver([n, n, n], [ps, ps], pos, n_theta, mb, 5000., 1e-7, pr, pi, coord_ls=coords)
 d = rng.random((n, n, n), dtype=np.float32) * 1e-6
 s.set_volume(d, 0.1 * d)
-meas = np.abs(rng.normal(1.0, 0.1, size=(mb, ps, ps))).astype(np.float32) * ps
+meas = np.abs(rng.normal(1.0, 0.1, size=(n_theta, mb, ps, ps))).astype(np.float32) * ps
+s.set_measurements(meas)               # the amplitudes of all angles resident in HBM (inputs resident when the timed region starts)
 print('setup %.1f s' % (time.time() - t0), flush=True)
 s.reset_moments()
 for it in range(1 + steps):
     if it == 1:
         s.ctx.sync()
         t0 = time.perf_counter()
-    s.loss_and_grad(it % n_theta, np.arange(mb), meas, want_loss=False)
-    s.adam_update(it, 1e-7)
+    s.step(it, it % n_theta, np.arange(mb), None, 1e-7)       # what reconstruct_ptychography runs per minibatch
 s.ctx.sync()
 dt = (time.perf_counter() - t0) / steps
 px = ps * ps
