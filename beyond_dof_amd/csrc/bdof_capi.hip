@@ -1,5 +1,6 @@
 // libbdof.so — host side of the C ABI declared in include/bdof.h.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cmath>
 #include <algorithm>
 #include <complex>
@@ -157,8 +158,9 @@ struct ProfScope {
     bdof_ctx* c;
     int cls;
     bool on;
+    bool ext;             // the launch itself carries the events (BDOF_LAUNCH -> hipExtLaunchKernelGGL): nothing is recorded here
     size_t idx = 0;
-    ProfScope(bdof_ctx* c_, int cls_) : c(c_), cls(cls_), on(c_->prof) {
+    ProfScope(bdof_ctx* c_, int cls_, bool ext_ = false) : c(c_), cls(cls_), on(c_->prof), ext(ext_) {
         if (on && c->prof_stride > 1 && cls <= BDOF_K_ROW_BWD) on = (c->prof_seen[cls]++ % (unsigned)c->prof_stride) == 0;
         if (!on) return;
         if (c->ev_next + 2 > c->ev_pool.size()) {
@@ -168,14 +170,24 @@ struct ProfScope {
         }
         idx = c->ev_next;
         c->ev_next += 2;
-        (void)hipEventRecord(c->ev_pool[idx], c->sub_stream ? c->sub_stream : c->stream);
+        if (!ext) (void)hipEventRecord(c->ev_pool[idx], c->sub_stream ? c->sub_stream : c->stream);
     }
+    hipEvent_t e0() const { return c->ev_pool[idx]; }
+    hipEvent_t e1() const { return c->ev_pool[idx + 1]; }
     ~ProfScope() {
         if (!on) return;
-        (void)hipEventRecord(c->ev_pool[idx + 1], c->sub_stream ? c->sub_stream : c->stream);
+        if (!ext) (void)hipEventRecord(c->ev_pool[idx + 1], c->sub_stream ? c->sub_stream : c->stream);
         c->ev_used.emplace_back(cls, (int)idx);
     }
 };
+// A timed launch of the per-slice kernel classes: hipExtLaunchKernelGGL stamps the two events with the dispatch's own begin
+// and end (what rocprofv3 reports), where an event pair recorded around the launch also contains the ~2.5 us between the
+// start marker and the first wave.
+#define BDOF_LAUNCH(ps, kernel, grid, blk, shmem, stream, ...)                                                     \
+    do {                                                                                                           \
+        if ((ps).on) hipExtLaunchKernelGGL(kernel, grid, blk, shmem, stream, (ps).e0(), (ps).e1(), 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, blk, shmem, stream, __VA_ARGS__);                                    \
+    } while (0)
 
 static void prof_collect(bdof_ctx* c) {
     for (auto& u : c->ev_used) {
@@ -324,7 +336,7 @@ static const cf* slice_carrier_field(const bdof_ctx* c, int z) { return c->pstac
 // start != nullptr: slice z starts from the real-space fields start[b] (scattered part) instead of the hybrid `in` — the
 // first slice of a range (bdof_forward_range); z == 0 without `start` starts from the probe shared by the batch.
 static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore, cf* phi_out = nullptr, const cf* start = nullptr) {
-    ProfScope ps(c, BDOF_K_ROW_FWD);
+    ProfScope ps(c, BDOF_K_ROW_FWD, true);
     RowFwdArgs a{sub_field(c, in), start ? sub_field(c, start) : c->probe, sub_field(c, out), sub_field(c, phi_out), sub_obj(c), B, c->NX, z,
                  c->k, carrier_at(c, z), c->twY, slice_carrier_field(c, z), cshift_at(c, z), 0, 1.f, start ? 1 : 0};
     const bool pf = a.pz != nullptr;
@@ -333,41 +345,41 @@ static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, boo
         const dim3 blk(BDOF_THREADS);
         if (z == 0 || start) {
             if (pf) {
-                if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, true, true, true>), grid, blk, 0, c->sub_stream, a);
-                else hipLaunchKernelGGL((k_row_fwd<N_, true, false, true>), grid, blk, 0, c->sub_stream, a);
+                if (tstore) BDOF_LAUNCH(ps, (k_row_fwd<N_, true, true, true>), grid, blk, 0, c->sub_stream, a);
+                else BDOF_LAUNCH(ps, (k_row_fwd<N_, true, false, true>), grid, blk, 0, c->sub_stream, a);
             } else {
-                if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, true, true>), grid, blk, 0, c->sub_stream, a);
-                else hipLaunchKernelGGL((k_row_fwd<N_, true, false>), grid, blk, 0, c->sub_stream, a);
+                if (tstore) BDOF_LAUNCH(ps, (k_row_fwd<N_, true, true>), grid, blk, 0, c->sub_stream, a);
+                else BDOF_LAUNCH(ps, (k_row_fwd<N_, true, false>), grid, blk, 0, c->sub_stream, a);
             }
         } else if (pf) {
-            if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, false, true, true>), grid, blk, 0, c->sub_stream, a);
-            else hipLaunchKernelGGL((k_row_fwd<N_, false, false, true>), grid, blk, 0, c->sub_stream, a);
+            if (tstore) BDOF_LAUNCH(ps, (k_row_fwd<N_, false, true, true>), grid, blk, 0, c->sub_stream, a);
+            else BDOF_LAUNCH(ps, (k_row_fwd<N_, false, false, true>), grid, blk, 0, c->sub_stream, a);
         } else {
-            if (tstore) hipLaunchKernelGGL((k_row_fwd<N_, false, true>), grid, blk, 0, c->sub_stream, a);
-            else hipLaunchKernelGGL((k_row_fwd<N_, false, false>), grid, blk, 0, c->sub_stream, a);
+            if (tstore) BDOF_LAUNCH(ps, (k_row_fwd<N_, false, true>), grid, blk, 0, c->sub_stream, a);
+            else BDOF_LAUNCH(ps, (k_row_fwd<N_, false, false>), grid, blk, 0, c->sub_stream, a);
         }
     });
 }
 
 // A_z^-1 (tape-free adjoint): scattered part of phi_z (L1 hybrid, or real space) -> R eps(psi_z) in L2
 static void launch_row_unmod(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool real_in, float in_scale) {
-    ProfScope ps(c, BDOF_K_ROW_FWD);
+    ProfScope ps(c, BDOF_K_ROW_FWD, true);
     RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), nullptr, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
                  slice_carrier_field(c, z), cshift_at(c, z), real_in ? 1 : 0, in_scale, 0};
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
-        if (a.pz) hipLaunchKernelGGL((k_row_fwd<N_, false, true, true, true>), grid, blk, 0, c->sub_stream, a);
-        else hipLaunchKernelGGL((k_row_fwd<N_, false, true, false, true>), grid, blk, 0, c->sub_stream, a);
+        if (a.pz) BDOF_LAUNCH(ps, (k_row_fwd<N_, false, true, true, true>), grid, blk, 0, c->sub_stream, a);
+        else BDOF_LAUNCH(ps, (k_row_fwd<N_, false, true, false, true>), grid, blk, 0, c->sub_stream, a);
     });
 }
 
 // B: L2 -> L1
 static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf* h, float scale, int conj_h) {
-    ProfScope ps(c, BDOF_K_COL_PROP);
+    ProfScope ps(c, BDOF_K_COL_PROP, true);
     RowPropArgs a{sub_field(c, in), sub_field(c, out), h, B, c->NY, scale, conj_h, c->twX};
     DISPATCH_N(c->NX, {
-        hipLaunchKernelGGL((k_row_prop<N_>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
+        BDOF_LAUNCH(ps, (k_row_prop<N_>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
     });
 }
 
@@ -380,7 +392,7 @@ struct GradTarget {            // where A'_z leaves the gradient rows / G(psi_z)
 };
 static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* tape, cf* gout, int hist = 0, float tape_scale = 1.f,
                            const GradTarget* gt = nullptr) {
-    ProfScope ps(c, BDOF_K_ROW_BWD);
+    ProfScope ps(c, BDOF_K_ROW_BWD, true);
     float2* grot = gt && gt->grot ? gt->grot + (size_t)c->sub_b0 * gt->S_ * c->NX * c->NY : c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY;
     RowBwdArgs a{sub_field(c, gin), hist == 2 ? c->probe : sub_field(c, tape), sub_field(c, gout),
                  grot, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
@@ -392,20 +404,20 @@ static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* t
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
         if (a.ac.gcar) {         // far field + plane-wave carrier (never together with a carrier field)
-            if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0, false, true>), grid, blk, 0, c->sub_stream, a);
-            else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1, false, true>), grid, blk, 0, c->sub_stream, a);
-            else if (hist == 2) hipLaunchKernelGGL((k_row_bwd<N_, 2, false, true>), grid, blk, 0, c->sub_stream, a);
-            else hipLaunchKernelGGL((k_row_bwd<N_, 3, false, true>), grid, blk, 0, c->sub_stream, a);
+            if (hist == 0) BDOF_LAUNCH(ps, (k_row_bwd<N_, 0, false, true>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 1) BDOF_LAUNCH(ps, (k_row_bwd<N_, 1, false, true>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 2) BDOF_LAUNCH(ps, (k_row_bwd<N_, 2, false, true>), grid, blk, 0, c->sub_stream, a);
+            else BDOF_LAUNCH(ps, (k_row_bwd<N_, 3, false, true>), grid, blk, 0, c->sub_stream, a);
         } else if (pf) {
-            if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0, true>), grid, blk, 0, c->sub_stream, a);
-            else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1, true>), grid, blk, 0, c->sub_stream, a);
-            else if (hist == 2) hipLaunchKernelGGL((k_row_bwd<N_, 2, true>), grid, blk, 0, c->sub_stream, a);
-            else hipLaunchKernelGGL((k_row_bwd<N_, 3, true>), grid, blk, 0, c->sub_stream, a);
+            if (hist == 0) BDOF_LAUNCH(ps, (k_row_bwd<N_, 0, true>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 1) BDOF_LAUNCH(ps, (k_row_bwd<N_, 1, true>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 2) BDOF_LAUNCH(ps, (k_row_bwd<N_, 2, true>), grid, blk, 0, c->sub_stream, a);
+            else BDOF_LAUNCH(ps, (k_row_bwd<N_, 3, true>), grid, blk, 0, c->sub_stream, a);
         } else {
-            if (hist == 0) hipLaunchKernelGGL((k_row_bwd<N_, 0>), grid, blk, 0, c->sub_stream, a);
-            else if (hist == 1) hipLaunchKernelGGL((k_row_bwd<N_, 1>), grid, blk, 0, c->sub_stream, a);
-            else if (hist == 2) hipLaunchKernelGGL((k_row_bwd<N_, 2>), grid, blk, 0, c->sub_stream, a);
-            else hipLaunchKernelGGL((k_row_bwd<N_, 3>), grid, blk, 0, c->sub_stream, a);
+            if (hist == 0) BDOF_LAUNCH(ps, (k_row_bwd<N_, 0>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 1) BDOF_LAUNCH(ps, (k_row_bwd<N_, 1>), grid, blk, 0, c->sub_stream, a);
+            else if (hist == 2) BDOF_LAUNCH(ps, (k_row_bwd<N_, 2>), grid, blk, 0, c->sub_stream, a);
+            else BDOF_LAUNCH(ps, (k_row_bwd<N_, 3>), grid, blk, 0, c->sub_stream, a);
         }
     });
 }
