@@ -58,6 +58,7 @@ struct bdof_ctx {
     // real-space truncated-kernel propagator (bdof_set_conv)
     bool have_conv = false;
     ConvTaps taps{};
+    ConvTaps* taps_dev = nullptr;
     std::complex<double> ksum{1.0, 0.0};
     float k_conv = 0.f;
     cf *bufC = nullptr, *conv_scal = nullptr;
@@ -785,12 +786,13 @@ static void free_generic(bdof_ctx* c) {
 
 static void free_workspace(bdof_ctx* c) {
     free_generic(c);
-    void* ptrs[] = {c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->gpsi0, c->partial, c->loss_dev};
+    void* ptrs[] = {c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->taps_dev, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->gpsi0, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
     c->pstack = c->pdet = c->pdetT = nullptr;
     c->resident = false;
     c->bufC = c->conv_scal = nullptr;
+    c->taps_dev = nullptr;
     c->have_conv = false;
     c->twY = c->twX = c->hs = c->hdet = c->hcomb = c->probe = c->bufA = c->bufB = c->tape = nullptr;
     c->grot = nullptr;
@@ -1503,6 +1505,9 @@ int bdof_set_conv(bdof_ctx* c, const float* ky, const float* kx, int ks, double 
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     if (!c->bufC) HIPC(c, hipMalloc((void**)&c->bufC, sizeof(cf) * fld));
     if (!c->conv_scal) HIPC(c, hipMalloc((void**)&c->conv_scal, sizeof(cf) * 4));
+    if (!c->taps_dev) HIPC(c, hipMalloc((void**)&c->taps_dev, sizeof(ConvTaps)));
+    HIPC(c, hipStreamSynchronize(c->stream));                  // a sweep still in flight reads the previous taps
+    HIPC(c, hipMemcpy(c->taps_dev, &c->taps, sizeof(ConvTaps), hipMemcpyHostToDevice));
     c->have_conv = true;
     c->mod_dirty = true;
     return 0;
@@ -1563,7 +1568,7 @@ static int conv_forward_sweep(bdof_ctx* c, int B, bool tape) {
         const bool last = z == c->S - 1;
         cf* out = last ? c->bufB : (tape ? c->tape + (size_t)(z + 1) * fld : (cur == c->bufA ? c->bufC : c->bufA));
         ConvArgs a{cur, out, nullptr, nullptr, obj, B, c->NX, c->NY, last ? -1 : z + 1, conv_pad(c, z), conv_carrier(c, z + 1),
-                   c->k_conv, c->taps};
+                   c->k_conv, c->taps_dev, c->taps.ks};
         if ((r = launch_conv<false>(c, a))) return r;
         cur = out;
     }
@@ -1672,7 +1677,7 @@ int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xo
     cf* gcur = gp;
     for (int z = c->S - 1; z >= 0; --z) {
         cf* gout = gcur == c->bufB ? c->bufA : c->bufB;
-        ConvArgs a{gcur, gout, c->tape + (size_t)z * fld, c->grot, obj, B, c->NX, c->NY, z, zero, conv_carrier(c, z), c->k_conv, c->taps};
+        ConvArgs a{gcur, gout, c->tape + (size_t)z * fld, c->grot, obj, B, c->NX, c->NY, z, zero, conv_carrier(c, z), c->k_conv, c->taps_dev, c->taps.ks};
         if ((r = launch_conv<true>(c, a))) return r;
         gcur = gout;
     }

@@ -1351,29 +1351,35 @@ struct ConvArgs {
     cf pad;              // forward: padding constant of the eps field (0 in backward)
     cf carrier;          // forward: a_{z+1} ; backward: a_z
     float k;
-    ConvTaps taps;
+    const ConvTaps* taps;   // device copy (bdof_set_conv): read through the scalar cache one pass at a time — by value in the
+    int ks;                 // kernel arguments all 134 dwords are fetched at entry and live in spilled SGPRs (v_readlane per use)
 };
 
 // 1-D pass over a register window: thread owns R consecutive outputs and the R + 2H inputs they need, so every LDS
 // value is read once per R outputs instead of once per tap.
+typedef float conv_v2f __attribute__((ext_vector_type(2)));
 template <bool BWD, int H, int R>
-__device__ __forceinline__ void conv_window(const cf (&win)[R + 2 * H], const float2* taps, cf (&out)[R]) {
+__device__ __forceinline__ void conv_window(const cf (&win)[R + 2 * H], const __attribute__((address_space(4))) float2* taps, cf (&out)[R]) {
+    conv_v2f acc[R];
 #pragma unroll
-    for (int o = 0; o < R; ++o) out[o] = make_float2(0.f, 0.f);
+    for (int o = 0; o < R; ++o) acc[o] = (conv_v2f){0.f, 0.f};
 #pragma unroll
     for (int d = -H; d <= H; ++d) {
-        const cf w = taps[H + d];
+        const cf w = make_float2(taps[H + d].x, taps[H + d].y);
+        // complex multiply-accumulate as two packed FMAs (v_pk_fma_f32: 2 x the rate of v_fma_f32): the splat of f.x / f.y,
+        // the swap of the tap's halves and the signs all fold into op_sel / neg modifiers, the tap sits in an SGPR pair.
+        // backward: multiply by conj(w).  Same operation order as four scalar FMAs, so the results are bit-identical.
+        const conv_v2f w1 = BWD ? (conv_v2f){w.x, -w.y} : (conv_v2f){w.x, w.y};
+        const conv_v2f w2 = BWD ? (conv_v2f){w.y, w.x} : (conv_v2f){-w.y, w.x};
 #pragma unroll
         for (int o = 0; o < R; ++o) {
-            // complex multiply-accumulate as four FMAs (cadd(out, cmul(f, w)) compiles to mul + fma + add per component)
             const cf f = win[o + H + (BWD ? d : -d)];
-            const float wy = BWD ? -w.y : w.y;                   // backward: multiply by conj(w)
-            out[o].x = fmaf(f.x, w.x, out[o].x);
-            out[o].x = fmaf(-f.y, wy, out[o].x);
-            out[o].y = fmaf(f.x, wy, out[o].y);
-            out[o].y = fmaf(f.y, w.x, out[o].y);
+            acc[o] = __builtin_elementwise_fma((conv_v2f){f.x, f.x}, w1, acc[o]);
+            acc[o] = __builtin_elementwise_fma((conv_v2f){f.y, f.y}, w2, acc[o]);
         }
     }
+#pragma unroll
+    for (int o = 0; o < R; ++o) out[o] = make_float2(acc[o].x, acc[o].y);
 }
 
 // workgroup barrier that orders LDS traffic only (see res_sync in bdof_resident.h)
@@ -1385,8 +1391,9 @@ template <bool BWD, int H>
 __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
     // R outputs per thread in the y pass (384 windows per tile), R2 in the x pass (512 windows: every thread busy)
     constexpr int TX = BDOF_CONV_TX, TY = BDOF_CONV_TY, R = 8, R2 = 4;
-    const int h = H > 0 ? H : (a.taps.ks - 1) / 2;
+    const int h = H > 0 ? H : (a.ks - 1) / 2;
     const int TXH = TX + 2 * h, TYH = TY + 2 * h;
+    typedef const __attribute__((address_space(4))) ConvTaps* TapsPtr;      // constant address space: s_load, no VGPRs
     // odd row strides: pass 1 runs with consecutive lanes on consecutive ROWS (each lane slides its own window along y),
     // so the row stride in 8-byte slots must be odd for those lanes to hit distinct LDS banks
     const int SA = TYH | 1, SM = TY + 1;
@@ -1402,34 +1409,40 @@ __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
     constexpr int NLD = (BDOF_CONV_MAXK - 1 + BDOF_CONV_TX) * (BDOF_CONV_MAXK - 1 + BDOF_CONV_TY) / BDOF_CONV_THREADS + 1;
     constexpr int NPF = H > 0 ? ((TX + 2 * H) * (TY + 2 * H) + BDOF_CONV_THREADS - 1) / BDOF_CONV_THREADS : NLD;
     cf nx[NPF];
-    auto fetch = [&](int tile, cf (&v)[NPF]) {
+    // per-thread offsets stay 32-bit (one wavefield is < 2^31 elements); the wavefield's base is a scalar: 64-bit
+    // multiplies (v_mad_u64_u32) are quarter rate and this kernel is bound by VALU issue
+    // returns the mask of the elements that lie inside the field (the others take the padding constant at stash time,
+    // so that the loads themselves are unconditional and all in flight together)
+    auto fetch = [&](int tile, cf (&v)[NPF]) -> unsigned {
         const int b = tile / (tiles_x * tiles_y);
         const int t2 = tile - b * tiles_x * tiles_y;
         const int x0 = (t2 / tiles_y) * TX, y0 = (t2 % tiles_y) * TY;
         const cf* src = a.in + (size_t)b * a.NX * a.NY;
+        unsigned inside = 0;
 #pragma unroll
         for (int q = 0; q < NPF; ++q) {
             const int e = min((int)threadIdx.x + q * BDOF_CONV_THREADS, TXH * TYH - 1);
             const int i = e / TYH, j = e - i * TYH;
             const int x = x0 - h + i, y = y0 - h + j;
-            const bool in = x >= 0 && x < a.NX && y >= 0 && y < a.NY;
-            const cf val = src[(size_t)min(max(x, 0), a.NX - 1) * a.NY + min(max(y, 0), a.NY - 1)];
-            v[q] = in ? val : a.pad;
+            inside |= ((unsigned)x < (unsigned)a.NX && (unsigned)y < (unsigned)a.NY) ? 1u << q : 0u;
+            v[q] = src[__umul24(min(max(x, 0), a.NX - 1), a.NY) + min(max(y, 0), a.NY - 1)];      // NX, NY <= 4096: 24-bit multiply
         }
+        return inside;
     };
-    auto stash = [&](const cf (&v)[NPF]) {
+    auto stash = [&](const cf (&v)[NPF], unsigned inside) {
 #pragma unroll
         for (int q = 0; q < NPF; ++q) {
             const int e = (int)threadIdx.x + q * BDOF_CONV_THREADS;
             if (e < TXH * TYH) {
                 const int i = e / TYH, j = e - i * TYH;
-                A[i * SA + j] = v[q];
+                A[i * SA + j] = (inside >> q) & 1u ? v[q] : a.pad;
             }
         }
     };
+    unsigned nx_in = 0;
     if ((int)blockIdx.x < ntiles) {
-        fetch(blockIdx.x, nx);
-        stash(nx);
+        nx_in = fetch(blockIdx.x, nx);
+        stash(nx, nx_in);
     }
     conv_sync();
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1441,9 +1454,24 @@ __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
         const int y = y0 + j;
         const int yg = y + (a.obj.yoff ? a.obj.yoff[b] : 0);
         const int yc = min(max(yg, 0), a.obj.volNY - 1);
-        long long srow[R2];
+        // modulation-table row of each output row (obj_src_row, with the per-wavefield part as a scalar base)
+        int srow[R2];
+        {
+            const int xg0 = x0 + i0 + (a.obj.tab && a.obj.xoff ? a.obj.xoff[b] : 0);
+            const int* tabrow = a.obj.tab ? a.obj.tab + ((long long)a.obj.angle_of_b[b] * a.obj.S + max(a.zmod, 0)) * a.obj.volNX : nullptr;
+            const int base = a.obj.tab ? 0 : (b * a.obj.S + max(a.zmod, 0)) * a.NX;
 #pragma unroll
-        for (int q = 0; q < R2; ++q) srow[q] = a.zmod >= 0 ? obj_src_row(a.obj, b, x0 + i0 + q, a.zmod, a.NX) : -1;
+            for (int q = 0; q < R2; ++q) {
+                const int xg = xg0 + q;
+                if (a.zmod < 0) srow[q] = -1;
+                else if (tabrow) srow[q] = (unsigned)xg < (unsigned)a.obj.volNX ? tabrow[xg] : -1;
+                else srow[q] = base + xg;
+            }
+        }
+        // the taps are re-read per pass (scalar cache hits): laundering the pointer keeps the loads from being hoisted out
+        // of the tile loop, where 68 SGPRs of taps would not fit beside the rest
+        TapsPtr kt = (TapsPtr)a.taps;
+        asm volatile("" : "+s"(kt));
         // pass along y.  forward: o[y] = sum_d K[h+d] f[y-d] ; backward: o[y] = sum_d conj(K[h+d]) g[y+d]
         if constexpr (H > 0) {
             for (int t = threadIdx.x; t < TXH * (TY / R); t += blockDim.x) {
@@ -1451,7 +1479,7 @@ __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
                 cf win[R + 2 * H], o[R];
 #pragma unroll
                 for (int q = 0; q < R + 2 * H; ++q) win[q] = A[i * SA + j0 + q];
-                conv_window<BWD, H, R>(win, a.taps.ky, o);
+                conv_window<BWD, H, R>(win, kt->ky, o);
 #pragma unroll
                 for (int q = 0; q < R; ++q) M[i * SM + j0 + q] = o[q];
             }
@@ -1461,57 +1489,64 @@ __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
                 cf acc = make_float2(0.f, 0.f);
                 for (int d = -h; d <= h; ++d) {
                     const cf f = A[i * SA + jj + h + (BWD ? d : -d)];
-                    acc = cadd(acc, BWD ? cmulc(f, a.taps.ky[h + d]) : cmul(f, a.taps.ky[h + d]));
+                    const cf w = make_float2(kt->ky[h + d].x, kt->ky[h + d].y);
+                    acc = cadd(acc, BWD ? cmulc(f, w) : cmul(f, w));
                 }
                 M[i * SM + jj] = acc;
             }
         }
         float2 m1[R2];
         cf tp[R2];
+        const cf* tape_b = BWD ? a.tape + (size_t)b * a.NX * a.NY : nullptr;
 #pragma unroll
         for (int q = 0; q < R2; ++q) {
-            m1[q] = a.obj.vol[(size_t)(srow[q] >= 0 ? srow[q] : 0) * a.obj.volNY + yc];
-            if constexpr (BWD) tp[q] = a.tape[((size_t)b * a.NX + x0 + i0 + q) * a.NY + y];
+            m1[q] = a.obj.vol[(size_t)max(srow[q], 0) * a.obj.volNY + yc];
+            if constexpr (BWD) tp[q] = tape_b[__umul24(x0 + i0 + q, a.NY) + y];
         }
         conv_sync();
         const int next = tile + gridDim.x;
-        if (next < ntiles) fetch(next, nx);          // in flight during the x pass
+        if (next < ntiles) nx_in = fetch(next, nx);  // in flight during the x pass
         // pass along x (window of R2 consecutive x for one y), then the pointwise physics
+        asm volatile("" : "+s"(kt));
         {
             cf o[R2];
+            const cf ke = make_float2(kt->e.x, kt->e.y);
+            cf* out_b = a.out + (size_t)b * a.NX * a.NY;
+            float2* grot_b = BWD ? a.grot + ((size_t)b * a.obj.S + a.zmod) * a.NX * a.NY : nullptr;
             if constexpr (H > 0) {
                 cf win[R2 + 2 * H];
 #pragma unroll
                 for (int q = 0; q < R2 + 2 * H; ++q) win[q] = M[(i0 + q) * SM + j];
-                conv_window<BWD, H, R2>(win, a.taps.kx, o);
+                conv_window<BWD, H, R2>(win, kt->kx, o);
             } else {
                 for (int q = 0; q < R2; ++q) {
                     cf acc = make_float2(0.f, 0.f);
                     for (int d = -h; d <= h; ++d) {
                         const cf f = M[(i0 + q + h + (BWD ? d : -d)) * SM + j];
-                        acc = cadd(acc, BWD ? cmulc(f, a.taps.kx[h + d]) : cmul(f, a.taps.kx[h + d]));
+                        const cf w = make_float2(kt->kx[h + d].x, kt->kx[h + d].y);
+                        acc = cadd(acc, BWD ? cmulc(f, w) : cmul(f, w));
                     }
                     o[q] = acc;
                 }
             }
 #pragma unroll
             for (int q = 0; q < R2; ++q) {
-                const cf acc = BWD ? cmulc(o[q], a.taps.e) : cmul(o[q], a.taps.e);
+                const cf acc = BWD ? cmulc(o[q], ke) : cmul(o[q], ke);
                 const int x = x0 + i0 + q;
-                const size_t off = ((size_t)b * a.NX + x) * a.NY + y;
+                const unsigned off = __umul24(x, a.NY) + y;
                 const bool in = srow[q] >= 0 && yg == yc;
                 const float2 mm = make_float2(in ? m1[q].x : 0.f, in ? m1[q].y : 0.f);
                 if constexpr (!BWD) {
-                    a.out[off] = modulate_eps(acc, a.carrier, mm);          // phi_{z+1} = c_{z+1} psi_{z+1}  (eps part)
+                    out_b[off] = modulate_eps(acc, a.carrier, mm);          // phi_{z+1} = c_{z+1} psi_{z+1}  (eps part)
                 } else {
                     const cf phi = cadd(tp[q], a.carrier);
                     const cf tt = cmulc(acc, phi);                              // G(phi) conj(phi)
-                    a.grot[(((size_t)b * a.obj.S + a.zmod) * a.NX + x) * a.NY + y] = make_float2(a.k * tt.y, -a.k * tt.x);
-                    a.out[off] = cmulc(acc, make_float2(1.f + mm.x, mm.y));     // G(psi_z) = conj(c_z) G(phi_z)
+                    grot_b[off] = make_float2(a.k * tt.y, -a.k * tt.x);
+                    out_b[off] = cmulc(acc, make_float2(1.f + mm.x, mm.y));     // G(psi_z) = conj(c_z) G(phi_z)
                 }
             }
         }
-        if (next < ntiles) stash(nx);                // A was last read before the barrier above
+        if (next < ntiles) stash(nx, nx_in);         // A was last read before the barrier above
         conv_sync();
     }
 }
