@@ -334,7 +334,8 @@ class TorchComm(object):
         """Zero-copy torch view of a DeviceBuffer (or pass a tensor through)."""
         if isinstance(buf, self.torch.Tensor):
             return buf.view(-1)
-        return self.torch.as_tensor(buf, device='cuda:{}'.format(self.torch.cuda.current_device())).view(-1)
+        t = self.torch.as_tensor(buf, device='cuda:{}'.format(self.torch.cuda.current_device()))
+        return (self.torch.view_as_real(t) if t.is_complex() else t).view(-1)          # counts are in floats
 
     def _sync(self, ctx, t):
         if ctx is not None:

@@ -9,17 +9,23 @@ tile's own FFT is periodic, so errors enter at its edges and move inwards by at 
 steepest ray the grid carries); before they have crossed the halo the cores are stitched back into the field and the tiles
 re-cut with fresh halos (bdof_tiles_scatter / bdof_tiles_gather).  The tiles apply the FIELD's transfer function
 (util.get_kernel_tile), not that of a T-point mesh.
+
+Several GPUs (comm with size > 1): the tiles are dealt to the ranks round-robin; every rank keeps the whole field.  At a
+stitch a rank writes its own cores into a zeroed field and the fields are summed over the ranks (every pixel lies in
+exactly one core, so the sum only fills in); in the adjoint sweep the tapered scatter-add of the tiles and, at the end, the
+object gradient are summed the same way.  One all-reduce of FY x FX complex values per stitch and direction.
 """
 import numpy as np
 
 from . import _lib, util
 from ._lib import DeviceBuffer
+from .comm import PseudoComm
 from .engine import MultisliceEngine
 
 
 class TiledPropagator(object):
     def __init__(self, field_shape, n_slice, energy_ev, psize_cm, tile=512, halo=64, slices_per_exchange=None, safety=0.5,
-                 taper=None, variant='numpy_skip_last', device=0, pi=util.PI, with_grad=False):
+                 taper=None, variant='numpy_skip_last', device=0, pi=util.PI, with_grad=False, comm=None):
         """field_shape (FY, FX); tile: fused plan size (64 ... 1024); halo: pixels per side that are recomputed, not kept; its
         outer `taper` pixels (default halo / 2) are ramped to zero so that the tile's periodic boundary has no jump.
         slices_per_exchange: slices between two stitches; default safety * (halo - taper) / (lambda dz / (2 dx^2))."""
@@ -39,8 +45,14 @@ class TiledPropagator(object):
         # tile origins: cores tile the field, halos reach periodically across its edges
         ox = [i * self.core - self.halo for i in range(-(-self.fx // self.core))]
         oy = [i * self.core - self.halo for i in range(-(-self.fy // self.core))]
-        self.x0 = np.repeat(np.array(ox, dtype=np.int32), len(oy))
-        self.y0 = np.tile(np.array(oy, dtype=np.int32), len(ox))
+        x0 = np.repeat(np.array(ox, dtype=np.int32), len(oy))
+        y0 = np.tile(np.array(oy, dtype=np.int32), len(ox))
+        self.n_tiles_field = len(x0)
+        self.comm = comm if comm is not None else PseudoComm()
+        if self.comm.size > self.n_tiles_field:
+            raise ValueError('{} ranks for {} tiles'.format(self.comm.size, self.n_tiles_field))
+        self.x0 = np.ascontiguousarray(x0[self.comm.rank::self.comm.size])        # this rank's tiles
+        self.y0 = np.ascontiguousarray(y0[self.comm.rank::self.comm.size])
         self.n_tiles = len(self.x0)
         # gradient: tape-free range sweeps with a per-range gradient buffer (bdof_adjoint_range); the ctx holds no [B][S] workspace
         self.with_grad = bool(with_grad)
@@ -49,6 +61,7 @@ class TiledPropagator(object):
         self.eng = MultisliceEngine(self.tile, self.tile, self.n_slice, self.n_tiles, with_grad=self.with_grad, device=device,
                                     engine='streaming', recompute=self.with_grad, no_grot=self.with_grad)
         self.ctx, self.lib, self.h = self.eng.ctx, self.eng.lib, self.eng.h
+        self.comm.attach(self.ctx)
         self.eng.set_physics(energy_ev, psize_cm, None, variant=variant, pi=pi, field_shape=(self.fy, self.fx))
         self.eng.set_probe_none()
         self.idx = DeviceBuffer.from_host(self.ctx, np.stack([np.zeros(self.n_tiles, dtype=np.int32), self.x0, self.y0]))
@@ -89,8 +102,20 @@ class TiledPropagator(object):
                                                  self.taper))
             self.ctx.check(lib.bdof_forward_range(h, self.n_tiles, a, xo, yo, z0, nz, self.tiles_in.ptr, self.tiles_out.ptr,
                                                   int(not last or self.variant == 'tf_all')))
-            self.ctx.check(lib.bdof_tiles_scatter(h, self.tiles_out.ptr, self.field.ptr, self.fx, self.fy, self.n_tiles, self.tile, self.tile,
-                                                  xo, yo, self.halo, self.halo))
+            self._stitch(self.tiles_out)
+
+    def _sum_over_ranks(self, buf):
+        if self.comm.size > 1:
+            self.comm.allreduce_sum_device(self.ctx, buf)
+
+    def _stitch(self, tiles):
+        """Cores of this rank's tiles -> field; with several ranks the other ranks' cores arrive by summation."""
+        p = self.idx.ptr
+        if self.comm.size > 1:
+            self.ctx.check(self.lib.bdof_memset(self.h, self.field.ptr, 0, self.field.nbytes))
+        self.ctx.check(self.lib.bdof_tiles_scatter(self.h, tiles.ptr, self.field.ptr, self.fx, self.fy, self.n_tiles, self.tile, self.tile,
+                                                   p + 4 * self.n_tiles, p + 8 * self.n_tiles, self.halo, self.halo))
+        self._sum_over_ranks(self.field)
 
     def forward(self, probe_real, probe_imag):
         """Exit wave (FY, FX) complex64 of the probe (FY, FX) through the object."""
@@ -118,7 +143,7 @@ class TiledPropagator(object):
         for (z0, nz), end in zip(segs, self._ends):
             self.ctx.check(lib.bdof_tiles_gather(h, self.field.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.taper))
             self.ctx.check(lib.bdof_forward_range(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, end.ptr, 1))
-            self.ctx.check(lib.bdof_tiles_scatter(h, end.ptr, self.field.ptr, self.fx, self.fy, B, T, T, xo, yo, self.halo, self.halo))
+            self._stitch(end)
         self.ctx.check(lib.bdof_field_loss_seed(h, self.field.ptr, _lib._ptr(meas_dev), self.fx, self.fy))
         gvol = self._gvol
         self.ctx.check(lib.bdof_memset(h, gvol.ptr, 0, gvol.nbytes))
@@ -127,6 +152,8 @@ class TiledPropagator(object):
             self.ctx.check(lib.bdof_adjoint_range(h, B, a, xo, yo, z0, nz, end.ptr, self.tiles_in.ptr, self.tiles_out.ptr, self._grot.ptr))
             self.ctx.check(lib.bdof_tiles_grad_add(h, self._grot.ptr, gvol.ptr, B, T, T, xo, yo, z0, nz))
             self.ctx.check(lib.bdof_tiles_gather_adjoint(h, self.tiles_out.ptr, self.field.ptr, self.fx, self.fy, B, T, T, xo, yo, self.taper))
+            self._sum_over_ranks(self.field)
+        self._sum_over_ranks(gvol)
         loss = ctypes.c_double(0)
         self.ctx.check(lib.bdof_get_loss(h, ctypes.byref(loss)))
         return loss.value, gvol

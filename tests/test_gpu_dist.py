@@ -23,14 +23,19 @@ def _free_port():
     return port
 
 
-def _run_two_ranks(tmp_path, sharded):
+def _launch_two(worker, *args):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
                    LOCAL_RANK=str(rank), BDOF_COMM_BACKEND='gloo')
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', '_dist_gpu_worker.py'), str(tmp_path), str(int(sharded))],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', worker)] + [str(a) for a in args],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    return procs
+
+
+def _run_two_ranks(tmp_path, sharded):
+    procs = _launch_two('_dist_gpu_worker.py', tmp_path, int(sharded))
     outs = []
     for p in procs:
         try:
@@ -155,3 +160,33 @@ def test_bench_py_single_rank_matches_contract():
     assert ro['bound'] == 'hbm' and abs(ro['frac'] - ro['achieved'] / ro['peak']) < 1e-12
     assert abs(ro['achieved'] * 1e9 - ro['algorithmic_bytes_per_launch'] / (ro['avg_launch_ms_events'] * 1e-3)) <= 1e-6 * ro['achieved'] * 1e9
     assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['value'] > 0
+
+
+def test_two_rank_tiled_propagation(tmp_path):
+    """cfg4's tiled propagation with the tiles dealt to two ranks (spatial decomposition): the stitched field,
+    the loss, the object gradient and G(probe) equal the single-rank run's — the forward field bit for bit (a sum with zeros),
+    the adjoint quantities to float32 summation order."""
+    import __graft_entry__ as entry
+    entry.build()
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import _dist_tiling_worker as w
+    procs = _launch_two('_dist_tiling_worker.py', tmp_path)
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0].decode())
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), '\n'.join(o[-3000:] for o in outs)
+    r0, r1 = [np.load(str(tmp_path / 'tiled_rank{}.npz'.format(r))) for r in range(2)]
+    for k in ('wave', 'loss', 'gd', 'gb', 'gprobe'):
+        assert np.array_equal(r0[k], r1[k]), k                     # every rank ends with the same field and gradient
+    tp, one = w.run(None)
+    assert tp.n_tiles == tp.n_tiles_field == 16
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    assert np.array_equal(r0['wave'], one['wave'])
+    assert abs(float(r0['loss']) - float(one['loss'])) <= 1e-6 * abs(float(one['loss']))
+    assert rel(r0['gd'], one['gd']) <= 2e-6 and rel(r0['gb'], one['gb']) <= 2e-6
+    assert rel(r0['gprobe'], one['gprobe']) <= 2e-6
