@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from beyond_dof_amd import h5io
 from beyond_dof_amd.fullfield import reconstruct_fullfield
 from beyond_dof_amd.solver import FullfieldSolver
-n, n_theta, mb = int(sys.argv[1]) if len(sys.argv) > 1 else 256, 20, 10
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+n_theta = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+mb = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 rng = np.random.default_rng(0)
 z, y, x = np.mgrid[:n, :n, :n]
 d = np.zeros((n, n, n), dtype=np.float32)
