@@ -50,7 +50,8 @@ struct bdof_ctx {
     int gpsi_B = 0;
     double *partial = nullptr, *loss_dev = nullptr;
     int npartial = 0;
-    float k = 0.f;
+    float k = 0.f;                              // the k the modulation table in c->mod was built with
+    float k_fft = 0.f;                          // bdof_set_physics' k (the reference's PI literal, quirk Q1)
     std::complex<double> h00{1.0, 0.0}, hdet00{1.0, 0.0}, a0{0.0, 0.0};   // carrier splitting (bdof_kernels.h)
     std::complex<double> cbm1{0.0, 0.0};        // cbar - 1: mean modulation factor of the object minus one (modulate_eps_s)
     double2* cbar_dev = nullptr;                // [npartial_cb + 1] per-workgroup sums of the modulation table, then the mean
@@ -77,6 +78,7 @@ struct bdof_ctx {
     bool have_physics = false, have_probe = false, tape_valid = false, last_valid = false;
     ObjView obj{};
     const float2* obj_src = nullptr;            // caller's (delta, beta) rows
+    bool obj_bound_mod = false;                 // bdof_set_object_bilinear: c->mod was written directly, there is no obj_src
     size_t obj_rows = 0;
     float2* mod = nullptr;                      // c - 1 table of those rows (k_modulation_table)
     size_t mod_cap = 0;
@@ -494,25 +496,24 @@ static void forward_sweep(bdof_ctx* c, const Group* groups, int ngroups, int tap
 }
 
 // (Re)build the modulation table c - 1 = exp(i k delta - k beta) - 1 of the object rows when the object or k changed.
-static int ensure_modulation(bdof_ctx* c) {
-    if (!c->mod_dirty) return 0;
-    const size_t n = c->obj_rows * (size_t)c->obj.volNY;
+// room for n modulation factors and, if the mean-refraction carrier is in use, for the per-workgroup sums of a pass
+static int modulation_room(bdof_ctx* c, size_t n, bool mean) {
     if (n > c->mod_cap) {
         if (c->mod) (void)hipFree(c->mod);
         c->mod = nullptr; c->mod_cap = 0;
         HIPC(c, hipMalloc((void**)&c->mod, sizeof(float2) * n));
         c->mod_cap = n;
     }
-    size_t need = (n + 255) / 256;
-    int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
-    const bool mean = want_cbar(c);
-    if (mean && c->ncb < grid + 1) {
+    if (mean && c->ncb < c->ncu * 16 + 1) {
         if (c->cbar_dev) (void)hipFree(c->cbar_dev);
         c->cbar_dev = nullptr; c->ncb = 0;
         HIPC(c, hipMalloc((void**)&c->cbar_dev, sizeof(double2) * (size_t)(c->ncu * 16 + 1)));
         c->ncb = c->ncu * 16 + 1;
     }
-    hipLaunchKernelGGL(k_modulation_table, dim3(grid), dim3(256), 0, c->stream, c->obj_src, c->mod, n, c->k, mean ? c->cbar_dev : nullptr);
+    return 0;
+}
+// after a pass that left c - 1 in c->mod (and `grid` partial sums in cbar_dev if mean): mean to the host, object bound
+static int modulation_done(bdof_ctx* c, size_t n, int grid, bool mean) {
     HIPC(c, hipGetLastError());
     std::complex<double> cb(0.0, 0.0);
     if (mean) {
@@ -529,6 +530,24 @@ static int ensure_modulation(bdof_ctx* c) {
     return 0;
 }
 
+static int ensure_modulation(bdof_ctx* c) {
+    if (!c->mod_dirty) return 0;
+    if (!c->obj_src) return fail(c, BDOF_ERR_STATE, "the object was bound as modulation factors (bdof_set_object_bilinear): bind it again for this propagator");
+    const size_t n = c->obj_rows * (size_t)c->obj.volNY;
+    const bool mean = want_cbar(c);
+    int r = modulation_room(c, n, mean);
+    if (r) return r;
+    size_t need = (n + 255) / 256;
+    int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
+    hipLaunchKernelGGL(k_modulation_table, dim3(grid), dim3(256), 0, c->stream, c->obj_src, c->mod, n, c->k, mean ? c->cbar_dev : nullptr);
+    return modulation_done(c, n, grid, mean);
+}
+
+static int ensure_modulation_k(bdof_ctx* c, float k) {
+    // the conv propagator's k uses numpy's pi, the FFT path's the reference's literal (quirk Q1): one table per k
+    if (c->k != k) { c->k = k; c->mod_dirty = true; }
+    return ensure_modulation(c);
+}
 
 // =================================================================================================
 // Generic-size engine (rocFFT).  Fields are real-space [b][x][y] in bufA; the tape holds phi_z.
@@ -737,7 +756,7 @@ static int check_ready(bdof_ctx* c, int B) {
     if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
     if (!c->have_physics) return fail(c, BDOF_ERR_STATE, "bdof_set_physics has not been called");
     if (!c->have_probe) return fail(c, BDOF_ERR_STATE, "bdof_set_probe has not been called");
-    if (!c->obj_src) return fail(c, BDOF_ERR_STATE, "bdof_set_object has not been called");
+    if (!c->obj_src && !c->obj_bound_mod) return fail(c, BDOF_ERR_STATE, "bdof_set_object has not been called");
     if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
     return 0;
 }
@@ -948,7 +967,7 @@ int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det
     }
     HIPC(c, hipStreamSynchronize(c->stream));
     c->res_dirty = true;
-    c->k = (float)k;
+    c->k = c->k_fft = (float)k;
     c->h00 = std::complex<double>(h00[0], h00[1]);
     c->hdet00 = hdet00 ? std::complex<double>(hdet00[0], hdet00[1]) : std::complex<double>(1.0, 0.0);
     c->det_mode = det_mode;
@@ -1104,6 +1123,7 @@ int bdof_set_object(bdof_ctx* c, const void* vol, long long n_rows, int volNY, c
     if (tab && (volNX < 1 || n_angles < 1)) return fail(c, BDOF_ERR_ARG, "volNX and n_angles must be >= 1 with a table");
     if (!tab && volNY != c->NY) return fail(c, BDOF_ERR_ARG, "without a rotation table volNY must equal NY");
     c->obj_src = (const float2*)vol;
+    c->obj_bound_mod = false;
     c->obj_rows = (size_t)n_rows;
     c->mod_dirty = true;
     c->obj.vol = nullptr;
@@ -1139,7 +1159,7 @@ int bdof_forward(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, con
     if (keep_tape && c->recompute) return fail(c, BDOF_ERR_STATE, "the per-slice history is not kept in tape-free (recompute) mode");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
-    if ((r = ensure_modulation(c))) return r;
+    if ((r = ensure_modulation_k(c, c->k_fft))) return r;
     if (use_resident(c, B) && !keep_tape) {
         if ((r = resident_run(c, B, nullptr, out_wave, false))) return r;
         c->tape_valid = c->last_valid = false;
@@ -1191,7 +1211,7 @@ int bdof_forward_range(bdof_ctx* c, int B, const int* angle_of_b, const int* xof
     if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
-    if ((r = ensure_modulation(c))) return r;
+    if ((r = ensure_modulation_k(c, c->k_fft))) return r;
     Group groups[BDOF_MAX_GROUPS];
     const int ng = batch_groups(c, B, c->NX, 16, groups);
     if ((r = fork_streams(c, ng))) return r;
@@ -1241,7 +1261,7 @@ int bdof_adjoint_range(bdof_ctx* c, int B, const int* angle_of_b, const int* xof
     if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
-    if ((r = ensure_modulation(c))) return r;
+    if ((r = ensure_modulation_k(c, c->k_fft))) return r;
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     cf* const rc1 = c->tape;                       // marched-back phi_hat_z (L1)
     cf* const rc2 = c->tape + fld;                 // R eps(psi_z) (L2)
@@ -1396,7 +1416,7 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
     if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
-    if ((r = ensure_modulation(c))) return r;
+    if ((r = ensure_modulation_k(c, c->k_fft))) return r;
     c->gpsi_src = c->gpsi0;
     c->gpsi_B = B;
     if (use_resident(c, B)) {
@@ -1585,11 +1605,6 @@ static int conv_check(bdof_ctx* c, int B, const int* angle_of_b) {
     return 0;
 }
 
-static int ensure_modulation_k(bdof_ctx* c, float k) {
-    // the conv propagator's k uses numpy's pi, the FFT path's the reference's literal (quirk Q1): one table per k
-    if (c->k != k) { c->k = k; c->mod_dirty = true; }
-    return ensure_modulation(c);
-}
 
 extern "C" {
 
@@ -1835,9 +1850,39 @@ int bdof_rotate_bilinear(bdof_ctx* c, const void* vol, int NXv, int NZv, int NYv
     RotBilinArgs a{(const float2*)vol, (float2*)out_rows, nullptr, (const double4*)prm, B, NXv, NZv, NYv, 0, 0, 0, 1.f};
     const size_t nrows = (size_t)B * NZv * NXv;
     const int grid = (int)std::min<size_t>((nrows + 3) / 4, (size_t)c->ncu * 16);
-    hipLaunchKernelGGL(k_rot_bilinear, dim3(grid), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL((k_rot_bilinear<false>), dim3(grid), dim3(256), 0, c->stream, a, 0.f, (double2*)nullptr);
     HIPC(c, hipGetLastError());
     return 0;
+}
+
+// bdof_rotate_bilinear + bdof_set_object in one pass: the B rotated objects are written straight into the ctx's modulation
+// table as factors c - 1 (no rotated (delta, beta) copy, no second pass over B volumes) and bound as the batch's objects.
+int bdof_set_object_bilinear(bdof_ctx* c, const void* vol, int NXv, int NZv, int NYv, const double* prm, int B, int conv) {
+    if (!c || !vol || !prm || B < 1) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    if (NXv < 1 || NZv < 1 || NYv < 2 || NYv % 2) return fail(c, BDOF_ERR_SIZE, "bdof_set_object_bilinear needs an even NY");
+    if (NYv != c->NY || NXv != c->NX || NZv != c->S) return fail(c, BDOF_ERR_ARG, "the volume must be (NX, S, NY) of the configured wavefields");
+    if (B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
+    if (conv && !c->have_conv) return fail(c, BDOF_ERR_STATE, "bdof_set_conv has not been called");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t nrows = (size_t)B * NZv * NXv, n = nrows * NYv;
+    // set the binding first: want_cbar looks at the physics and probe only
+    c->obj_src = nullptr;
+    c->obj_bound_mod = true;
+    c->obj_rows = nrows;
+    c->obj.volNY = NYv;
+    c->obj.tab = nullptr;
+    c->obj.volNX = c->NX;
+    c->obj.S = c->S;
+    c->n_angles = 0;
+    c->k = conv ? c->k_conv : c->k_fft;
+    const bool mean = want_cbar(c);
+    int r = modulation_room(c, n, mean);
+    if (r) return r;
+    RotBilinArgs a{(const float2*)vol, c->mod, nullptr, (const double4*)prm, B, NXv, NZv, NYv, 0, 0, 0, 1.f};
+    const int grid = (int)std::min<size_t>((nrows + 3) / 4, (size_t)c->ncu * 16);
+    hipLaunchKernelGGL((k_rot_bilinear<true>), dim3(grid), dim3(256), 0, c->stream, a, c->k, mean ? c->cbar_dev : (double2*)nullptr);
+    return modulation_done(c, n, grid, mean);
 }
 
 int bdof_rotate_bilinear_adjoint(bdof_ctx* c, const void* grot, int NXv, int NZv, int NYv, const double* prm, int B, void* gvol, int row0,

@@ -1103,11 +1103,15 @@ __device__ __forceinline__ void bilin_taps(const double4 p, int h, int w, int H,
         wt[i] = in ? cw[i] : 0.f;
     }
 }
-// one wave per output row (4 rows per workgroup)
-__global__ __launch_bounds__(256) void k_rot_bilinear(RotBilinArgs a) {
+// one wave per output row (4 rows per workgroup).  MOD: the rows are written as modulation factors c - 1 of the interpolated
+// (delta, beta) (what k_modulation_table would make of them in a second pass over B volumes), with the per-workgroup
+// float64 sums of c - 1 in `partial` when the mean-refraction carrier needs them.
+template <bool MOD>
+__global__ __launch_bounds__(256) void k_rot_bilinear(RotBilinArgs a, float k, double2* __restrict__ partial) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t nrows = (size_t)a.B * a.NZv * a.NXv;
     const int nv = a.NYv / 2;                      // float4 = two (delta, beta) pairs
+    double sx = 0.0, sy = 0.0;
     for (size_t o = (size_t)blockIdx.x * 4 + wave; o < nrows; o += (size_t)gridDim.x * 4) {
         const int x = o % a.NXv;
         const size_t r = o / a.NXv;
@@ -1126,7 +1130,23 @@ __global__ __launch_bounds__(256) void k_rot_bilinear(RotBilinArgs a) {
                     acc.z = fmaf(wt[i], s.z, acc.z); acc.w = fmaf(wt[i], s.w, acc.w);
                 }
             }
+            if constexpr (MOD) {
+                const float2 m0 = slice_modulation_m1(make_float2(acc.x, acc.y), k), m1 = slice_modulation_m1(make_float2(acc.z, acc.w), k);
+                acc = make_float4(m0.x, m0.y, m1.x, m1.y);
+                sx += (double)m0.x + (double)m1.x;
+                sy += (double)m0.y + (double)m1.y;
+            }
             dst[v] = acc;
+        }
+    }
+    if constexpr (MOD) {
+        if (partial) {
+            __shared__ double w[2][4];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off, 64); sy += __shfl_down(sy, off, 64); }
+            if (lane == 0) { w[0][wave] = sx; w[1][wave] = sy; }
+            __syncthreads();
+            if (threadIdx.x == 0) partial[blockIdx.x] = make_double2(w[0][0] + w[0][1] + w[0][2] + w[0][3], w[1][0] + w[1][1] + w[1][2] + w[1][3]);
         }
     }
 }

@@ -304,8 +304,6 @@ class FullfieldSolver(_VolumeSolver):
             c, sn = np.cos(th), np.sin(th)
             self.rot_prm = np.stack([c, sn, ((W - 1) - (c * (W - 1) - sn * (H - 1))) / 2.0, ((H - 1) - (sn * (W - 1) + c * (H - 1))) / 2.0], axis=1)
             self.prm_buf = DeviceBuffer(self.ctx, self.mb * 32, np.float64, (self.mb, 4))
-            self.rot_rows = DeviceBuffer(self.ctx, self.mb * self.dim_z * self.dim_x * self.dim_y * 8, np.float32,
-                                         (self.mb, self.dim_z, self.dim_x, self.dim_y, 2))
             self.tab = self.off = self.order = None
         else:
             # rotation lookup tables (cnn_propagator/util.py:294-347), uploaded once
@@ -330,13 +328,14 @@ class FullfieldSolver(_VolumeSolver):
         self.eng.set_volume(self.x[self.cur], self.dim_x * self.dim_z, self.dim_y, self.tab, self.dim_x, self.n_theta)
 
     def _rotate_batch(self, idx, B):
-        """Bilinear rotation of the current volume to the B angles idx -> rot_rows, bound as a batch of rotated objects."""
+        """Bilinear rotation of the current volume to the B angles idx, bound as a batch of rotated objects: one pass that
+        writes the rotated objects' modulation factors into the ctx (bdof_set_object_bilinear)."""
         lib, h = self.ctx.lib, self.ctx.handle
         prm = np.zeros((self.mb, 4))
         prm[:B] = self.rot_prm[np.asarray(idx)]
         self.prm_buf.upload(prm)
-        self.ctx.check(lib.bdof_rotate_bilinear(h, self.x[self.cur].ptr, self.dim_x, self.dim_z, self.dim_y, self.prm_buf.ptr, B, self.rot_rows.ptr))
-        self.eng.set_volume(self.rot_rows, B * self.dim_z * self.dim_x, self.dim_y, None, 0, 0)
+        self.ctx.check(lib.bdof_set_object_bilinear(h, self.x[self.cur].ptr, self.dim_x, self.dim_z, self.dim_y, self.prm_buf.ptr, B,
+                                                    int(self.conv)))
 
     def set_measurements(self, prj_abs):
         """|prj| for every angle, (n_theta, Y, X) (loss uses np.abs(this_prj_batch), fullfield.py:106)."""

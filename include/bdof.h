@@ -194,6 +194,11 @@ int bdof_rotation_adjoint_rows(bdof_ctx* ctx, int B, const int* angle_of_b, void
  * already rotated objects.  The adjoint takes the rotated-frame gradient bdof_grot() back to volume rows [row0, row0+n_rows)
  * of gvol (deterministic gather; same slab interface as bdof_rotation_adjoint_rows). */
 int bdof_rotate_bilinear(bdof_ctx* ctx, const void* vol, int NXv, int NZv, int NYv, const double* prm, int B, void* out_rows);
+/* The two calls above in one pass (what FullfieldSolver(rotation='bilinear') runs every step): the B rotated objects are
+ * written straight into the ctx's table of modulation factors exp(i k (delta + i beta) dz) - 1 and bound as the batch's objects
+ * — no rotated (delta, beta) copy, no second pass over B volumes.  The volume must be (NX, S, NY) of the configured wavefields.
+ * conv != 0: factors for the real-space propagator's k (bdof_set_conv), which the conv entry points then use. */
+int bdof_set_object_bilinear(bdof_ctx* ctx, const void* vol, int NXv, int NZv, int NYv, const double* prm, int B, int conv);
 int bdof_rotate_bilinear_adjoint(bdof_ctx* ctx, const void* grot, int NXv, int NZv, int NYv, const double* prm, int B, void* gvol, int row0,
                                  int n_rows, int accumulate, float scale);
 

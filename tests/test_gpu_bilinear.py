@@ -46,9 +46,19 @@ def test_bilinear_rotation_forward_gradient_and_adam(fp):
     s.set_volume(od, ob)
     w = s.forward_angles(idx)
     assert rel(np.abs(w) ** 2, np.abs(ref) ** 2) <= 1e-5 and rel(w, ref) <= 1e-5
-    # the rotated objects themselves
-    got = s.rot_rows.download()                                           # [b][z][x][y][2]
+    # the rotated objects themselves (bdof_rotate_bilinear; the solver's one-pass bdof_set_object_bilinear writes their
+    # modulation factors instead) ...
+    from beyond_dof_amd._lib import DeviceBuffer
+    lib, h = s.ctx.lib, s.ctx.handle
+    rows = DeviceBuffer(s.ctx, mb * n * n * n * 8, np.float32, (mb, n, n, n, 2))
+    prm = DeviceBuffer.from_host(s.ctx, np.ascontiguousarray(s.rot_prm[idx]))
+    s.ctx.check(lib.bdof_rotate_bilinear(h, s.x[s.cur].ptr, n, n, n, prm.ptr, mb, rows.ptr))
+    s.ctx.sync()
+    got = rows.download()                                                 # [b][z][x][y][2]
     assert rel(got[..., 0].transpose(0, 3, 2, 1), rot[..., 0]) <= 2e-6
+    # ... and bound the two-pass way they give the same wave, bit for bit
+    s.eng.set_volume(rows, mb * n * n, n, None, 0, 0)
+    assert np.array_equal(s.eng.forward(mb), w)
     prj = np.zeros((n_theta, n, n))
     prj[idx] = (np.abs(ref) * (1 + 0.03 * rng.normal(size=ref.shape))).astype(np.float32)
     s.set_measurements(prj)
