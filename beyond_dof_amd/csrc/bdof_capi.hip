@@ -1895,7 +1895,12 @@ int bdof_rotate_bilinear_adjoint(bdof_ctx* c, const void* grot, int NXv, int NZv
     ProfScope ps(c, BDOF_K_ROT_ADJ);
     RotBilinArgs a{nullptr, (float2*)grot, (float2*)gvol, (const double4*)prm, B, NXv, NZv, NYv, row0, row0 + n_rows, accumulate, scale};
     const int grid = std::min((n_rows + 3) / 4, c->ncu * 16);
-    hipLaunchKernelGGL(k_rot_bilinear_adjoint, dim3(grid), dim3(256), 0, c->stream, a);
+    const int nv4 = (NYv / 2 + 63) / 64;
+    if (nv4 <= 1) hipLaunchKernelGGL((k_rot_bilinear_adjoint<1>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (nv4 <= 2) hipLaunchKernelGGL((k_rot_bilinear_adjoint<2>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (nv4 <= 4) hipLaunchKernelGGL((k_rot_bilinear_adjoint<4>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (nv4 <= 8) hipLaunchKernelGGL((k_rot_bilinear_adjoint<8>), dim3(grid), dim3(256), 0, c->stream, a);
+    else return fail(c, BDOF_ERR_SIZE, "bdof_rotate_bilinear_adjoint: NY <= 1024");
     HIPC(c, hipGetLastError());
     return 0;
 }

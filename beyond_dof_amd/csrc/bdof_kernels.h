@@ -1154,43 +1154,89 @@ __global__ __launch_bounds__(256) void k_rot_bilinear(RotBilinArgs a, float k, d
 // source point lies within one pixel of it.  A rotation preserves distances, so those (x, z) lie within sqrt(2) of the
 // inverse-rotated (x', z'): the 4 x 4 lattice points around it are examined, the weight of each comes from the FORWARD map
 // (the same numbers the forward kernel used).
+// Per destination row the candidates (angle b, lattice point (jh, jw)) are examined 64 at a time, one per lane (the float64
+// tap arithmetic is done once per candidate, not once per lane); the ones with a non-zero weight are compacted, in candidate
+// order, into a per-wave list, and the wave then streams those rows — four float4 columns per lane, two rows in flight.
+template <int NV4>       // float4 columns per lane: NYv / 2 <= 64 * NV4
 __global__ __launch_bounds__(256) void k_rot_bilinear_adjoint(RotBilinArgs a) {
+    __shared__ int l_row[4][64];
+    __shared__ float l_wgt[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nv = a.NYv / 2;
     const int H = a.NXv, W = a.NZv;
     for (int d = a.d0 + blockIdx.x * 4 + wave; d < a.d1; d += gridDim.x * 4) {
         const int hp = d / W, wp = d - hp * W;            // (x', z')
-        float4* drow = reinterpret_cast<float4*>(a.gvol + (size_t)d * a.NYv);
-        for (int v0 = 0; v0 < nv; v0 += 64) {
-            const int v = v0 + lane;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int b = 0; b < a.B; ++b) {
+        float4 acc[NV4];
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b0 = 0; b0 < a.B; b0 += 4) {
+            const int b = b0 + (lane >> 4), jh = (lane >> 2) & 3, jw = lane & 3;
+            float wgt = 0.f;
+            int row = 0;
+            if (b < a.B) {
                 const double4 p = a.prm[b];
                 // inverse of (h', w') = (s w + c h + yo, c w - s h + xo):  w = c (w' - xo) + s (h' - yo),  h = -s (w' - xo) + c (h' - yo)
                 const double dw = wp - p.z, dh = hp - p.w;
                 const double wi = p.x * dw + p.y * dh, hi = -p.y * dw + p.x * dh;
-                const int w0 = (int)floor(wi) - 1, h0 = (int)floor(hi) - 1;
-                for (int jh = 0; jh < 4; ++jh) {
-                    const int h = h0 + jh;
-                    if (h < 0 || h >= H) continue;
-                    for (int jw = 0; jw < 4; ++jw) {
-                        const int w = w0 + jw;
-                        if (w < 0 || w >= W) continue;
-                        const double sw = p.x * w - p.y * h + p.z, sh = p.y * w + p.x * h + p.w;
-                        const double fw = floor(sw), fh = floor(sh);
-                        const int iw = wp - (int)fw, ih = hp - (int)fh;     // which of the 2 x 2 taps of (h, w) is (h', w'): 0 or 1
-                        if (iw < 0 || iw > 1 || ih < 0 || ih > 1) continue;
+                const int w = (int)floor(wi) - 1 + jw, h = (int)floor(hi) - 1 + jh;
+                if (h >= 0 && h < H && w >= 0 && w < W) {
+                    const double sw = p.x * w - p.y * h + p.z, sh = p.y * w + p.x * h + p.w;
+                    const double fw = floor(sw), fh = floor(sh);
+                    const int iw = wp - (int)fw, ih = hp - (int)fh;         // which of the 2 x 2 taps of (h, w) is (h', w'): 0 or 1
+                    if (iw >= 0 && iw <= 1 && ih >= 0 && ih <= 1) {
                         const float aw = (float)(sw - fw), ah = (float)(sh - fh);
-                        const float wgt = (ih ? ah : 1.f - ah) * (iw ? aw : 1.f - aw);
-                        if (wgt == 0.f || v >= nv) continue;
-                        const float4 s = reinterpret_cast<const float4*>(a.rot + (((size_t)b * W + w) * H + h) * a.NYv)[v];
-                        acc.x = fmaf(wgt, s.x, acc.x); acc.y = fmaf(wgt, s.y, acc.y);
-                        acc.z = fmaf(wgt, s.z, acc.z); acc.w = fmaf(wgt, s.w, acc.w);
+                        wgt = (ih ? ah : 1.f - ah) * (iw ? aw : 1.f - aw);
+                        row = (b * W + w) * H + h;
                     }
                 }
             }
+            const unsigned long long live = __ballot(wgt != 0.f);
+            const int n = __popcll(live);
+            if (wgt != 0.f) {
+                const int pos = __popcll(live & ((1ull << lane) - 1ull));      // candidate order is kept: deterministic sums
+                l_row[wave][pos] = row;
+                l_wgt[wave][pos] = wgt;
+            }
+            // a wave's LDS accesses execute in program order: no hardware barrier between the list's writes and reads
+            __builtin_amdgcn_wave_barrier();
+            int e = 0;
+            for (; e + 1 < n; e += 2) {
+                const float w0 = l_wgt[wave][e], w1 = l_wgt[wave][e + 1];
+                const float4* r0 = reinterpret_cast<const float4*>(a.rot + (size_t)l_row[wave][e] * a.NYv);
+                const float4* r1 = reinterpret_cast<const float4*>(a.rot + (size_t)l_row[wave][e + 1] * a.NYv);
+                float4 s0[NV4], s1[NV4];
+#pragma unroll
+                for (int i = 0; i < NV4; ++i) {
+                    const int v = min(lane + 64 * i, nv - 1);
+                    s0[i] = r0[v];
+                    s1[i] = r1[v];
+                }
+#pragma unroll
+                for (int i = 0; i < NV4; ++i) {
+                    acc[i].x = fmaf(w0, s0[i].x, acc[i].x); acc[i].y = fmaf(w0, s0[i].y, acc[i].y);
+                    acc[i].z = fmaf(w0, s0[i].z, acc[i].z); acc[i].w = fmaf(w0, s0[i].w, acc[i].w);
+                    acc[i].x = fmaf(w1, s1[i].x, acc[i].x); acc[i].y = fmaf(w1, s1[i].y, acc[i].y);
+                    acc[i].z = fmaf(w1, s1[i].z, acc[i].z); acc[i].w = fmaf(w1, s1[i].w, acc[i].w);
+                }
+            }
+            if (e < n) {
+                const float w0 = l_wgt[wave][e];
+                const float4* r0 = reinterpret_cast<const float4*>(a.rot + (size_t)l_row[wave][e] * a.NYv);
+#pragma unroll
+                for (int i = 0; i < NV4; ++i) {
+                    const float4 s = r0[min(lane + 64 * i, nv - 1)];
+                    acc[i].x = fmaf(w0, s.x, acc[i].x); acc[i].y = fmaf(w0, s.y, acc[i].y);
+                    acc[i].z = fmaf(w0, s.z, acc[i].z); acc[i].w = fmaf(w0, s.w, acc[i].w);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        float4* drow = reinterpret_cast<float4*>(a.gvol + (size_t)d * a.NYv);
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int v = lane + 64 * i;
             if (v < nv) {
-                float4 o = make_float4(acc.x * a.scale, acc.y * a.scale, acc.z * a.scale, acc.w * a.scale);
+                float4 o = make_float4(acc[i].x * a.scale, acc[i].y * a.scale, acc[i].z * a.scale, acc[i].w * a.scale);
                 if (a.accumulate) f4acc(o, drow[v]);
                 drow[v] = o;
             }
