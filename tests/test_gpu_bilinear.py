@@ -108,3 +108,22 @@ def test_reconstruct_fullfield_bilinear(tmp_path, monkeypatch):
     assert os.path.exists(os.path.join('case', 'out', 'delta_ds_1.tiff')) and d.shape == (n, n, n)
     assert not os.path.exists('arrsize_64_64_64_ntheta_6')                  # no lookup tables are made in this mode
     assert np.linalg.norm(d - od) < np.linalg.norm(0.9 * od - od)           # moved towards the truth
+
+
+def test_bilinear_binding_for_the_real_space_propagator():
+    """bdof_set_object_bilinear(conv=1) writes the factors for the real-space propagator's k (numpy's pi, not the FFT path's
+    literal — the two agree to 1e-8, i.e. they are the same float32 here): same waves as rotating first
+    (bdof_rotate_bilinear) and binding the rows (bdof_set_object)."""
+    from beyond_dof_amd._lib import DeviceBuffer
+    from beyond_dof_amd.solver import FullfieldSolver
+    n, n_theta, mb = 64, 7, 3
+    rng, od, ob, theta, idx = _case(n, n_theta, mb)
+    s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, rotation='bilinear', theta=theta, propagator='conv')
+    s.set_volume(od, ob)
+    w = s.forward_angles(idx)                                             # fused binding, conv sweep
+    lib, h = s.ctx.lib, s.ctx.handle
+    rows = DeviceBuffer(s.ctx, mb * n * n * n * 8, np.float32, (mb, n, n, n, 2))
+    prm = DeviceBuffer.from_host(s.ctx, np.ascontiguousarray(s.rot_prm[idx]))
+    s.ctx.check(lib.bdof_rotate_bilinear(h, s.x[s.cur].ptr, n, n, n, prm.ptr, mb, rows.ptr))
+    s.eng.set_volume(rows, mb * n * n, n, None, 0, 0)
+    assert np.array_equal(s.eng.forward(mb, conv=True), w)
