@@ -392,8 +392,10 @@ def gaussian_probe(shape, mag_sigma, phase_sigma, phase_max):
 
 # ---------------------------------------------------------------------------
 # Real-space truncated-kernel propagator            cnn_propagator/propagation.py:18-133   
-# RESTATEMENT ONLY: the reference function needs autograd.scipy.signal.convolve, which is not installed, so it
-# cannot be executed here; get_kernel (the only numerical ingredient besides FFT/convolution) is golden-pinned.
+# Pinned by golden vector G9 (tests/golden/make_golden.py --g9): the reference's own function executed from its file, with
+# its one absent third-party primitive — HIPS autograd's autograd.scipy.signal.convolve, un-versioned in the reference —
+# stood in by scipy.signal.convolve2d for the single call form it uses ('valid', axes=([1, 2], [0, 1])).  The restatement
+# below reproduces those outputs to 1e-12; what stays unpinned is that primitive's definition (a true convolution).
 # ---------------------------------------------------------------------------
 def conv_kernel_2d(delta_nm, lmbda_nm, voxel_nm, grid_shape, kernel_size):
     """propagation.py:35-44: H on the (Y-1, X-1) mesh -> real space -> centre crop of kernel_size^2."""

@@ -5,11 +5,18 @@ Run only in the build container (needs /root/reference, which never travels):
     python tests/golden/make_golden.py            # G1-G6  -> tests/golden/*.npz
     /opt/conda/bin/python3.9 tests/golden/make_golden.py --h5   # G7 (h5py 3.3.0 lives there)
     python tests/golden/make_golden.py --g8       # G8 (get_kernel_ir, upsample_2x)
+    python tests/golden/make_golden.py --g9       # G9 (propagation.multislice_propagate_cnn, the real-space propagator)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
 stubbed, pyfftw's numpy interface is aliased to numpy.fft (the reference's own
 fallback, tensorflow_recon/util.py:7-14) and autograd.numpy to numpy.
+G9 runs propagation.multislice_propagate_cnn unmodified.  Its one third-party primitive, HIPS autograd's
+autograd.scipy.signal.convolve (not installed, no pinned version anywhere in the reference), is stood in by
+scipy.signal.convolve2d per batch element for the one call form the function uses (mode='valid',
+axes=([1, 2], [0, 1]): true convolution of every [b] image with the 2-D kernel).  The vector therefore pins everything
+the reference itself writes — kernel construction and crop, the running padding constant, the slice loop, the corner
+renormalisation, the detector step — up to the definition of that primitive.
 The fixtures are data only (inputs + outputs); no reference source is stored.
 """
 import os
@@ -165,6 +172,49 @@ def main_g8():
     print('wrote g8')
 
 
+def main_g9():
+    """G9: the real-space truncated-kernel propagator (cnn_propagator/propagation.py:18-133)."""
+    _import_reference()
+    from scipy.signal import convolve2d
+
+    def convolve(a, b, mode='full', axes=None):
+        if mode != 'valid' or axes != ([1, 2], [0, 1]):
+            raise NotImplementedError('stand-in covers the call form of propagation.py:93 only')
+        return np.stack([convolve2d(img, b, mode='valid') for img in a])
+
+    autograd = sys.modules['autograd']
+    autograd.grad = lambda *a, **k: None
+    sys.modules['autograd.numpy.random'] = np.random
+    ascipy = types.ModuleType('autograd.scipy')
+    asignal = types.ModuleType('autograd.scipy.signal')
+    asignal.convolve = convolve
+    ascipy.signal = asignal
+    autograd.scipy = ascipy
+    sys.modules['autograd.scipy'] = ascipy
+    sys.modules['autograd.scipy.signal'] = asignal
+    import propagation as ref_prop
+    ref_prop.trange = range                                   # no progress bar in the log
+    g9 = {}
+    rng = np.random.default_rng(9)
+    delta = rng.uniform(0, 1e-5, size=(2, 16, 20, 6))
+    beta = 0.1 * delta
+    g9['delta16'], g9['beta16'] = delta, beta
+    prr, pii = 1 + 0.1 * rng.normal(size=(16, 20)), 0.1 * rng.normal(size=(16, 20))
+    g9['probe_real16'], g9['probe_imag16'] = prr, pii
+    for name, fp in [('none', None), ('near', 1e-4), ('inf', 'inf')]:
+        g9['wave16_k5_' + name] = ref_prop.multislice_propagate_cnn(delta, beta, np.ones((16, 20)), np.zeros((16, 20)), 5000., [1e-7] * 3,
+                                                                    kernel_size=5, free_prop_cm=fp)
+    g9['wave16_k9_probe_near'] = ref_prop.multislice_propagate_cnn(delta, beta, prr, pii, 5000., [1e-7] * 3, kernel_size=9, free_prop_cm=1e-4)
+    # cfg1: 64^3 tube phantom, first 32 slices, beta := 0.1 delta, the entry points' default kernel_size = 17
+    gd = np.load('/root/reference/tensorflow_recon/grid_delta.npy')[..., :32]
+    gd = gd.reshape(1, *gd.shape).astype(np.float64)
+    for name, fp in [('none', None), ('near', 1e-4)]:
+        g9['wave_cfg1_k17_' + name] = ref_prop.multislice_propagate_cnn(gd, 0.1 * gd, np.ones((64, 64)), np.zeros((64, 64)), 5000., [1e-7] * 3,
+                                                                        kernel_size=17, free_prop_cm=fp)
+    np.savez_compressed(os.path.join(HERE, 'g9_conv_propagator.npz'), **g9)
+    print('wrote g9')
+
+
 def main_h5():
     """G7: exchange/data files written by h5py 3.3.0 (run under /opt/conda/bin/python3.9)."""
     import h5py
@@ -192,5 +242,7 @@ if __name__ == '__main__':
         main_h5()
     elif '--g8' in sys.argv:
         main_g8()
+    elif '--g9' in sys.argv:
+        main_g9()
     else:
         main()

@@ -106,3 +106,22 @@ def test_fullfield_with_conv_propagator(engine_mod):
     rgb = sum(orc.apply_rotation_adjoint(gb_rot[b], coords[j]) for b, j in enumerate(idx))
     assert abs(loss - rl) <= 2e-5 * rl
     assert rel(gd, rgd) <= 2e-4 and rel(gb, rgb) <= 2e-4
+
+
+@pytest.mark.parametrize('name,fp', [('none', None), ('near', 1e-4)])
+def test_conv_forward_vs_reference_golden_vector(engine_mod, name, fp):
+    """The HIP path against golden vector G9 directly: the reference's own multislice_propagate_cnn on cfg1's object
+    (64 x 64 tube phantom, 32 slices, 17 taps; tests/golden/make_golden.py --g9) — 1e-5 on intensities, the north-star bound."""
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    delta = np.load(os.path.join(gdir, 'g2_forward_cfg1.npz'))['delta']
+    ref = np.load(os.path.join(gdir, 'g9_conv_propagator.npz'))['wave_cfg1_k17_' + name]
+    B, Y, X, S = delta.shape
+    eng = engine_mod.MultisliceEngine(Y, X, S, B, with_grad=False)
+    eng.set_physics(5000., 1e-7, fp)
+    eng.set_conv(5000., [1e-7] * 3, 17)
+    eng.set_probe(np.ones((Y, X)), np.zeros((Y, X)))
+    eng.set_object_batch(delta, 0.1 * delta)
+    wave = eng.forward(B, conv=True)
+    assert rel(np.abs(wave) ** 2, np.abs(ref) ** 2) <= 1e-5
+    assert rel(wave, ref) <= 5e-6

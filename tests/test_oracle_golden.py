@@ -107,3 +107,25 @@ def test_g8_kernel_ir_and_upsample(golden_dir):
     for tag in ('3', '4'):
         for fn in (orc.upsample_2x, util.upsample_2x):
             np.testing.assert_allclose(fn(g['up_in' + tag]), g['up_out' + tag], rtol=0, atol=1e-15)
+
+
+def test_g9_real_space_propagator(golden_dir):
+    """multislice_propagate_cnn (cnn_propagator/propagation.py:18-133) executed from the reference's own file (its
+    autograd.scipy.signal.convolve stood in by scipy.signal.convolve2d, see make_golden.py): the oracle's restatement
+    reproduces kernel construction and crop, the running padding constant, the slice loop, the corner renormalisation and
+    the detector step to round-off."""
+    g = np.load(os.path.join(golden_dir, 'g9_conv_propagator.npz'))
+    d, b = g['delta16'], g['beta16']
+    one, zero = np.ones(d.shape[1:3]), np.zeros(d.shape[1:3])
+    for name, fp in [('none', None), ('near', 1e-4), ('inf', 'inf')]:
+        w = orc.multislice_propagate_cnn(d, b, one, zero, 5000., [1e-7] * 3, kernel_size=5, free_prop_cm=fp)
+        ref = g['wave16_k5_' + name]
+        np.testing.assert_allclose(w, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    w = orc.multislice_propagate_cnn(d, b, g['probe_real16'], g['probe_imag16'], 5000., [1e-7] * 3, kernel_size=9, free_prop_cm=1e-4)
+    np.testing.assert_allclose(w, g['wave16_k9_probe_near'], rtol=0, atol=1e-12 * np.abs(g['wave16_k9_probe_near']).max())
+    # cfg1's object, the entry points' default kernel_size = 17.  No file of the phantom travels: delta is rebuilt from G2b
+    gd = np.load(os.path.join(golden_dir, 'g2_forward_cfg1.npz'))['delta']
+    for name, fp in [('none', None), ('near', 1e-4)]:
+        w = orc.multislice_propagate_cnn(gd, 0.1 * gd, np.ones((64, 64)), np.zeros((64, 64)), 5000., [1e-7] * 3, kernel_size=17, free_prop_cm=fp)
+        ref = g['wave_cfg1_k17_' + name]
+        np.testing.assert_allclose(w, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
