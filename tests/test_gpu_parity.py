@@ -299,6 +299,33 @@ def test_adam_kernel_vs_oracle(engine_mod):
         assert np.abs(b - xr[1]).max() <= 2e-6 * xr[1].max()
 
 
+def test_adam_kernel_vs_reference_golden_vector(engine_mod, golden_dir):
+    """bdof_adam_step against golden vector G4 directly: three steps of the reference's own apply_gradient_adam
+    (cnn_propagator/util.py:280-291, incl. the m = v = None start) on a (2, 4, 5, 6) array; no regulariser, mask or clip."""
+    from beyond_dof_amd import util
+    from beyond_dof_amd._lib import DeviceBuffer
+    g4 = np.load(os.path.join(golden_dir, 'g4_adam.npz'))
+    eng = engine_mod.MultisliceEngine(64, 64, 2, 1, with_grad=False)
+    _, Y, X, Z = g4['x0'].shape
+    x = [DeviceBuffer.from_host(eng.ctx, util.volume_to_rows(g4['x0'][0], g4['x0'][1])), DeviceBuffer.zeros(eng.ctx, (X, Z, Y, 2), np.float32)]
+    m = DeviceBuffer.zeros(eng.ctx, (X, Z, Y, 2), np.float32)
+    v = DeviceBuffer.zeros(eng.ctx, (X, Z, Y, 2), np.float32)
+    cur = 0
+    for it in range(3):
+        gdat = g4['g{}'.format(it)]
+        g = DeviceBuffer.from_host(eng.ctx, util.volume_to_rows(gdat[0], gdat[1]))
+        eng.adam_step(x[cur], x[1 - cur], g, m, v, None, (X, Z, Y), it, 1e-7, g_scale=1.0, alpha_d=0.0, alpha_b=0.0, gamma=0.0, clip=False)
+        cur = 1 - cur
+        eng.sync()
+        d, b = util.rows_to_volume(x[cur].download())
+        want = g4['x{}'.format(it + 1)]
+        # float32 volume: the result is the float32 neighbour of the reference's float64 number, plus the step's own rounding
+        assert np.abs(d - want[0]).max() <= 2e-7 * np.abs(want).max() + 2e-6 * 1e-7
+        assert np.abs(b - want[1]).max() <= 2e-7 * np.abs(want).max() + 2e-6 * 1e-7
+        md, mb_ = util.rows_to_volume(m.download())
+        assert np.abs(md - g4['m{}'.format(it + 1)][0]).max() <= 2e-6 * np.abs(g4['m{}'.format(it + 1)]).max()
+
+
 def test_full_size_properties_512(engine_mod):
     """Size-independent properties at the benchmark's wavefield size (512 x 512, 64 slices)."""
     B, Y, X, S = 2, 512, 512, 64
