@@ -6,6 +6,7 @@ Run only in the build container (needs /root/reference, which never travels):
     /opt/conda/bin/python3.9 tests/golden/make_golden.py --h5   # G7 (h5py 3.3.0 lives there)
     python tests/golden/make_golden.py --g8       # G8 (get_kernel_ir, upsample_2x)
     python tests/golden/make_golden.py --g9       # G9 (propagation.multislice_propagate_cnn, the real-space propagator)
+    python tests/golden/make_golden.py --g10      # G10 (fullfield.reconstruct_fullfield: the whole loop, ~2 min)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -17,6 +18,11 @@ scipy.signal.convolve2d per batch element for the one call form the function use
 axes=([1, 2], [0, 1]): true convolution of every [b] image with the 2-D kernel).  The vector therefore pins everything
 the reference itself writes — kernel construction and crop, the running padding constant, the slice loop, the corner
 renormalisation, the detector step — up to the definition of that primitive.
+G10 runs fullfield.reconstruct_fullfield unmodified on an 8^3 problem: h5py / dxchange are in-memory stand-ins for the
+file traffic, and autograd.grad — reverse-mode differentiation by HIPS autograd, absent — is stood in by float64 central
+finite differences of the reference's own calculate_loss (1024 variables, relative accuracy ~1e-8).  The vector pins the
+loop itself: minibatch schedule from the global numpy seed, per-epoch Adam restart, mask, clip, regulariser variants
+(incl. quirk Q6), the order of all of it — with the reference's own forward model, rotation and Adam underneath.
 The fixtures are data only (inputs + outputs); no reference source is stored.
 """
 import os
@@ -215,6 +221,133 @@ def main_g9():
     print('wrote g9')
 
 
+def _setup_conv_reference():
+    """Import propagation.py with the stand-in of G9 for autograd's convolve; returns (stubs dict, module)."""
+    _import_reference()
+    from scipy.signal import convolve2d
+
+    def convolve(a, b, mode='full', axes=None):
+        if mode != 'valid' or axes != ([1, 2], [0, 1]):
+            raise NotImplementedError('stand-in covers the call form of propagation.py:93 only')
+        return np.stack([convolve2d(img, b, mode='valid') for img in a])
+
+    autograd = sys.modules['autograd']
+    sys.modules['autograd.numpy.random'] = np.random
+    ascipy = types.ModuleType('autograd.scipy')
+    asignal = types.ModuleType('autograd.scipy.signal')
+    asignal.convolve = convolve
+    ascipy.signal = asignal
+    autograd.scipy = ascipy
+    sys.modules['autograd.scipy'] = ascipy
+    sys.modules['autograd.scipy.signal'] = asignal
+    return autograd
+
+
+def main_g10():
+    """G10: reconstruct_fullfield (cnn_propagator/fullfield.py:19-390), the whole optimisation loop, on 8^3."""
+    import contextlib
+    import io
+    import tempfile
+    autograd = _setup_conv_reference()
+
+    def fd_grad(fn, argnums):
+        assert list(argnums) == [0, 1]
+
+        def g(obj_delta, obj_beta, *rest):
+            out = []
+            with contextlib.redirect_stdout(io.StringIO()):           # calculate_loss prints the loss on every call
+                for which in (0, 1):
+                    args = [np.array(obj_delta, dtype=np.float64), np.array(obj_beta, dtype=np.float64)]
+                    gr = np.zeros_like(args[which])
+                    h = 1e-9 if which == 0 else 1e-10
+                    it = np.nditer(args[which], flags=['multi_index'])
+                    for _ in it:
+                        i = it.multi_index
+                        keep = args[which][i]
+                        args[which][i] = keep + h
+                        lp = fn(args[0], args[1], *rest)
+                        args[which][i] = keep - h
+                        lm = fn(args[0], args[1], *rest)
+                        args[which][i] = keep
+                        gr[i] = (lp - lm) / (2 * h)
+                    out.append(gr)
+            return tuple(out)
+        return g
+
+    autograd.grad = fd_grad
+    import propagation as ref_prop
+    ref_prop.trange = range
+    import fullfield as ref_ff
+    ref_ff.trange = range
+
+    n, n_theta, mb = 8, 4, 2
+    rng = np.random.default_rng(10)
+    true_d = np.zeros((n, n, n))
+    true_d[2:6, 2:6, 2:6] = rng.uniform(2e-6, 6e-6, size=(4, 4, 4))
+    true_b = 0.1 * true_d
+    mask = np.ones((n, n, n), dtype=np.float32)
+    mask[0] = 0
+    init_d = np.clip(rng.normal(3e-6, 1e-6, size=(n, n, n)), 0, None)
+    init_b = np.clip(rng.normal(3e-7, 1e-7, size=(n, n, n)), 0, None)
+    store = {}
+
+    class _Dataset(object):
+        def __init__(self, arr):
+            self.arr = arr
+
+        def __getitem__(self, key):
+            return self.arr[key]
+
+    class _File(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def __getitem__(self, key):
+            assert key == 'exchange/data'
+            return _Dataset(store['prj'])
+
+    sys.modules['h5py'].File = _File
+    ref_ff.h5py.File = _File
+    dx = sys.modules['dxchange']
+    written = {}
+    dx.read_tiff_stack = lambda fname, ind, digit=5: np.array(mask)
+    dx.read_tiff = lambda fname: np.array(mask)
+    dx.write_tiff = lambda arr, fname=None, dtype=None, overwrite=False: written.__setitem__(os.path.basename(fname), np.array(arr))
+    dx.write_tiff_stack = lambda *a, **k: None
+
+    g10 = {'true_delta': true_d, 'true_beta': true_b, 'mask': mask, 'init_delta': init_d, 'init_beta': init_b}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            # the data: the reference's own forward model on its own rotation tables
+            ref_ff.save_rotation_lookup([n, n, n], n_theta)
+            folder = 'arrsize_{0}_{0}_{0}_ntheta_{1}'.format(n, n_theta)
+            coords = ref_ff.read_all_origin_coords(folder, n_theta)
+            obj = np.stack([true_d, true_b], axis=3)
+            rot = np.stack([ref_ff.apply_rotation(obj, c, folder) for c in coords])
+            prj = ref_prop.multislice_propagate_cnn(rot[..., 0], rot[..., 1], np.ones((n, n)), np.zeros((n, n)), 5000., [1e-7] * 3,
+                                                    kernel_size=5, free_prop_cm=1e-4)
+            store['prj'] = prj.astype('complex64')
+            g10['prj'] = store['prj']
+            cases = {'a': dict(alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11, n_epochs=2, seed=7),
+                     'b': dict(alpha=1e-8, alpha_d=None, alpha_b=None, gamma=0., n_epochs=1, seed=3)}      # quirk Q6 branch
+            for tag, kw in cases.items():
+                np.random.seed(kw.pop('seed'))                        # the schedule is shuffled from the global state (:196-197)
+                written.clear()
+                with contextlib.redirect_stdout(io.StringIO()):
+                    ref_ff.reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, learning_rate=1e-7, minibatch_size=mb,
+                                                 energy_ev=5000, psize_cm=1e-7, free_prop_cm=1e-4, save_path='.', output_folder='out',
+                                                 initial_guess=[init_d.copy(), init_b.copy()], shrink_cycle=None, kernel_size=5, **kw)
+                g10['delta_' + tag] = np.asarray(written['delta_ds_1'], dtype=np.float64)
+                g10['beta_' + tag] = np.asarray(written['beta_ds_1'], dtype=np.float64)
+                print('case', tag, 'done: |delta - init| =', np.abs(g10['delta_' + tag] - init_d * mask).max())
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, 'g10_reconstruct_fullfield.npz'), **g10)
+    print('wrote g10')
+
+
 def main_h5():
     """G7: exchange/data files written by h5py 3.3.0 (run under /opt/conda/bin/python3.9)."""
     import h5py
@@ -244,5 +377,7 @@ if __name__ == '__main__':
         main_g8()
     elif '--g9' in sys.argv:
         main_g9()
+    elif '--g10' in sys.argv:
+        main_g10()
     else:
         main()
