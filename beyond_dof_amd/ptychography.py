@@ -38,6 +38,25 @@ def epoch_schedule(n_theta, n_pos, minibatch_size, rng):
     return np.concatenate(rows, axis=0)
 
 
+def batches_of_epoch(n_theta, n_pos, minibatch_size, size, rank, rng):
+    """[(i_theta, sorted position indices of this rank)] of one epoch, cnn_propagator/ptychography.py:253-297: the epoch's
+    (theta, position) list in chunks of size * minibatch_size; a short chunk is topped up from the first one; the NUMBER of
+    chunks that are run is ceil(n_theta * n_pos / (size * minibatch_size)) — counted from the un-padded number of spots
+    (:257-260), so when n_pos is not a multiple of the minibatch the tail of the padded list is never visited; the angle is
+    the one of the rank's first entry.  Pinned by golden vector G11 (the reference's own loop executed)."""
+    n_tot = minibatch_size * size
+    chunks = split_tasks(epoch_schedule(n_theta, n_pos, minibatch_size, rng), n_tot)
+    n_batch = int(np.ceil(float(n_theta * n_pos) / n_tot))
+    out = []
+    for i_batch in range(n_batch):
+        chunk = chunks[i_batch]
+        if len(chunk) < n_tot:
+            chunk = np.concatenate([chunk, chunks[0][:n_tot - len(chunk)]])
+        mine = chunk[rank * minibatch_size:(rank + 1) * minibatch_size]
+        out.append((int(chunk[rank * minibatch_size, 0]), np.sort(mine[:, 1])))
+    return out
+
+
 def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0, theta_end=PI, theta_downsample=None,
                              n_epochs='auto', crit_conv_rate=0.03, max_nepochs=200,
                              alpha=1e-7, alpha_d=None, alpha_b=None, gamma=1e-6, learning_rate=1.0,
@@ -150,19 +169,12 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
             create_summary(output_folder, locals(), preset='ptycho')
 
         rng = np.random.RandomState(seed)
-        n_tot_per_batch = minibatch_size * size
         i_epoch, cont = 0, True
         while cont:
             t0 = time.time()
-            ind_list_rand = split_tasks(epoch_schedule(n_theta, n_pos, minibatch_size, rng), n_tot_per_batch)
+            batches = batches_of_epoch(n_theta, n_pos, minibatch_size, size, rank, rng)
             solver.reset_moments()                          # m, v = (None, None), ptychography.py:262
-            for i_batch in range(len(ind_list_rand)):
-                if len(ind_list_rand[i_batch]) < n_tot_per_batch:
-                    n_supp = n_tot_per_batch - len(ind_list_rand[i_batch])
-                    ind_list_rand[i_batch] = np.concatenate([ind_list_rand[i_batch], ind_list_rand[0][:n_supp]])
-                this_ind_batch = ind_list_rand[i_batch]
-                this_i_theta = this_ind_batch[rank * minibatch_size, 0]
-                this_ind_rank = np.sort(this_ind_batch[rank * minibatch_size:(rank + 1) * minibatch_size, 1])
+            for i_batch, (this_i_theta, this_ind_rank) in enumerate(batches):
                 this_prj_batch = None
                 if not resident:
                     this_prj_batch = np.abs(prj[int(prj_theta_ind[this_i_theta]), this_ind_rank.tolist()])

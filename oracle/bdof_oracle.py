@@ -350,9 +350,11 @@ def ptycho_pad_amounts(probe_pos, probe_size, obj_size):
 
 
 def ptycho_loss_and_grad(obj_delta, obj_beta, coord_old, probe_pos_all, this_pos_batch, this_prj_batch,
-                         probe_real, probe_imag, probe_size, energy_ev, psize_cm, variant='numpy_skip_last', pi=PI):
-    """Loss of cnn_propagator/ptychography.py:30-81 with the FFT forward, far field ('inf'),
-    and its gradient w.r.t. the un-rotated (delta, beta)."""
+                         probe_real, probe_imag, probe_size, energy_ev, psize_cm, variant='numpy_skip_last', pi=PI,
+                         propagator='fft', kernel_size=17):
+    """Loss of cnn_propagator/ptychography.py:30-81, far field ('inf'), and its gradient w.r.t. the un-rotated (delta, beta).
+    propagator='fft': the transfer-function forward of np_funcs.py (the north-star path); 'conv': the real-space propagator the
+    reference function literally calls (:74-76, kernel_size 17) — the form golden vector G11 pins."""
     obj_size = obj_delta.shape
     obj_stack = np.stack([obj_delta, obj_beta], axis=3)
     obj_rot = apply_rotation(obj_stack, coord_old)
@@ -364,8 +366,13 @@ def ptycho_loss_and_grad(obj_delta, obj_beta, coord_old, probe_pos_all, this_pos
         p1 = int(pos[1]) + pad[1, 0]
         subs.append(obj_pad[p0 - half[0]:p0 - half[0] + probe_size[0], p1 - half[1]:p1 - half[1] + probe_size[1]])
     subs = np.stack(subs)
-    loss, gd_sub, gb_sub = multislice_loss_and_grad(subs[..., 0], subs[..., 1], probe_real, probe_imag, energy_ev,
-                                                    psize_cm, np.abs(this_prj_batch), 'inf', variant, pi)
+    if propagator == 'conv':
+        loss, gd_sub, gb_sub = cnn_loss_and_grad(subs[..., 0], subs[..., 1], probe_real, probe_imag, energy_ev,
+                                                 [psize_cm] * 3 if np.isscalar(psize_cm) else psize_cm, np.abs(this_prj_batch),
+                                                 kernel_size=kernel_size, free_prop_cm='inf')
+    else:
+        loss, gd_sub, gb_sub = multislice_loss_and_grad(subs[..., 0], subs[..., 1], probe_real, probe_imag, energy_ev,
+                                                        psize_cm, np.abs(this_prj_batch), 'inf', variant, pi)
     g_pad = np.zeros(obj_pad.shape)
     for b, pos in enumerate(this_pos_batch):
         p0 = int(pos[0]) + pad[0, 0]

@@ -6,7 +6,8 @@ Run only in the build container (needs /root/reference, which never travels):
     /opt/conda/bin/python3.9 tests/golden/make_golden.py --h5   # G7 (h5py 3.3.0 lives there)
     python tests/golden/make_golden.py --g8       # G8 (get_kernel_ir, upsample_2x)
     python tests/golden/make_golden.py --g9       # G9 (propagation.multislice_propagate_cnn, the real-space propagator)
-    python tests/golden/make_golden.py --g10      # G10 (fullfield.reconstruct_fullfield: the whole loop, ~2 min)
+    python tests/golden/make_golden.py --g10      # G10 (fullfield.reconstruct_fullfield: the whole loop, ~1 min)
+    python tests/golden/make_golden.py --g11      # G11 (ptychography.reconstruct_ptychography: the whole loop, ~10 min)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -23,6 +24,9 @@ file traffic, and autograd.grad — reverse-mode differentiation by HIPS autogra
 finite differences of the reference's own calculate_loss (1024 variables, relative accuracy ~1e-8).  The vector pins the
 loop itself: minibatch schedule from the global numpy seed, per-epoch Adam restart, mask, clip, regulariser variants
 (incl. quirk Q6), the order of all of it — with the reference's own forward model, rotation and Adam underneath.
+G11 does the same for ptychography.reconstruct_ptychography (10^3 object, 18 x 18 gaussian probe, 3 positions x 2 angles,
+minibatches of 2): additionally mpi4py's COMM_WORLD is a one-rank stand-in and the module's clock is frozen, because the
+function seeds numpy from int(time.time() / 60) right before it draws the epoch's schedule.
 The fixtures are data only (inputs + outputs); no reference source is stored.
 """
 import os
@@ -348,6 +352,133 @@ def main_g10():
     print('wrote g10')
 
 
+def _fd_grad(fn, argnums):
+    """Stand-in for autograd.grad(fn, [0, 1]): float64 central differences, one variable at a time."""
+    import contextlib
+    import io
+    assert list(argnums) == [0, 1]
+
+    def g(obj_delta, obj_beta, *rest):
+        out = []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for which in (0, 1):
+                args = [np.array(obj_delta, dtype=np.float64), np.array(obj_beta, dtype=np.float64)]
+                gr = np.zeros_like(args[which])
+                h = 1e-9 if which == 0 else 1e-10
+                it = np.nditer(args[which], flags=['multi_index'])
+                for _ in it:
+                    i = it.multi_index
+                    keep = args[which][i]
+                    args[which][i] = keep + h
+                    lp = fn(args[0], args[1], *rest)
+                    args[which][i] = keep - h
+                    lm = fn(args[0], args[1], *rest)
+                    args[which][i] = keep
+                    gr[i] = (lp - lm) / (2 * h)
+                out.append(gr)
+        return tuple(out)
+    return g
+
+
+def main_g11():
+    """G11: reconstruct_ptychography (cnn_propagator/ptychography.py:19-365), the whole loop, on a 10^3 object."""
+    import contextlib
+    import io
+    import tempfile
+    autograd = _setup_conv_reference()
+    autograd.grad = _fd_grad
+
+    class _Comm(object):
+        def Get_size(self):
+            return 1
+
+        def Get_rank(self):
+            return 0
+
+        def Barrier(self):
+            pass
+
+        def Allreduce(self, src, dst):
+            dst[...] = src
+
+    mpi4py = types.ModuleType('mpi4py')
+    mpi4py.MPI = types.SimpleNamespace(COMM_WORLD=_Comm())
+    sys.modules['mpi4py'] = mpi4py
+    import propagation as ref_prop
+    ref_prop.trange = range
+    import ptychography as ref_pt
+    ref_pt.trange = range
+    frozen = types.SimpleNamespace(time=lambda: 42 * 60.0 + 1.0)      # seed = int(time.time() / 60) = 42  (:165-166)
+    ref_pt.time = frozen
+
+    n, n_theta, psz, mb = 10, 2, (18, 18), 2
+    pos = [(3, 4), (6, 5), (5, 7)]                                    # 3 positions, minibatches of 2: the padding quirk is exercised
+    rng = np.random.default_rng(11)
+    true_d = np.zeros((n, n, n))
+    true_d[2:8, 2:8, 2:8] = rng.uniform(2e-6, 6e-6, size=(6, 6, 6))
+    true_b = 0.1 * true_d
+    init_d = np.clip(rng.normal(3e-6, 1e-6, size=(n, n, n)), 0, None)
+    init_b = np.clip(rng.normal(3e-7, 1e-7, size=(n, n, n)), 0, None)
+    kw = dict(probe_mag_sigma=4., probe_phase_sigma=4., probe_phase_max=0.5)
+    store, written = {}, {}
+
+    class _Dataset(object):
+        def __init__(self, arr):
+            self.arr = arr
+            self.shape = arr.shape
+
+        def __getitem__(self, key):
+            return self.arr[key]
+
+    class _File(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def __getitem__(self, key):
+            assert key == 'exchange/data'
+            return _Dataset(store['prj'])
+
+    ref_pt.h5py.File = _File
+    dx = sys.modules['dxchange']
+    dx.write_tiff = lambda arr, fname=None, dtype=None, overwrite=False: written.__setitem__(os.path.basename(fname), np.array(arr))
+
+    g11 = {'true_delta': true_d, 'true_beta': true_b, 'init_delta': init_d, 'init_beta': init_b, 'probe_pos': np.array(pos),
+           'probe_size': np.array(psz)}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            # the data: the reference's own window cut + forward model, evaluated through its calculate_loss ingredients
+            ref_pt.save_rotation_lookup([n, n, n], n_theta)
+            folder = 'arrsize_{0}_{0}_{0}_ntheta_{1}'.format(n, n_theta)
+            coords = ref_pt.read_all_origin_coords(folder, n_theta)
+            py = np.arange(psz[0]) - (psz[0] - 1.) / 2
+            px = np.arange(psz[1]) - (psz[1] - 1.) / 2
+            pxx, pyy = np.meshgrid(px, py)
+            pr, pi_ = ref_pt.mag_phase_to_real_imag(np.exp(-(pxx ** 2 + pyy ** 2) / (2 * 4. ** 2)), 0.5 * np.exp(-(pxx ** 2 + pyy ** 2) / (2 * 4. ** 2)))
+            half = (np.array(psz) / 2).astype('int')
+            prj = np.zeros((n_theta, len(pos), psz[0], psz[1]), dtype='complex64')
+            for t in range(n_theta):
+                rot = ref_pt.apply_rotation(np.stack([true_d, true_b], axis=3), coords[t], folder)
+                rot = np.pad(rot, ((half[0], half[0]), (half[1], half[1]), (0, 0), (0, 0)), mode='constant')
+                subs = np.stack([rot[p[0]:p[0] + psz[0], p[1]:p[1] + psz[1]] for p in pos])     # window starts at pos - half in the un-padded frame
+                prj[t] = ref_prop.multislice_propagate_cnn(subs[..., 0], subs[..., 1], pr, pi_, 5000., [1e-7] * 3, free_prop_cm='inf')
+            store['prj'] = prj
+            g11['prj'] = prj
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref_pt.reconstruct_ptychography('data.h5', [tuple(p) for p in pos], psz, (n, n, n), theta_st=0, theta_end=2 * np.pi, n_epochs=2,
+                                                learning_rate=2e-7, minibatch_size=mb, energy_ev=5000, psize_cm=1e-7, save_path='.',
+                                                output_folder='out', initial_guess=[init_d.copy(), init_b.copy()], probe_type='gaussian',
+                                                dynamic_dropping=False, **kw)
+            g11['delta'] = np.asarray(written['delta_ds_1'], dtype=np.float64)
+            g11['beta'] = np.asarray(written['beta_ds_1'], dtype=np.float64)
+            print('done: |delta - init| max =', np.abs(g11['delta'] - init_d).max())
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, 'g11_reconstruct_ptychography.npz'), **g11)
+    print('wrote g11')
+
+
 def main_h5():
     """G7: exchange/data files written by h5py 3.3.0 (run under /opt/conda/bin/python3.9)."""
     import h5py
@@ -379,5 +510,7 @@ if __name__ == '__main__':
         main_g9()
     elif '--g10' in sys.argv:
         main_g10()
+    elif '--g11' in sys.argv:
+        main_g11()
     else:
         main()

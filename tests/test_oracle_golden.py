@@ -173,3 +173,30 @@ def test_g10_reconstruct_fullfield_loop(golden_dir, tag, n_epochs, seed, reg):
         # regulariser term lifts small gradients above the differences' round-off), typically 1e-6
         assert np.abs(got - want).max() <= 1e-3 * lr, (key, np.abs(got - want).max() / lr)
         assert np.sqrt(np.mean((got - want) ** 2)) <= 2e-5 * lr
+
+
+def test_g11_reconstruct_ptychography_loop(golden_dir):
+    """The reference's own reconstruct_ptychography executed (make_golden.py --g11: 10^3 object, 18 x 18 gaussian probe,
+    3 positions x 2 angles, minibatches of 2, two epochs, seed 42 through the frozen clock; autograd.grad stood in by
+    central differences).  The product's schedule (ptychography.epoch_schedule / batches_of_epoch) driving the oracle's
+    window cut, real-space forward, gradient, Adam and clip lands on the reference's volume — including the quirks of
+    the padded position lists and of the batch count taken from the UNPADDED number of spots (:257-260,269-282)."""
+    from beyond_dof_amd.ptychography import batches_of_epoch
+    g = np.load(os.path.join(golden_dir, 'g11_reconstruct_ptychography.npz'))
+    n, n_theta, mb, lr = g['init_delta'].shape[0], g['prj'].shape[0], 2, 2e-7
+    pos, psz = g['probe_pos'], tuple(int(v) for v in g['probe_size'])
+    coords = orc.rotation_lookup([n, n, n], n_theta)
+    pr, pi_ = orc.gaussian_probe(psz, 4., 4., 0.5)
+    x = np.array([g['init_delta'], g['init_beta']])
+    rng = np.random.RandomState(42)
+    for _ in range(2):
+        m = v = None
+        for i_batch, (i_theta, ind) in enumerate(batches_of_epoch(n_theta, len(pos), mb, 1, 0, rng)):
+            _, gd, gb = orc.ptycho_loss_and_grad(x[0], x[1], coords[i_theta], pos, pos[ind], g['prj'][i_theta, ind], pr, pi_, psz,
+                                                 5000., 1e-7, propagator='conv', kernel_size=17)
+            x, m, v = orc.apply_gradient_adam(x, np.array([gd, gb]), i_batch, m, v, step_size=lr)
+            x = np.clip(x, 0, None)
+    for got, key in ((x[0], 'delta'), (x[1], 'beta')):
+        assert np.abs(g[key] - g['init_' + key]).max() >= 0.9 * lr
+        assert np.abs(got - g[key]).max() <= 1e-3 * lr, (key, np.abs(got - g[key]).max() / lr)
+        assert np.sqrt(np.mean((got - g[key]) ** 2)) <= 2e-5 * lr
