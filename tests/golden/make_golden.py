@@ -7,7 +7,8 @@ Run only in the build container (needs /root/reference, which never travels):
     python tests/golden/make_golden.py --g8       # G8 (get_kernel_ir, upsample_2x)
     python tests/golden/make_golden.py --g9       # G9 (propagation.multislice_propagate_cnn, the real-space propagator)
     python tests/golden/make_golden.py --g10      # G10 (fullfield.reconstruct_fullfield: the whole loop, ~1 min)
-    python tests/golden/make_golden.py --g11      # G11 (ptychography.reconstruct_ptychography: the whole loop, ~10 min)
+    python tests/golden/make_golden.py --g11      # G11 (ptychography.reconstruct_ptychography: the whole loop, ~4 min)
+    python tests/golden/make_golden.py --g12      # G12 (simulation.create_fullfield_data_numpy / create_ptychography_data_batch_numpy)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -479,6 +480,98 @@ def main_g11():
     print('wrote g11')
 
 
+def main_g12():
+    """G12: the dataset simulators (simulation.py:80-161,283-386).  cnn_propagator/simulation.py imports a module `npfuncs`
+    that only tensorflow_recon/ holds; the two simulation.py are identical in these functions, so the TF twin's directory —
+    simulation.py, util.py, npfuncs.py side by side — is the one imported (tensorflow and tensorflow.contrib.image are empty
+    stand-ins: the numpy simulators never touch them; h5py is an in-memory stand-in that keeps what is written)."""
+    import contextlib
+    import io
+    import tempfile
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    written = {}
+
+    class _Dataset(object):
+        def __init__(self, shape, dtype):
+            self.arr = np.zeros(shape, dtype=dtype)
+
+        def __setitem__(self, key, val):
+            self.arr[key] = val
+
+    class _Group(object):
+        def __init__(self, fname):
+            self.fname = fname
+
+        def create_dataset(self, name, shape=None, dtype=None):
+            d = _Dataset(shape, dtype)
+            written[os.path.basename(self.fname)] = d
+            return d
+
+    class _File(object):
+        def __init__(self, fname, mode='r'):
+            self.fname = fname
+
+        def create_group(self, name):
+            return _Group(self.fname)
+
+        def close(self):
+            pass
+
+    stub('dxchange', write_tiff=lambda *a, **k: None)
+    stub('h5py', File=_File)
+    tf = stub('tensorflow')
+    contrib = stub('tensorflow.contrib')
+    image = stub('tensorflow.contrib.image', rotate=lambda *a, **k: None)
+    tf.contrib, contrib.image = contrib, image
+    import matplotlib
+    matplotlib.use = lambda *a, **k: None
+    if not hasattr(np, 'int'):
+        np.int = int
+    sys.path.insert(0, '/root/reference/tensorflow_recon')
+    import simulation as sim
+    sim.tqdm = lambda x: x
+
+    n = 16
+    rng = np.random.default_rng(12)
+    z, y, x = np.mgrid[:n, :n, :n].astype(np.float64)
+    d = np.zeros((n, n, n))
+    for _ in range(4):
+        c = rng.uniform(5, 11, size=3)
+        r = rng.uniform(1.5, 3.0)
+        d += 4e-6 * np.exp(-((z - c[0]) ** 2 + (y - c[1]) ** 2 + (x - c[2]) ** 2) / (2 * r ** 2))
+    g12 = {'grid_delta': d, 'grid_beta': 0.1 * d}
+    pos = [(4, 4), (8, 9), (12, 6), (15, 15)]
+    g12['probe_pos'] = np.array(pos)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            os.makedirs('phantom')
+            np.save('phantom/grid_delta.npy', d)
+            np.save('phantom/grid_beta.npy', 0.1 * d)
+            with contextlib.redirect_stdout(io.StringIO()):
+                sim.create_fullfield_data_numpy(5000., 1e-7, 1e-4, 3, 'phantom', '.', 'ff_plane.h5', batch_size=2, probe_type='plane',
+                                                theta_st=0, theta_end=2 * np.pi)
+                sim.create_fullfield_data_numpy(5000., 1e-7, None, 2, 'phantom', '.', 'ff_gauss.h5', batch_size=1, probe_type='gaussian',
+                                                theta_st=0, theta_end=np.pi, probe_mag_sigma=4., probe_phase_sigma=4., probe_phase_max=0.5)
+                sim.create_ptychography_data_batch_numpy(5000., 1e-7, 2, 'phantom', '.', 'pt.h5', pos, probe_type='gaussian', probe_size=(8, 8),
+                                                         theta_st=0, theta_end=2 * np.pi, probe_circ_mask=None, minibatch_size=3,
+                                                         probe_mag_sigma=2., probe_phase_sigma=2., probe_phase_max=0.5)
+        finally:
+            os.chdir(cwd)
+    for k, v in written.items():
+        g12[k.replace('.h5', '')] = v.arr
+        print(k, v.arr.shape, v.arr.dtype, np.abs(v.arr).max())
+    np.savez_compressed(os.path.join(HERE, 'g12_simulators.npz'), **g12)
+    print('wrote g12')
+
+
 def main_h5():
     """G7: exchange/data files written by h5py 3.3.0 (run under /opt/conda/bin/python3.9)."""
     import h5py
@@ -512,5 +605,7 @@ if __name__ == '__main__':
         main_g10()
     elif '--g11' in sys.argv:
         main_g11()
+    elif '--g12' in sys.argv:
+        main_g12()
     else:
         main()
