@@ -427,11 +427,12 @@ static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* t
 
 // Real-space detector on L1 rows.  Returns the grid (= number of partial sums when meas != null).
 static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool tstore, cf* out_wave, const float* meas,
-                            float in_scale, float out_scale, float seed_scale, cf carrier, const cf* pfield = nullptr) {
+                            float in_scale, float out_scale, float seed_scale, cf carrier, const cf* pfield = nullptr,
+                            const float* dref_override = nullptr) {
     ProfScope ps(c, BDOF_K_LOSS);
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NX,
                in_scale, out_scale, seed_scale, carrier, c->twY, pfield, c->meas_dev, nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0),
-               c->meas_dev ? meas_dref(c) : 0.f};
+               c->meas_dev ? (dref_override ? *dref_override : meas_dref(c)) : 0.f};
     int grid = 0;
     DISPATCH_N(c->NY, {
         grid = rows_grid<N_>(c, B, c->NX);
@@ -1621,10 +1622,10 @@ int bdof_forward_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff
     const int egrid = (int)std::min<size_t>((n + 255) / 256, (size_t)c->ncu * 16);
     const cf zero = make_float2(0.f, 0.f);
     if (c->det_mode == BDOF_DET_NONE) {
-        ConvFinalArgs fa{c->bufB, (cf*)out_wave, nullptr, nullptr, nullptr, c->conv_scal, conv_carrier(c, c->S), n, 0.f};
+        ConvFinalArgs fa{c->bufB, (cf*)out_wave, nullptr, nullptr, nullptr, c->conv_scal, conv_carrier(c, c->S), n, 0.f, 0, make_float2(0.f, 0.f), 0.f, 0.f};
         hipLaunchKernelGGL((k_conv_final<0>), dim3(egrid), dim3(256), 0, c->stream, fa);
     } else {
-        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, conv_carrier(c, c->S), n, 0.f};
+        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, conv_carrier(c, c->S), n, 0.f, 0, make_float2(0.f, 0.f), 0.f, 0.f};
         hipLaunchKernelGGL((k_conv_final<0>), dim3(egrid), dim3(256), 0, c->stream, fa);
         RealToHybArgs ra{c->bufA, c->bufC, B, c->NX, c->twY};
         DISPATCH_N(c->NY, { hipLaunchKernelGGL((k_row_real_to_hyb<N_>), dim3(rows_grid<N_>(c, B, c->NX)), dim3(BDOF_THREADS), 0, c->stream, ra); });
@@ -1646,7 +1647,12 @@ int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xo
     int r = conv_check(c, B, angle_of_b);
     if (r) return r;
     if (!meas) return BDOF_ERR_ARG;
-    if (c->meas_dev) return fail(c, BDOF_ERR_STATE, "bdof_set_meas_mode(1) applies to the transfer-function path only");
+    // residual splitting at the detector (bdof_set_meas_mode(1): meas holds m - |a_0|), real-space detectors: the renormalised
+    // wave is kept as A + e', A = s a_S a float64 scalar formed on the host from the corner pixel, and |A + e'| - m is
+    // evaluated without the cancellation of two numbers of size one (loss_seed_dev) — as on the transfer-function path
+    const bool split = c->meas_dev != 0;
+    if (split && (c->det_mode == BDOF_DET_FAR || std::abs(c->a0) == 0.0))
+        return fail(c, BDOF_ERR_STATE, "bdof_set_meas_mode(1) needs a plane-wave carrier and a real-space detector");
     if (!c->with_grad) return fail(c, BDOF_ERR_STATE, "bdof_loss_grad_conv needs bdof_configure(with_grad=1)");
     c->gpsi_src = nullptr;                   // the real-space propagator does not export the probe gradient
     HIPC(c, hipSetDevice(c->device));
@@ -1661,19 +1667,36 @@ int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xo
     const cf zero = make_float2(0.f, 0.f);
     cf* gp;
     int npart;
+    cf carA = zero;                 // split: A (times Hdet[0,0] for the near detector), the constant part of the detector wave
+    float absA = 0.f, dref = 0.f;
+    if (split) {
+        cf e0, p0;                  // corner pixel of batch element 0: scattered part of psi_S and of the probe
+        HIPC(c, hipMemcpyAsync(&e0, c->bufB, sizeof(cf), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipMemcpyAsync(&p0, c->probe, sizeof(cf), hipMemcpyDeviceToHost, c->stream));
+        HIPC(c, hipStreamSynchronize(c->stream));
+        const std::complex<double> aS = c->a0 * std::pow(c->ksum, c->S);
+        const std::complex<double> sd = (c->a0 + std::complex<double>(p0.x, p0.y)) / (aS + std::complex<double>(e0.x, e0.y));
+        std::complex<double> A = sd * aS;
+        if (c->det_mode == BDOF_DET_NEAR) A *= c->hdet00;
+        carA = make_float2((float)A.real(), (float)A.imag());
+        absA = (float)std::abs(A);
+        dref = (float)(std::abs(A) - std::abs(c->a0));
+    }
+    const cf car_end = split ? zero : conv_carrier(c, c->S);       // split: only the scattered part e' = s eps goes on
     if (c->det_mode == BDOF_DET_NONE) {
-        ConvFinalArgs fa{c->bufB, (cf*)out_wave, c->bufA, meas, c->partial, c->conv_scal, conv_carrier(c, c->S), n, (float)seed_scale};
+        ConvFinalArgs fa{c->bufB, (cf*)out_wave, c->bufA, meas, c->partial, c->conv_scal, car_end, n, (float)seed_scale, split ? 1 : 0, carA, absA, dref};
         hipLaunchKernelGGL((k_conv_final<1>), dim3(egrid), dim3(256), 0, c->stream, fa);
         npart = egrid;
         gp = c->bufA;
     } else {
-        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, conv_carrier(c, c->S), n, 0.f};
+        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, car_end, n, 0.f, 0, zero, 0.f, 0.f};
         hipLaunchKernelGGL((k_conv_final<0>), dim3(egrid), dim3(256), 0, c->stream, fa);
         RealToHybArgs ra{c->bufA, c->bufC, B, c->NX, c->twY};
         DISPATCH_N(c->NY, { hipLaunchKernelGGL((k_row_real_to_hyb<N_>), dim3(rows_grid<N_>(c, B, c->NX)), dim3(BDOF_THREADS), 0, c->stream, ra); });
         if (c->det_mode == BDOF_DET_NEAR) {
             launch_row_prop(c, B, c->bufC, c->bufA, c->hdet, 1.f, 0);                                     // d_hat (L1)
-            npart = launch_loss_real(c, B, c->bufA, c->bufC, true, (cf*)out_wave, meas, 1.f, 1.f, (float)seed_scale, zero);
+            npart = launch_loss_real(c, B, c->bufA, c->bufC, true, (cf*)out_wave, meas, 1.f, 1.f, (float)seed_scale, carA, nullptr,
+                                     split ? &dref : nullptr);
             launch_row_prop(c, B, c->bufC, c->bufA, c->hdet, 1.f, 1);                                     // g_hat(q) (L1)
         } else {
             const std::complex<double> keep = c->a0;

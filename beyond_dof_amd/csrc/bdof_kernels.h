@@ -1659,9 +1659,14 @@ struct ConvFinalArgs {
     const float* meas;   // MODE 1
     double* partial;     // MODE 1: [2 * gridDim.x]: sum r^2, sum r |d|
     const cf* scal;
-    cf carrier_end;
+    cf carrier_end;      // a_S; zero when `split` (only the scattered part e' = s eps is formed)
     size_t n;
     float seed_scale;
+    // MODE 1 with residual splitting (bdof_set_meas_mode(1)): d = A + e', A = s a_S from the host in float64, meas = m - |a_0|,
+    // dref = |A| - |a_0|
+    int split;
+    cf A;
+    float absA, dref;
 };
 template <int MODE>
 __global__ __launch_bounds__(256) void k_conv_final(ConvFinalArgs a) {
@@ -1669,6 +1674,13 @@ __global__ __launch_bounds__(256) void k_conv_final(ConvFinalArgs a) {
     double acc = 0.0, acc2 = 0.0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.n; idx += (size_t)gridDim.x * blockDim.x) {
         const cf q = cmul(cadd(a.psi_eps[idx], a.carrier_end), s);
+        if constexpr (MODE == 1) {
+            if (a.split) {
+                if (a.out) a.out[idx] = cadd(q, a.A);
+                a.out2[idx] = cmulc(loss_seed_dev(q, a.A, a.absA, a.meas[idx], a.seed_scale, acc, acc2, a.dref), s);
+                continue;
+            }
+        }
         if (a.out) a.out[idx] = q;
         if constexpr (MODE == 1) {
             const float ab = sqrtf(q.x * q.x + q.y * q.y);

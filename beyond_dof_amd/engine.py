@@ -188,8 +188,7 @@ class MultisliceEngine(object):
         """Residual splitting at the detector (include/bdof.h, bdof_set_meas_mode): with a plane-wave carrier and a real-space
         detector the measured amplitudes go to the device as m - |a0|."""
         self.meas_ref = 0.0
-        if (a0 != 0 and self.det_mode != _lib.DET_FAR and not getattr(self, '_conv_set', False)
-                and not os.environ.get('BDOF_NO_RESIDUAL_SPLIT')):
+        if a0 != 0 and self.det_mode != _lib.DET_FAR and not os.environ.get('BDOF_NO_RESIDUAL_SPLIT'):
             self.meas_ref = abs(a0)
         self.ctx.check(self.lib.bdof_set_meas_mode(self.h, 1 if self.meas_ref else 0))
 

@@ -180,10 +180,11 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
         this_n_epochs = n_epochs
         if ds_level == 1 and n_epoch_final_pass is not None and multiscale_level > 1:
             this_n_epochs = n_epoch_final_pass
-        rng = np.random.RandomState(seed)
+        # the angles are shuffled ONCE per resolution level and every epoch walks the same minibatches
+        # (cnn_propagator/fullfield.py:196-203 sits outside the epoch loop; pinned by golden vectors G10 / G13)
+        ind_ls = minibatch_schedule(n_theta, size, minibatch_size, rng=np.random.RandomState(seed), shuffle=random_theta)
         i_epoch, last_loss, cont = 0, None, True
         while cont:
-            ind_ls = minibatch_schedule(n_theta, size, minibatch_size, rng=rng, shuffle=random_theta)
             solver.reset_moments()                                   # m, v = (None, None), fullfield.py:338
             use_mask = i_epoch < n_epochs_mask_release
             t0 = time.time()

@@ -9,6 +9,7 @@ Run only in the build container (needs /root/reference, which never travels):
     python tests/golden/make_golden.py --g10      # G10 (fullfield.reconstruct_fullfield: the whole loop, ~1 min)
     python tests/golden/make_golden.py --g11      # G11 (ptychography.reconstruct_ptychography: the whole loop, ~4 min)
     python tests/golden/make_golden.py --g12      # G12 (simulation.create_fullfield_data_numpy / create_ptychography_data_batch_numpy)
+    python tests/golden/make_golden.py --g13      # G13 (reconstruct_fullfield at a size the GPU's real-space kernels take)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -28,6 +29,10 @@ loop itself: minibatch schedule from the global numpy seed, per-epoch Adam resta
 G11 does the same for ptychography.reconstruct_ptychography (10^3 object, 18 x 18 gaussian probe, 3 positions x 2 angles,
 minibatches of 2): additionally mpi4py's COMM_WORLD is a one-rank stand-in and the module's clock is frozen, because the
 function seeds numpy from int(time.time() / 60) right before it draws the epoch's schedule.
+G13 runs reconstruct_fullfield once more at (Y, X, Z) = (64, 64, 64) with 17 taps — a size the HIP real-space kernels
+accept, so the product's entry point can be compared with the reference's loop DIRECTLY — where 524288 finite-difference
+variables are out of reach: there autograd.grad is stood in by the oracle's analytic gradient of the same loss (itself pinned
+by finite differences, torch autograd and, through G10, by this very loop at 8^3).
 The fixtures are data only (inputs + outputs); no reference source is stored.
 """
 import os
@@ -572,6 +577,103 @@ def main_g12():
     print('wrote g12')
 
 
+def main_g13():
+    """G13: reconstruct_fullfield at (64, 64, 64), kernel_size 17; gradient by the oracle's analytic adjoint.  Initial guess and
+    mask are formulas (g13_inputs.py); the reconstructed volumes are stored on every second voxel per axis, as float32."""
+    import contextlib
+    import io
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import bdof_oracle as orc
+    autograd = _setup_conv_reference()
+
+    def oracle_grad(fn, argnums):
+        assert list(argnums) == [0, 1]
+        cl = dict(zip(fn.__code__.co_freevars, [c.cell_contents for c in fn.__closure__]))
+
+        def g(obj_delta, obj_beta, this_ind_batch, this_prj_batch):
+            coords = cl['coord_ls']
+            rot = np.stack([orc.apply_rotation(np.stack([obj_delta, obj_beta], axis=3), coords[j]) for j in this_ind_batch])
+            _, gd_rot, gb_rot = orc.cnn_loss_and_grad(rot[..., 0], rot[..., 1], cl['probe_real'], cl['probe_imag'], cl['energy_ev'],
+                                                      [cl['psize_cm'] * cl['ds_level']] * 3, np.abs(this_prj_batch),
+                                                      kernel_size=cl['kernel_size'], free_prop_cm=cl['free_prop_cm'])
+            gd = sum(orc.apply_rotation_adjoint(gd_rot[b], coords[j]) for b, j in enumerate(this_ind_batch))
+            gb = sum(orc.apply_rotation_adjoint(gb_rot[b], coords[j]) for b, j in enumerate(this_ind_batch))
+            rd, rb = orc.regularizer_grad(obj_delta, obj_beta, alpha=cl['alpha'], alpha_d=cl['alpha_d'], alpha_b=cl['alpha_b'], gamma=cl['gamma'])
+            return gd + rd, gb + rb
+        return g
+
+    autograd.grad = oracle_grad
+    import propagation as ref_prop
+    ref_prop.trange = range
+    import fullfield as ref_ff
+    ref_ff.trange = range
+
+    sys.path.insert(0, HERE)
+    import g13_inputs
+    ny, nx, n_theta, mb = 64, 64, 4, 2
+    rng = np.random.default_rng(13)
+    yy, xx, zz = np.mgrid[:ny, :nx, :nx].astype(np.float64)
+    true_d = np.zeros((ny, nx, nx))
+    for _ in range(5):
+        c = (rng.uniform(16, 48), rng.uniform(20, 44), rng.uniform(20, 44))
+        r = rng.uniform(4, 8)
+        true_d += 3e-6 * np.exp(-((yy - c[0]) ** 2 + (xx - c[1]) ** 2 + (zz - c[2]) ** 2) / (2 * r ** 2))
+    true_b = 0.1 * true_d
+    mask = g13_inputs.mask()
+    init_d, init_b = g13_inputs.initial_guess()
+    store, written = {}, {}
+
+    class _Dataset(object):
+        def __init__(self, arr):
+            self.arr = arr
+
+        def __getitem__(self, key):
+            return self.arr[key]
+
+    class _File(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def __getitem__(self, key):
+            return _Dataset(store['prj'])
+
+    ref_ff.h5py.File = _File
+    dx = sys.modules['dxchange']
+    dx.read_tiff_stack = lambda fname, ind, digit=5: np.array(mask)
+    dx.read_tiff = lambda fname: np.array(mask)
+    dx.write_tiff = lambda arr, fname=None, dtype=None, overwrite=False: written.__setitem__(os.path.basename(fname), np.array(arr))
+    dx.write_tiff_stack = lambda *a, **k: None
+    g13 = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            ref_ff.save_rotation_lookup([ny, nx, nx], n_theta)
+            folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(ny, nx, nx, n_theta)
+            coords = ref_ff.read_all_origin_coords(folder, n_theta)
+            obj = np.stack([true_d, true_b], axis=3)
+            rot = np.stack([ref_ff.apply_rotation(obj, c, folder) for c in coords])
+            prj = ref_prop.multislice_propagate_cnn(rot[..., 0], rot[..., 1], np.ones((ny, nx)), np.zeros((ny, nx)), 5000., [1e-7] * 3,
+                                                    kernel_size=17, free_prop_cm=1e-4)
+            store['prj'] = prj.astype('complex64')
+            g13['prj'] = store['prj']
+            np.random.seed(5)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref_ff.reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, n_epochs=2, learning_rate=1e-7, minibatch_size=mb,
+                                             energy_ev=5000, psize_cm=1e-7, free_prop_cm=1e-4, save_path='.', output_folder='out',
+                                             initial_guess=[init_d.copy(), init_b.copy()], shrink_cycle=None, kernel_size=17,
+                                             alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)
+            g13['delta_sub'] = np.asarray(written['delta_ds_1'])[::2, ::2, ::2].astype(np.float32)
+            g13['beta_sub'] = np.asarray(written['beta_ds_1'])[::2, ::2, ::2].astype(np.float32)
+            g13['delta_moved_max'] = np.abs(np.asarray(written['delta_ds_1']) - init_d * mask).max()
+            print('done: |delta - init| max =', g13['delta_moved_max'])
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, 'g13_reconstruct_fullfield_64.npz'), **g13)
+    print('wrote g13')
+
+
 def main_h5():
     """G7: exchange/data files written by h5py 3.3.0 (run under /opt/conda/bin/python3.9)."""
     import h5py
@@ -607,5 +709,7 @@ if __name__ == '__main__':
         main_g11()
     elif '--g12' in sys.argv:
         main_g12()
+    elif '--g13' in sys.argv:
+        main_g13()
     else:
         main()
