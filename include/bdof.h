@@ -162,7 +162,8 @@ int bdof_probe_grad(bdof_ctx* ctx, void* out, int accumulate);
  * to bdof_set_probe; every transfer-function step has unit modulus at DC, so |a0| is the carrier's modulus at the detector
  * too).  The residual is then formed as (|a + e| - |a|) - (m - |a|) with |a + e| - |a| evaluated without cancellation —
  * three times more accurate gradients for plane-wave illumination.  Real-space detectors (none / near) and a scalar carrier
- * only; mode 0 (default): plain amplitudes. */
+ * only; mode 0 (default): plain amplitudes.  bdof_loss_grad_conv honours it too: there the constant part of the detector
+ * wave is A = s a_S with s the corner-pixel renormalisation of propagation.py:79,109-110, formed in float64 per call. */
 int bdof_set_meas_mode(bdof_ctx* ctx, int mode);
 
 /* Real-space truncated-kernel propagator: replaces multislice_propagate_cnn (cnn_propagator/propagation.py:18-133), the
