@@ -10,6 +10,7 @@ Run only in the build container (needs /root/reference, which never travels):
     python tests/golden/make_golden.py --g11      # G11 (ptychography.reconstruct_ptychography: the whole loop, ~4 min)
     python tests/golden/make_golden.py --g12      # G12 (simulation.create_fullfield_data_numpy / create_ptychography_data_batch_numpy)
     python tests/golden/make_golden.py --g13      # G13 (reconstruct_fullfield at a size the GPU's real-space kernels take)
+    python tests/golden/make_golden.py --g14      # G14 (reconstruct_ptychography likewise: 64 x 64 probe, 64^3 object)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -674,6 +675,125 @@ def main_g13():
     print('wrote g13')
 
 
+def main_g14():
+    """G14: reconstruct_ptychography with a 64 x 64 gaussian probe on a (64, 64, 64) object, 4 positions x 2 angles, minibatches
+    of 2, two epochs; gradient by the oracle's analytic adjoint (as G13).  Volumes stored on every second voxel, float32."""
+    import contextlib
+    import io
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import bdof_oracle as orc
+    autograd = _setup_conv_reference()
+
+    def oracle_grad(fn, argnums):
+        assert list(argnums) == [0, 1]
+        cl = dict(zip(fn.__code__.co_freevars, [c.cell_contents for c in fn.__closure__]))
+
+        def g(obj_delta, obj_beta, this_i_theta, this_pos_batch, this_prj_batch):
+            _, gd, gb = orc.ptycho_loss_and_grad(obj_delta, obj_beta, cl['coord_ls'][this_i_theta], cl['probe_pos'], this_pos_batch,
+                                                 this_prj_batch, cl['probe_real'], cl['probe_imag'], tuple(cl['probe_size']), cl['energy_ev'],
+                                                 cl['psize_cm'] * cl['ds_level'], propagator='conv', kernel_size=17)
+            return gd, gb
+        return g
+
+    autograd.grad = oracle_grad
+
+    class _Comm(object):
+        def Get_size(self):
+            return 1
+
+        def Get_rank(self):
+            return 0
+
+        def Barrier(self):
+            pass
+
+        def Allreduce(self, src, dst):
+            dst[...] = src
+
+    mpi4py = types.ModuleType('mpi4py')
+    mpi4py.MPI = types.SimpleNamespace(COMM_WORLD=_Comm())
+    sys.modules['mpi4py'] = mpi4py
+    import propagation as ref_prop
+    ref_prop.trange = range
+    import ptychography as ref_pt
+    ref_pt.trange = range
+    ref_pt.time = types.SimpleNamespace(time=lambda: 42 * 60.0 + 1.0)          # seed 42
+
+    obj_size, psz, n_theta, mb = (64, 64, 64), (64, 64), 2, 2     # X = Z: the reference's lookup tables are only sound for square (x, z)
+    pos = [(20, 22), (24, 40), (42, 26), (40, 44)]
+    yy, xx, zz = np.mgrid[:obj_size[0], :obj_size[1], :obj_size[2]].astype(np.float64)
+    rng = np.random.default_rng(14)
+    true_d = np.zeros(obj_size)
+    for _ in range(5):
+        c = (rng.uniform(16, 48), rng.uniform(16, 48), rng.uniform(16, 48))
+        r = rng.uniform(3, 7)
+        true_d += 3e-6 * np.exp(-((yy - c[0]) ** 2 + (xx - c[1]) ** 2 + (zz - c[2]) ** 2) / (2 * r ** 2))
+    true_b = 0.1 * true_d
+    sys.path.insert(0, HERE)
+    import g13_inputs
+    init_d, init_b = g13_inputs.initial_guess(obj_size)
+    # a wide probe: the real-space propagator pads with the constant 1 and renormalises by the corner pixel
+    # (propagation.py:79,91,109-110), so a probe that has decayed at the window's corner is scaled to nothing
+    kw = dict(probe_mag_sigma=40., probe_phase_sigma=40., probe_phase_max=0.5)
+    store, written = {}, {}
+
+    class _Dataset(object):
+        def __init__(self, arr):
+            self.arr = arr
+            self.shape = arr.shape
+
+        def __getitem__(self, key):
+            return self.arr[key]
+
+    class _File(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def __getitem__(self, key):
+            return _Dataset(store['prj'])
+
+    ref_pt.h5py.File = _File
+    dx = sys.modules['dxchange']
+    dx.write_tiff = lambda arr, fname=None, dtype=None, overwrite=False: written.__setitem__(os.path.basename(fname), np.array(arr))
+    g14 = {'probe_pos': np.array(pos), 'probe_size': np.array(psz), 'obj_size': np.array(obj_size)}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            n = obj_size
+            ref_pt.save_rotation_lookup(list(n), n_theta)
+            folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(n[0], n[1], n[2], n_theta)
+            coords = ref_pt.read_all_origin_coords(folder, n_theta)
+            pr, pi_ = orc.gaussian_probe(psz, 40., 40., 0.5)
+            half = (np.array(psz) / 2).astype('int')
+            prj = np.zeros((n_theta, len(pos), psz[0], psz[1]), dtype='complex64')
+            for t in range(n_theta):
+                rot = ref_pt.apply_rotation(np.stack([true_d, true_b], axis=3), coords[t], folder)
+                rot = np.pad(rot, ((half[0], half[0]), (half[1], half[1]), (0, 0), (0, 0)), mode='constant')
+                subs = np.stack([rot[p[0]:p[0] + psz[0], p[1]:p[1] + psz[1]] for p in pos])
+                prj[t] = ref_prop.multislice_propagate_cnn(subs[..., 0], subs[..., 1], pr, pi_, 5000., [1e-7] * 3, free_prop_cm='inf')
+            # 2 % amplitude noise: a noise-free far-field pattern of this weak object differs from the initial guess's by 4e-6 of
+            # its size, a residual no float32 detector wave can resolve (measured data are not like that)
+            prj = (prj * (1 + 0.02 * rng.normal(size=prj.shape))).astype('complex64')
+            store['prj'] = prj
+            g14['prj'] = prj
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref_pt.reconstruct_ptychography('data.h5', [tuple(p) for p in pos], psz, obj_size, theta_st=0, theta_end=2 * np.pi, n_epochs=2,
+                                                learning_rate=2e-7, minibatch_size=mb, energy_ev=5000, psize_cm=1e-7, save_path='.',
+                                                output_folder='out', initial_guess=[init_d.copy(), init_b.copy()], probe_type='gaussian',
+                                                dynamic_dropping=False, **kw)
+            full_d = np.asarray(written['delta_ds_1'])
+            g14['delta_sub'] = full_d[::2, ::2, ::2].astype(np.float32)
+            g14['beta_sub'] = np.asarray(written['beta_ds_1'])[::2, ::2, ::2].astype(np.float32)
+            g14['delta_moved_max'] = np.abs(full_d - init_d).max()
+            print('done: |delta - init| max =', g14['delta_moved_max'])
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, 'g14_reconstruct_ptychography_64.npz'), **g14)
+    print('wrote g14')
+
+
 def main_h5():
     """G7: exchange/data files written by h5py 3.3.0 (run under /opt/conda/bin/python3.9)."""
     import h5py
@@ -711,5 +831,7 @@ if __name__ == '__main__':
         main_g12()
     elif '--g13' in sys.argv:
         main_g13()
+    elif '--g14' in sys.argv:
+        main_g14()
     else:
         main()

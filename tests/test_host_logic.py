@@ -135,3 +135,20 @@ def test_ptychography_epoch_schedule():
     assert np.array_equal(sched, again)                                # every rank derives the same schedule from the seed
     exact = epoch_schedule(2, 8, 4, np.random.RandomState(0))
     assert exact.shape == (16, 2)
+
+
+def test_rotation_tables_square_and_non_square():
+    """util.rotation_lookup equals the reference's tables (oracle restatement, golden vector G3) whenever the rotation plane is
+    square (X = Z) — every case the reference drivers run.  For X != Z the reference enumerates the new coordinates with
+    np.reshape(np.tile(coord1, Z), [X, Z]) (cnn_propagator/util.py:304-306), which is only the intended repeat when X = Z:
+    its (x, z) pairs then repeat some voxels and skip others, i.e. the rotated object is scrambled.  The product keeps the
+    intended enumeration there — a deliberate deviation, found by executing the reference's loop on a (64, 64, 32) object."""
+    from oracle import bdof_oracle as orc
+    for size in ([8, 8, 8], [6, 10, 10], [12, 5, 5]):
+        assert all(np.array_equal(a, b) for a, b in zip(orc.rotation_lookup(size, 5), util.rotation_lookup(size, 5)))
+    size = [8, 10, 6]
+    ours = util.rotation_lookup(size, 1)[0]                       # theta = 0: the identity map of the enumeration
+    pairs = set(map(tuple, ours))
+    assert len(pairs) == size[1] * size[2]                        # every (x, z) once
+    theirs = orc.rotation_lookup(size, 1)[0]
+    assert len(set(map(tuple, theirs))) < size[1] * size[2]       # the reference's enumeration repeats pairs
