@@ -11,6 +11,7 @@ Run only in the build container (needs /root/reference, which never travels):
     python tests/golden/make_golden.py --g12      # G12 (simulation.create_fullfield_data_numpy / create_ptychography_data_batch_numpy)
     python tests/golden/make_golden.py --g13      # G13 (reconstruct_fullfield at a size the GPU's real-space kernels take)
     python tests/golden/make_golden.py --g14      # G14 (reconstruct_ptychography likewise: 64 x 64 probe, 64^3 object)
+    python tests/golden/make_golden.py --g15      # G15 (reconstruct_fullfield's loop around np_funcs' FFT forward model)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -34,6 +35,10 @@ G13 runs reconstruct_fullfield once more at (Y, X, Z) = (64, 64, 64) with 17 tap
 accept, so the product's entry point can be compared with the reference's loop DIRECTLY — where 524288 finite-difference
 variables are out of reach: there autograd.grad is stood in by the oracle's analytic gradient of the same loss (itself pinned
 by finite differences, torch autograd and, through G10, by this very loop at 8^3).
+G15 is G13 with one substitution inside the reference: the name multislice_propagate_cnn that fullfield.py calls is bound to
+the reference's OTHER forward model, np_funcs.multislice_propagate_batch_numpy (the transfer-function propagator that the
+north star names) — two pieces of reference code composed, so that the product's default entry point has a reference-run
+loop to be compared with.
 The fixtures are data only (inputs + outputs); no reference source is stored.
 """
 import os
@@ -794,6 +799,102 @@ def main_g14():
     print('wrote g14')
 
 
+def main_g15():
+    """G15: reconstruct_fullfield at (64, 64, 64) around np_funcs' FFT forward; gradient by the oracle's analytic adjoint."""
+    import contextlib
+    import io
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import bdof_oracle as orc
+    autograd = _setup_conv_reference()
+    ref_util, ref_np = sys.modules.get('util'), sys.modules.get('np_funcs')
+
+    def oracle_grad(fn, argnums):
+        assert list(argnums) == [0, 1]
+        cl = dict(zip(fn.__code__.co_freevars, [c.cell_contents for c in fn.__closure__]))
+
+        def g(obj_delta, obj_beta, this_ind_batch, this_prj_batch):
+            _, gd, gb = orc.fullfield_loss_and_grad(obj_delta, obj_beta, cl['coord_ls'], this_ind_batch, this_prj_batch, cl['probe_real'],
+                                                    cl['probe_imag'], cl['energy_ev'], cl['psize_cm'] * cl['ds_level'], free_prop_cm=cl['free_prop_cm'],
+                                                    alpha=cl['alpha'], alpha_d=cl['alpha_d'], alpha_b=cl['alpha_b'], gamma=cl['gamma'], with_reg=True)
+            return gd, gb
+        return g
+
+    autograd.grad = oracle_grad
+    import propagation as ref_prop
+    ref_prop.trange = range
+    import fullfield as ref_ff
+
+    def fft_forward(grid_delta, grid_beta, probe_real, probe_imag, energy_ev, psize_cm, kernel_size=17, free_prop_cm=None, debug=False):
+        return ref_np.multislice_propagate_batch_numpy(grid_delta, grid_beta, probe_real, probe_imag, energy_ev, psize_cm[0],
+                                                       free_prop_cm=free_prop_cm, obj_batch_shape=grid_delta.shape)[0]
+    ref_ff.multislice_propagate_cnn = fft_forward
+
+    sys.path.insert(0, HERE)
+    import g13_inputs
+    ny, nx, n_theta, mb = 64, 64, 4, 2
+    rng = np.random.default_rng(15)
+    yy, xx, zz = np.mgrid[:ny, :nx, :nx].astype(np.float64)
+    true_d = np.zeros((ny, nx, nx))
+    for _ in range(5):
+        c = (rng.uniform(16, 48), rng.uniform(20, 44), rng.uniform(20, 44))
+        r = rng.uniform(4, 8)
+        true_d += 3e-6 * np.exp(-((yy - c[0]) ** 2 + (xx - c[1]) ** 2 + (zz - c[2]) ** 2) / (2 * r ** 2))
+    true_b = 0.1 * true_d
+    mask = g13_inputs.mask()
+    init_d, init_b = g13_inputs.initial_guess()
+    store, written = {}, {}
+
+    class _Dataset(object):
+        def __init__(self, arr):
+            self.arr = arr
+
+        def __getitem__(self, key):
+            return self.arr[key]
+
+    class _File(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def __getitem__(self, key):
+            return _Dataset(store['prj'])
+
+    ref_ff.h5py.File = _File
+    dx = sys.modules['dxchange']
+    dx.read_tiff_stack = lambda fname, ind, digit=5: np.array(mask)
+    dx.read_tiff = lambda fname: np.array(mask)
+    dx.write_tiff = lambda arr, fname=None, dtype=None, overwrite=False: written.__setitem__(os.path.basename(fname), np.array(arr))
+    dx.write_tiff_stack = lambda *a, **k: None
+    g15 = {}
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            ref_ff.save_rotation_lookup([ny, nx, nx], n_theta)
+            folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(ny, nx, nx, n_theta)
+            coords = ref_ff.read_all_origin_coords(folder, n_theta)
+            obj = np.stack([true_d, true_b], axis=3)
+            rot = np.stack([ref_ff.apply_rotation(obj, c, folder) for c in coords])
+            prj = fft_forward(rot[..., 0], rot[..., 1], np.ones((ny, nx)), np.zeros((ny, nx)), 5000., [1e-7] * 3, free_prop_cm=1e-4)
+            store['prj'] = prj.astype('complex64')
+            g15['prj'] = store['prj']
+            np.random.seed(5)
+            with contextlib.redirect_stdout(io.StringIO()):
+                ref_ff.reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, n_epochs=2, learning_rate=1e-7, minibatch_size=mb,
+                                             energy_ev=5000, psize_cm=1e-7, free_prop_cm=1e-4, save_path='.', output_folder='out',
+                                             initial_guess=[init_d.copy(), init_b.copy()], shrink_cycle=None,
+                                             alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)
+            full_d = np.asarray(written['delta_ds_1'])
+            g15['delta_sub'] = full_d[::2, ::2, ::2].astype(np.float32)
+            g15['beta_sub'] = np.asarray(written['beta_ds_1'])[::2, ::2, ::2].astype(np.float32)
+            g15['delta_moved_max'] = np.abs(full_d - init_d * mask).max()
+            print('done: |delta - init| max =', g15['delta_moved_max'])
+        finally:
+            os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, 'g15_reconstruct_fullfield_fft_64.npz'), **g15)
+    print('wrote g15')
+
+
 def main_h5():
     """G7: exchange/data files written by h5py 3.3.0 (run under /opt/conda/bin/python3.9)."""
     import h5py
@@ -833,5 +934,7 @@ if __name__ == '__main__':
         main_g13()
     elif '--g14' in sys.argv:
         main_g14()
+    elif '--g15' in sys.argv:
+        main_g15()
     else:
         main()

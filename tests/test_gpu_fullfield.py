@@ -232,3 +232,35 @@ def test_slab_pipelined_step_through_rccl():
     env = dict(os.environ, BDOF_FORCE_COMM='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and b'SLAB_RCCL_OK' in r.stdout, r.stdout.decode()[-3000:]
+
+
+def test_reconstruct_fullfield_vs_the_reference_loop_fft(tmp_path, monkeypatch):
+    """The product's DEFAULT entry point (transfer-function propagator, the north-star path) against golden vector G15: the
+    reference's own reconstruct_fullfield loop executed at 64^3 with the name it calls for the forward model bound to the
+    reference's np_funcs.multislice_propagate_batch_numpy (tests/golden/make_golden.py --g15) — 4 angles in minibatches of 2,
+    two epochs = four Adam steps, L1 + TV, mask, clip.  Same data file, mask files, initial guess and seed in, volume out."""
+    import sys
+    import __graft_entry__ as entry
+    entry.build()
+    from beyond_dof_amd import h5io, tiffio
+    from beyond_dof_amd.fullfield import reconstruct_fullfield
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, gdir)
+    import g13_inputs
+    g = np.load(os.path.join(gdir, 'g15_reconstruct_fullfield_fft_64.npz'))
+    init_d, init_b = g13_inputs.initial_guess()
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('case')
+    h5io.write_dataset('case/data.h5', 'exchange/data', g['prj'])
+    tiffio.write_tiff_stack(g13_inputs.mask(), 'case/fin_sup_mask/mask', dtype='float32', overwrite=True)
+    lr = 1e-7
+    d, b = reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, n_epochs=2, learning_rate=lr, minibatch_size=2, energy_ev=5000,
+                                 psize_cm=1e-7, free_prop_cm=1e-4, save_path='case', output_folder='out', initial_guess=[init_d, init_b],
+                                 shrink_cycle=None, seed=5, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)
+    assert float(g['delta_moved_max']) >= 3.9 * lr                       # four whole steps were taken
+    d, b = d[::2, ::2, ::2], b[::2, ::2, ::2]
+    rel = lambda a, c: np.linalg.norm(a - c) / np.linalg.norm(c)
+    stats = (np.abs(d - g['delta_sub']).max() / lr, rel(d, g['delta_sub']), np.abs(b - g['beta_sub']).max() / lr, rel(b, g['beta_sub']))
+    print('G15 stats', stats)
+    assert stats[0] <= 0.01 and stats[1] <= 1e-5, stats                 # the north-star bound on the reconstructed delta
+    assert stats[2] <= 0.01 and stats[3] <= 5e-5, stats
