@@ -12,6 +12,7 @@ Run only in the build container (needs /root/reference, which never travels):
     python tests/golden/make_golden.py --g13      # G13 (reconstruct_fullfield at a size the GPU's real-space kernels take)
     python tests/golden/make_golden.py --g14      # G14 (reconstruct_ptychography likewise: 64 x 64 probe, 64^3 object)
     python tests/golden/make_golden.py --g15      # G15 (reconstruct_fullfield's loop around np_funcs' FFT forward model)
+    python tests/golden/make_golden.py --g16      # G16 (tensorflow_recon/create_noisy_data.py: Poisson noise, ptychography branch)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -895,6 +896,86 @@ def main_g15():
     print('wrote g15')
 
 
+def main_g16():
+    """G16: tensorflow_recon/create_noisy_data.py run as the script it is (runpy), in a directory laid out with the file
+    names it hard-codes; its clock is frozen (it seeds numpy from int(time.time())) and h5py / dxchange are in-memory
+    stand-ins.  Its source path contains 'ptycho', so the ptychography branch (:45-72) is the one that runs."""
+    import contextlib
+    import io
+    import runpy
+    import tempfile
+    import time as _time
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    rng = np.random.default_rng(16)
+    n = 12
+    gd = np.zeros((n, n, n))
+    gd[3:9, 3:9, 3:9] = rng.uniform(1e-6, 3e-6, size=(6, 6, 6))
+    src = (rng.uniform(0.5, 3.0, size=(2, 3, 8, 8)) * np.exp(1j * rng.uniform(0, 6.28, size=(2, 3, 8, 8)))).astype('complex64')
+    written = {}
+
+    class _Dataset(object):
+        def __init__(self, arr):
+            self.arr = arr
+            self.shape = arr.shape
+
+        def __getitem__(self, key):
+            return self.arr[key]
+
+        def __setitem__(self, key, val):
+            self.arr[key] = val
+
+    class _Group(object):
+        def __init__(self, fname):
+            self.fname = fname
+
+        def create_dataset(self, name, dtype=None, shape=None):
+            d = _Dataset(np.zeros(shape, dtype=dtype))
+            written[os.path.basename(self.fname)] = d
+            return d
+
+    class _File(object):
+        def __init__(self, fname, mode='r'):
+            self.fname, self.mode = fname, mode
+
+        def __getitem__(self, key):
+            assert key == 'exchange/data' and self.mode == 'r'
+            return _Dataset(src)
+
+        def create_group(self, name):
+            return _Group(self.fname)
+
+    stub('h5py', File=_File)
+    stub('dxchange', write_tiff=lambda *a, **k: None)
+    import matplotlib
+    matplotlib.use = lambda *a, **k: None
+    cwd = os.getcwd()
+    real_time = _time.time
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            os.makedirs('cell/phantom')
+            os.makedirs('cell/ptychography')
+            np.save('cell/phantom/grid_delta.npy', gd)
+            _time.time = lambda: 1234.5
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                runpy.run_path('/root/reference/tensorflow_recon/create_noisy_data.py', run_name='__main__')
+        finally:
+            _time.time = real_time
+            os.chdir(cwd)
+    g16 = {'grid_delta': gd, 'src': src, 'seed': np.array(1234)}
+    for k, v in written.items():
+        g16[k.replace('.h5', '').replace('.', 'p')] = v.arr
+        print(k, v.arr.shape, float(np.abs(v.arr).max()))
+    np.savez_compressed(os.path.join(HERE, 'g16_noisy_data.npz'), **g16)
+    print('wrote g16')
+
+
 def main_h5():
     """G7: exchange/data files written by h5py 3.3.0 (run under /opt/conda/bin/python3.9)."""
     import h5py
@@ -936,5 +1017,7 @@ if __name__ == '__main__':
         main_g14()
     elif '--g15' in sys.argv:
         main_g15()
+    elif '--g16' in sys.argv:
+        main_g16()
     else:
         main()

@@ -136,3 +136,23 @@ def test_bigtiff_round_trip(tmp_path):
         assert np.array_equal(tifffile.imread(f), vol)
     except ImportError:
         pass
+
+
+def test_create_noisy_data_vs_the_reference_script(tmp_path, golden_dir):
+    """Golden vector G16: tensorflow_recon/create_noisy_data.py run as the script it is (tests/golden/make_golden.py --g16;
+    seed 1234 through its frozen clock, ptychography branch).  create_noisy_data, fed the same numpy stream in the script's
+    order (three photon budgets x two output files), writes the same six datasets bit for bit."""
+    import os
+    from beyond_dof_amd import h5io
+    from beyond_dof_amd.simulation import create_noisy_data
+    g = np.load(os.path.join(golden_dir, 'g16_noisy_data.npz'))
+    src = str(tmp_path / 'data_cell_phase_ptycho.h5')
+    h5io.write_dataset(src, 'exchange/data', g['src'])
+    rng = np.random.RandomState(int(g['seed']))
+    for n_ph_tx in ('1.75e6', '1.75e7', '1.75e8'):
+        for postfix in ('', '_ref'):
+            dst = str(tmp_path / 'out_n{}{}.h5'.format(n_ph_tx, postfix))
+            create_noisy_data(src, dst, n_ph_tx, grid_delta=g['grid_delta'], is_ptycho=True, rng=rng)
+            want = g['data_cell_phase_n{}{}'.format(n_ph_tx, postfix).replace('.', 'p')]
+            got = np.asarray(h5io.read_dataset(dst))
+            assert got.dtype == np.complex64 and np.array_equal(got, want), (n_ph_tx, postfix)
