@@ -13,6 +13,7 @@ Run only in the build container (needs /root/reference, which never travels):
     python tests/golden/make_golden.py --g14      # G14 (reconstruct_ptychography likewise: 64 x 64 probe, 64^3 object)
     python tests/golden/make_golden.py --g15      # G15 (reconstruct_fullfield's loop around np_funcs' FFT forward model)
     python tests/golden/make_golden.py --g16      # G16 (tensorflow_recon/create_noisy_data.py: Poisson noise, ptychography branch)
+    python tests/golden/make_golden.py --g17      # G17 (reconstruct_ptychography's loop around np_funcs' FFT forward model)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -681,9 +682,12 @@ def main_g13():
     print('wrote g13')
 
 
-def main_g14():
+def main_g14(fft=False):
     """G14: reconstruct_ptychography with a 64 x 64 gaussian probe on a (64, 64, 64) object, 4 positions x 2 angles, minibatches
-    of 2, two epochs; gradient by the oracle's analytic adjoint (as G13).  Volumes stored on every second voxel, float32."""
+    of 2, two epochs; gradient by the oracle's analytic adjoint (as G13).  Volumes stored on every second voxel, float32.
+    fft=True is G17: the name multislice_propagate_cnn that ptychography.py calls is bound to np_funcs' transfer-function
+    forward model (as G15 does for full field), with the drivers' kind of probe (sigma 10: it has decayed at the window's
+    edge, which that model does not mind)."""
     import contextlib
     import io
     import tempfile
@@ -698,7 +702,7 @@ def main_g14():
         def g(obj_delta, obj_beta, this_i_theta, this_pos_batch, this_prj_batch):
             _, gd, gb = orc.ptycho_loss_and_grad(obj_delta, obj_beta, cl['coord_ls'][this_i_theta], cl['probe_pos'], this_pos_batch,
                                                  this_prj_batch, cl['probe_real'], cl['probe_imag'], tuple(cl['probe_size']), cl['energy_ev'],
-                                                 cl['psize_cm'] * cl['ds_level'], propagator='conv', kernel_size=17)
+                                                 cl['psize_cm'] * cl['ds_level'], propagator='fft' if fft else 'conv', kernel_size=17)
             return gd, gb
         return g
 
@@ -725,6 +729,15 @@ def main_g14():
     import ptychography as ref_pt
     ref_pt.trange = range
     ref_pt.time = types.SimpleNamespace(time=lambda: 42 * 60.0 + 1.0)          # seed 42
+    sigma = 10. if fft else 40.
+    if fft:
+        ref_np = sys.modules['np_funcs']
+
+        def fft_forward(grid_delta, grid_beta, probe_real, probe_imag, energy_ev, psize_cm, kernel_size=17, free_prop_cm=None, debug=False):
+            return ref_np.multislice_propagate_batch_numpy(grid_delta, grid_beta, probe_real, probe_imag, energy_ev, psize_cm[0],
+                                                           free_prop_cm=free_prop_cm, obj_batch_shape=grid_delta.shape)[0]
+        ref_pt.multislice_propagate_cnn = fft_forward
+    forward = ref_pt.multislice_propagate_cnn
 
     obj_size, psz, n_theta, mb = (64, 64, 64), (64, 64), 2, 2     # X = Z: the reference's lookup tables are only sound for square (x, z)
     pos = [(20, 22), (24, 40), (42, 26), (40, 44)]
@@ -741,7 +754,7 @@ def main_g14():
     init_d, init_b = g13_inputs.initial_guess(obj_size)
     # a wide probe: the real-space propagator pads with the constant 1 and renormalises by the corner pixel
     # (propagation.py:79,91,109-110), so a probe that has decayed at the window's corner is scaled to nothing
-    kw = dict(probe_mag_sigma=40., probe_phase_sigma=40., probe_phase_max=0.5)
+    kw = dict(probe_mag_sigma=sigma, probe_phase_sigma=sigma, probe_phase_max=0.5)
     store, written = {}, {}
 
     class _Dataset(object):
@@ -771,14 +784,14 @@ def main_g14():
             ref_pt.save_rotation_lookup(list(n), n_theta)
             folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(n[0], n[1], n[2], n_theta)
             coords = ref_pt.read_all_origin_coords(folder, n_theta)
-            pr, pi_ = orc.gaussian_probe(psz, 40., 40., 0.5)
+            pr, pi_ = orc.gaussian_probe(psz, sigma, sigma, 0.5)
             half = (np.array(psz) / 2).astype('int')
             prj = np.zeros((n_theta, len(pos), psz[0], psz[1]), dtype='complex64')
             for t in range(n_theta):
                 rot = ref_pt.apply_rotation(np.stack([true_d, true_b], axis=3), coords[t], folder)
                 rot = np.pad(rot, ((half[0], half[0]), (half[1], half[1]), (0, 0), (0, 0)), mode='constant')
                 subs = np.stack([rot[p[0]:p[0] + psz[0], p[1]:p[1] + psz[1]] for p in pos])
-                prj[t] = ref_prop.multislice_propagate_cnn(subs[..., 0], subs[..., 1], pr, pi_, 5000., [1e-7] * 3, free_prop_cm='inf')
+                prj[t] = forward(subs[..., 0], subs[..., 1], pr, pi_, 5000., [1e-7] * 3, free_prop_cm='inf')
             # 2 % amplitude noise: a noise-free far-field pattern of this weak object differs from the initial guess's by 4e-6 of
             # its size, a residual no float32 detector wave can resolve (measured data are not like that)
             prj = (prj * (1 + 0.02 * rng.normal(size=prj.shape))).astype('complex64')
@@ -796,8 +809,9 @@ def main_g14():
             print('done: |delta - init| max =', g14['delta_moved_max'])
         finally:
             os.chdir(cwd)
-    np.savez_compressed(os.path.join(HERE, 'g14_reconstruct_ptychography_64.npz'), **g14)
-    print('wrote g14')
+    g14['probe_sigma'] = np.array(sigma)
+    np.savez_compressed(os.path.join(HERE, 'g17_reconstruct_ptychography_fft_64.npz' if fft else 'g14_reconstruct_ptychography_64.npz'), **g14)
+    print('wrote', 'g17' if fft else 'g14')
 
 
 def main_g15():
@@ -1017,6 +1031,8 @@ if __name__ == '__main__':
         main_g14()
     elif '--g15' in sys.argv:
         main_g15()
+    elif '--g17' in sys.argv:
+        main_g14(fft=True)
     elif '--g16' in sys.argv:
         main_g16()
     else:

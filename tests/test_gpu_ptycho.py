@@ -135,3 +135,37 @@ def test_resident_measurements_equal_per_step_upload():
             s.step(i, i_theta, sel, None if resident else meas[i_theta, sel], 1e-7)
         vols.append(s.get_volume())
     assert np.array_equal(vols[0][0], vols[1][0]) and np.array_equal(vols[0][1], vols[1][1])
+
+
+def test_reconstruct_ptychography_vs_the_reference_loop_fft(tmp_path, monkeypatch):
+    """The DEFAULT ptychography entry point (transfer-function propagator, LDS-resident engine for the 64 x 64 probe, far field)
+    against golden vector G17: the reference's own reconstruct_ptychography loop executed with the name it calls for the forward
+    model bound to the reference's np_funcs.multislice_propagate_batch_numpy (tests/golden/make_golden.py --g17) — 64^3 object,
+    gaussian probe (sigma 10), 4 positions x 2 angles in minibatches of 2, two epochs = 8 Adam steps, 2 % noise on the data."""
+    import sys
+    import __graft_entry__ as entry
+    entry.build()
+    from beyond_dof_amd import h5io
+    from beyond_dof_amd.ptychography import reconstruct_ptychography
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, gdir)
+    import g13_inputs
+    g = np.load(os.path.join(gdir, 'g17_reconstruct_ptychography_fft_64.npz'))
+    obj_size, psz, sigma = tuple(int(v) for v in g['obj_size']), tuple(int(v) for v in g['probe_size']), float(g['probe_sigma'])
+    init_d, init_b = g13_inputs.initial_guess(obj_size)
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('case')
+    h5io.write_dataset('case/data.h5', 'exchange/data', g['prj'])
+    lr = 2e-7
+    d, b = reconstruct_ptychography('data.h5', [tuple(int(v) for v in p) for p in g['probe_pos']], psz, obj_size, theta_st=0, theta_end=2 * np.pi,
+                                    n_epochs=2, learning_rate=lr, minibatch_size=2, energy_ev=5000, psize_cm=1e-7, save_path='case',
+                                    output_folder='out', initial_guess=[init_d, init_b], probe_type='gaussian', dynamic_dropping=False,
+                                    seed=42, probe_mag_sigma=sigma, probe_phase_sigma=sigma, probe_phase_max=0.5)
+    assert float(g['delta_moved_max']) >= 5 * lr
+    d, b = d[::2, ::2, ::2], b[::2, ::2, ::2]
+    rel = lambda a, c: np.linalg.norm(a - c) / np.linalg.norm(c)
+    dev, devb = np.abs(d - g['delta_sub']), np.abs(b - g['beta_sub'])
+    stats = (dev.max() / lr, rel(d, g['delta_sub']), devb.max() / lr, rel(b, g['beta_sub']), float(np.mean(dev > 0.05 * lr)))
+    print('G17 stats', stats)
+    # measured: delta 4.9e-5, beta 5.8e-6 relative after eight Adam steps, no voxel more than 0.045 of a step away
+    assert stats[0] <= 0.1 and stats[1] <= 1e-4 and stats[3] <= 2e-5 and stats[4] == 0.0, stats
