@@ -289,9 +289,11 @@ def main_g10():
                         args[which][i] = keep
                         gr[i] = (lp - lm) / (2 * h)
                     out.append(gr)
+            first_call.append((np.array(obj_delta), np.array(obj_beta), np.array(rest[0]), out[0].copy(), out[1].copy()))
             return tuple(out)
         return g
 
+    first_call = []
     autograd.grad = fd_grad
     import propagation as ref_prop
     ref_prop.trange = range
@@ -357,6 +359,8 @@ def main_g10():
                     ref_ff.reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, learning_rate=1e-7, minibatch_size=mb,
                                                  energy_ev=5000, psize_cm=1e-7, free_prop_cm=1e-4, save_path='.', output_folder='out',
                                                  initial_guess=[init_d.copy(), init_b.copy()], shrink_cycle=None, kernel_size=5, **kw)
+                if tag == 'a':            # the gradient of the first minibatch: finite differences of the reference's calculate_loss
+                    g10['grad0_delta_in'], g10['grad0_beta_in'], g10['grad0_ind'], g10['grad0_gd'], g10['grad0_gb'] = first_call[0]
                 g10['delta_' + tag] = np.asarray(written['delta_ds_1'], dtype=np.float64)
                 g10['beta_' + tag] = np.asarray(written['beta_ds_1'], dtype=np.float64)
                 print('case', tag, 'done: |delta - init| =', np.abs(g10['delta_' + tag] - init_d * mask).max())

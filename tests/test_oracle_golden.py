@@ -200,3 +200,23 @@ def test_g11_reconstruct_ptychography_loop(golden_dir):
         assert np.abs(g[key] - g['init_' + key]).max() >= 0.9 * lr
         assert np.abs(got - g[key]).max() <= 1e-3 * lr, (key, np.abs(got - g[key]).max() / lr)
         assert np.sqrt(np.mean((got - g[key]) ** 2)) <= 2e-5 * lr
+
+
+def test_g10_gradient_of_the_reference_loss(golden_dir):
+    """The gradient itself: float64 central differences of the REFERENCE's calculate_loss (real-space forward, rotation, loss,
+    L1 + TV; captured at the first minibatch of G10's case a) against the oracle's analytic adjoint — what stands in for
+    autograd.grad everywhere else."""
+    g = np.load(os.path.join(golden_dir, 'g10_reconstruct_fullfield.npz'))
+    n = g['mask'].shape[0]
+    coords = orc.rotation_lookup([n, n, n], 4)
+    idx = g['grad0_ind']
+    d, b = g['grad0_delta_in'], g['grad0_beta_in']
+    rot = np.stack([orc.apply_rotation(np.stack([d, b], axis=3), coords[j]) for j in idx])
+    one, zero = np.ones((n, n)), np.zeros((n, n))
+    _, gd_rot, gb_rot = orc.cnn_loss_and_grad(rot[..., 0], rot[..., 1], one, zero, 5000., [1e-7] * 3, np.abs(g['prj'][idx]), kernel_size=5,
+                                              free_prop_cm=1e-4)
+    gd = sum(orc.apply_rotation_adjoint(gd_rot[k], coords[j]) for k, j in enumerate(idx))
+    gb = sum(orc.apply_rotation_adjoint(gb_rot[k], coords[j]) for k, j in enumerate(idx))
+    rd, rb = orc.regularizer_grad(d, b, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)
+    rel = lambda a, c: np.linalg.norm(a - c) / np.linalg.norm(c)
+    assert rel(gd + rd, g['grad0_gd']) <= 1e-6 and rel(gb + rb, g['grad0_gb']) <= 1e-6, (rel(gd + rd, g['grad0_gd']), rel(gb + rb, g['grad0_gb']))
