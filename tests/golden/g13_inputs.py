@@ -14,7 +14,31 @@ def initial_guess(shape=SHAPE):
     return d.astype(np.float64), b.astype(np.float64)          # exactly what a float32 volume holds
 
 
-def mask():
-    m = np.ones(SHAPE, dtype=np.float32)
+def mask(shape=SHAPE):
+    m = np.ones(shape, dtype=np.float32)
     m[:3] = 0
     return m
+
+
+def phantom(shape):
+    """Five soft blobs (delta up to ~3e-6) placed by fixed fractions of the volume: the G18 phantom."""
+    y, x, z = np.mgrid[:shape[0], :shape[1], :shape[2]].astype(np.float64)
+    d = np.zeros(shape)
+    for cy, cx, cz, r in ((0.35, 0.40, 0.45, 0.08), (0.60, 0.55, 0.40, 0.11), (0.45, 0.62, 0.60, 0.07), (0.55, 0.38, 0.58, 0.09),
+                          (0.50, 0.50, 0.50, 0.05)):
+        d += 3e-6 * np.exp(-((y - cy * shape[0]) ** 2 + (x - cx * shape[1]) ** 2 + (z - cz * shape[2]) ** 2) / (2 * (r * shape[0]) ** 2))
+    return d
+
+
+def data_from_phantom(orc, shape, n_theta):
+    """exchange/data of G18, (n_theta, Y, X) complex64: the oracle's forward model on the phantom, 1 um to the detector."""
+    d = phantom(shape)
+    coords = orc.rotation_lookup(list(shape), n_theta)
+    one, zero = np.ones(shape[:2]), np.zeros(shape[:2])
+    out = []
+    for c in coords:
+        rot = orc.apply_rotation(np.stack([d, 0.1 * d], axis=3), c)[None]
+        w, _ = orc.multislice_propagate_batch_numpy(rot[..., 0], rot[..., 1], one, zero, 5000., 1e-7, 1e-4, rot[..., 0].shape,
+                                                    return_probe_array=False)
+        out.append(w[0])
+    return np.array(out).astype(np.complex64)

@@ -14,6 +14,7 @@ Run only in the build container (needs /root/reference, which never travels):
     python tests/golden/make_golden.py --g15      # G15 (reconstruct_fullfield's loop around np_funcs' FFT forward model)
     python tests/golden/make_golden.py --g16      # G16 (tensorflow_recon/create_noisy_data.py: Poisson noise, ptychography branch)
     python tests/golden/make_golden.py --g17      # G17 (reconstruct_ptychography's loop around np_funcs' FFT forward model)
+    python tests/golden/make_golden.py --g18      # G18 (G15 at BASELINE config 2's size, 256^3; ~10 min)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -818,8 +819,12 @@ def main_g14(fft=False):
     print('wrote', 'g17' if fft else 'g14')
 
 
-def main_g15():
-    """G15: reconstruct_fullfield at (64, 64, 64) around np_funcs' FFT forward; gradient by the oracle's analytic adjoint."""
+def main_g15(n=64):
+    """G15: reconstruct_fullfield at (64, 64, 64) around np_funcs' FFT forward; gradient by the oracle's analytic adjoint.
+    n = 256 is G18: the same at BASELINE config 2's volume size (256^3, 256 slices).  There the measured data are not stored
+    (4 x 256^2 complex values): generator and test both compute them with the oracle's forward model from the phantom formula
+    of g13_inputs.phantom — they are an input, any array would do as long as both sides read the same one; the stored outputs
+    are the reference loop's volumes on every eighth voxel per axis."""
     import contextlib
     import io
     import tempfile
@@ -851,17 +856,21 @@ def main_g15():
 
     sys.path.insert(0, HERE)
     import g13_inputs
-    ny, nx, n_theta, mb = 64, 64, 4, 2
-    rng = np.random.default_rng(15)
-    yy, xx, zz = np.mgrid[:ny, :nx, :nx].astype(np.float64)
-    true_d = np.zeros((ny, nx, nx))
-    for _ in range(5):
-        c = (rng.uniform(16, 48), rng.uniform(20, 44), rng.uniform(20, 44))
-        r = rng.uniform(4, 8)
-        true_d += 3e-6 * np.exp(-((yy - c[0]) ** 2 + (xx - c[1]) ** 2 + (zz - c[2]) ** 2) / (2 * r ** 2))
+    ny, nx, n_theta, mb = n, n, 4, 2
+    sub = 2 if n == 64 else 8
+    if n == 64:
+        rng = np.random.default_rng(15)
+        yy, xx, zz = np.mgrid[:ny, :nx, :nx].astype(np.float64)
+        true_d = np.zeros((ny, nx, nx))
+        for _ in range(5):
+            c = (rng.uniform(16, 48), rng.uniform(20, 44), rng.uniform(20, 44))
+            r = rng.uniform(4, 8)
+            true_d += 3e-6 * np.exp(-((yy - c[0]) ** 2 + (xx - c[1]) ** 2 + (zz - c[2]) ** 2) / (2 * r ** 2))
+    else:
+        true_d = g13_inputs.phantom((n, n, n))
     true_b = 0.1 * true_d
-    mask = g13_inputs.mask()
-    init_d, init_b = g13_inputs.initial_guess()
+    mask = g13_inputs.mask((n, n, n))
+    init_d, init_b = g13_inputs.initial_guess((n, n, n))
     store, written = {}, {}
 
     class _Dataset(object):
@@ -893,10 +902,13 @@ def main_g15():
             folder = 'arrsize_{}_{}_{}_ntheta_{}'.format(ny, nx, nx, n_theta)
             coords = ref_ff.read_all_origin_coords(folder, n_theta)
             obj = np.stack([true_d, true_b], axis=3)
-            rot = np.stack([ref_ff.apply_rotation(obj, c, folder) for c in coords])
-            prj = fft_forward(rot[..., 0], rot[..., 1], np.ones((ny, nx)), np.zeros((ny, nx)), 5000., [1e-7] * 3, free_prop_cm=1e-4)
-            store['prj'] = prj.astype('complex64')
-            g15['prj'] = store['prj']
+            rot = np.stack([ref_ff.apply_rotation(obj, c, folder) for c in coords]) if n == 64 else None
+            if n == 64:
+                prj = fft_forward(rot[..., 0], rot[..., 1], np.ones((ny, nx)), np.zeros((ny, nx)), 5000., [1e-7] * 3, free_prop_cm=1e-4)
+                store['prj'] = prj.astype('complex64')
+                g15['prj'] = store['prj']
+            else:
+                store['prj'] = g13_inputs.data_from_phantom(orc, (n, n, n), n_theta)
             np.random.seed(5)
             with contextlib.redirect_stdout(io.StringIO()):
                 ref_ff.reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, n_epochs=2, learning_rate=1e-7, minibatch_size=mb,
@@ -904,14 +916,14 @@ def main_g15():
                                              initial_guess=[init_d.copy(), init_b.copy()], shrink_cycle=None,
                                              alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)
             full_d = np.asarray(written['delta_ds_1'])
-            g15['delta_sub'] = full_d[::2, ::2, ::2].astype(np.float32)
-            g15['beta_sub'] = np.asarray(written['beta_ds_1'])[::2, ::2, ::2].astype(np.float32)
+            g15['delta_sub'] = full_d[::sub, ::sub, ::sub].astype(np.float32)
+            g15['beta_sub'] = np.asarray(written['beta_ds_1'])[::sub, ::sub, ::sub].astype(np.float32)
             g15['delta_moved_max'] = np.abs(full_d - init_d * mask).max()
             print('done: |delta - init| max =', g15['delta_moved_max'])
         finally:
             os.chdir(cwd)
-    np.savez_compressed(os.path.join(HERE, 'g15_reconstruct_fullfield_fft_64.npz'), **g15)
-    print('wrote g15')
+    np.savez_compressed(os.path.join(HERE, 'g15_reconstruct_fullfield_fft_64.npz' if n == 64 else 'g18_reconstruct_fullfield_fft_256.npz'), **g15)
+    print('wrote', 'g15' if n == 64 else 'g18')
 
 
 def main_g16():
@@ -1037,6 +1049,8 @@ if __name__ == '__main__':
         main_g15()
     elif '--g17' in sys.argv:
         main_g14(fft=True)
+    elif '--g18' in sys.argv:
+        main_g15(n=256)
     elif '--g16' in sys.argv:
         main_g16()
     else:
