@@ -352,14 +352,16 @@ def main_g10():
             store['prj'] = prj.astype('complex64')
             g10['prj'] = store['prj']
             cases = {'a': dict(alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11, n_epochs=2, seed=7),
-                     'b': dict(alpha=1e-8, alpha_d=None, alpha_b=None, gamma=0., n_epochs=1, seed=3)}      # quirk Q6 branch
+                     'b': dict(alpha=1e-8, alpha_d=None, alpha_b=None, gamma=0., n_epochs=1, seed=3),      # quirk Q6 branch
+                     # shrink-wrap from the first epoch on (with shrink_cycle > i_epoch the reference dies on an unbound name, :369-372)
+                     'c': dict(alpha_d=4e-6, alpha_b=1.5e-9, gamma=0., n_epochs=2, seed=11, shrink_cycle=0)}
             for tag, kw in cases.items():
                 np.random.seed(kw.pop('seed'))                        # the schedule is shuffled from the global state (:196-197)
                 written.clear()
                 with contextlib.redirect_stdout(io.StringIO()):
                     ref_ff.reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, learning_rate=1e-7, minibatch_size=mb,
                                                  energy_ev=5000, psize_cm=1e-7, free_prop_cm=1e-4, save_path='.', output_folder='out',
-                                                 initial_guess=[init_d.copy(), init_b.copy()], shrink_cycle=None, kernel_size=5, **kw)
+                                                 initial_guess=[init_d.copy(), init_b.copy()], kernel_size=5, **dict(dict(shrink_cycle=None), **kw))
                 if tag == 'a':            # the gradient of the first minibatch: finite differences of the reference's calculate_loss
                     g10['grad0_delta_in'], g10['grad0_beta_in'], g10['grad0_ind'], g10['grad0_gd'], g10['grad0_gb'] = first_call[0]
                 g10['delta_' + tag] = np.asarray(written['delta_ds_1'], dtype=np.float64)

@@ -131,7 +131,7 @@ def test_g9_real_space_propagator(golden_dir):
         np.testing.assert_allclose(w, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
-def _oracle_conv_loop(g, n_theta, mb, n_epochs, seed, lr, kernel_size, fp, **reg):
+def _oracle_conv_loop(g, n_theta, mb, n_epochs, seed, lr, kernel_size, fp, shrink_cycle=None, **reg):
     """The loop of cnn_propagator/fullfield.py:337-362 driven by the oracle's pieces (real-space propagator)."""
     from beyond_dof_amd.comm import minibatch_schedule
     n = g['mask'].shape[0]
@@ -141,7 +141,7 @@ def _oracle_conv_loop(g, n_theta, mb, n_epochs, seed, lr, kernel_size, fp, **reg
     one, zero = np.ones((n, n)), np.zeros((n, n))
     x = np.clip(np.array([g['init_delta'] * mask, g['init_beta'] * mask]), 0, None)
     prj = g['prj']
-    for _ in range(n_epochs):
+    for i_epoch in range(n_epochs):
         m = v = None
         for i_batch, idx in enumerate(sched):
             rot = np.stack([orc.apply_rotation(np.stack([x[0], x[1]], axis=3), coords[j]) for j in idx])
@@ -152,16 +152,19 @@ def _oracle_conv_loop(g, n_theta, mb, n_epochs, seed, lr, kernel_size, fp, **reg
             rd, rb = orc.regularizer_grad(x[0], x[1], **reg)
             x, m, v = orc.apply_gradient_adam(x, np.array([gd + rd, gb + rb]), i_batch, m, v, step_size=lr)
             x = np.clip(x * mask, 0, None)
+            if shrink_cycle is not None and i_epoch >= shrink_cycle:             # shrink wrap, fullfield.py:369-372
+                mask = mask * (x[0] > 1e-15)
     return x
 
 
 @pytest.mark.parametrize('tag,n_epochs,seed,reg', [('a', 2, 7, dict(alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)),
-                                                   ('b', 1, 3, dict(alpha=1e-8, alpha_d=None, alpha_b=None, gamma=0.))])
+                                                   ('b', 1, 3, dict(alpha=1e-8, alpha_d=None, alpha_b=None, gamma=0.)),
+                                                   ('c', 2, 11, dict(alpha_d=4e-6, alpha_b=1.5e-9, gamma=0., shrink_cycle=0))])
 def test_g10_reconstruct_fullfield_loop(golden_dir, tag, n_epochs, seed, reg):
     """The reference's own reconstruct_fullfield executed on 8^3 (make_golden.py --g10: file traffic in memory, autograd.grad
     stood in by float64 central differences of the reference's calculate_loss).  The oracle-driven loop — the one the GPU
     tests compare the product with — lands on the same volume: schedule from the seed, per-epoch Adam restart, bias-correction
-    exponent, regulariser branch (b: quirk Q6), mask and clip order, analytic gradient."""
+    exponent, regulariser branch (b: quirk Q6), mask and clip order, shrink-wrap (c), analytic gradient."""
     g = np.load(os.path.join(golden_dir, 'g10_reconstruct_fullfield.npz'))
     lr = 1e-7
     x = _oracle_conv_loop(g, 4, 2, n_epochs, seed, lr, 5, 1e-4, **reg)
