@@ -42,6 +42,22 @@ static inline bool resident_supported(int n) {
 // counter is sufficient; the one hand-over through global memory (forward tape -> adjoint sweep) has a full barrier.
 __device__ __forceinline__ void res_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// e / N for the element indices of the point-wise sweeps (0 <= e < N * N + 1024), as a 24-bit multiply and a shift (both
+// full rate; the compiler's v_mul_hi_i32 is quarter rate).  The magic constant is checked exhaustively at compile time.
+template <int N> struct ResDiv {
+    static constexpr unsigned SH = 20, M = ((1u << SH) + N - 1) / N;
+    static constexpr bool ok() {
+        for (unsigned e = 0; e < (unsigned)(N * N + 1024); ++e)
+            if (((e * M) >> SH) != e / (unsigned)N) return false;
+        return true;
+    }
+    static_assert(M < (1u << 24) && (unsigned long long)(N * N + 1024) * M < (1ull << 32), "24 x 24 -> 32 bit multiply");
+};
+template <int N> __device__ __forceinline__ int res_div(int e) {
+    static_assert(ResDiv<N>::ok(), "magic division constant is not exact over the element range");
+    return (int)(__umul24((unsigned)e, ResDiv<N>::M) >> ResDiv<N>::SH);
+}
+
 // ROUND: how sqrt(3)/2 is represented (see mul_sqrt_half in bdof_fft.h): 0 hi + lo pair, 1 nearest float32 (1.8e-8 short),
 // 2 its upper neighbour (5.1e-8 long)
 template <int ROUND> __device__ __forceinline__ float mul_sqrt3_half(float t) {
@@ -381,20 +397,23 @@ template <int N, int T> struct ResPipe {
     static constexpr int EPT = (N * N + T - 1) / T;      // field elements per thread
 
     // object row of field row x = tid at slice z (-1: outside the volume / the sweep)
+    // ... as the element offset of that row in the modulation table (row * volNY: the 64-bit multiply is done once per row
+    // and slice by the thread that fills the ring, not once per element by every thread that reads it)
     static __device__ __forceinline__ long long row_of(const ResArgs& a, int b, int z, int tid) {
         if (tid >= N || z < 0 || z >= a.S) return -1;
-        return obj_src_row(a.obj, b, tid, z, N);
+        const long long r = obj_src_row(a.obj, b, tid, z, N);
+        return r >= 0 ? r * a.obj.volNY : -1;
     }
     static __device__ __forceinline__ void load_factors(const ResArgs& a, const long long* rows, int y0, int tid, float2 (&m)[EPT]) {
         asm volatile("" : "+v"(tid));
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
             const int e = min(tid + i * T, N * N - 1);
-            const int x = e / N, y = e - x * N;
+            const int x = res_div<N>(e), y = e - x * N;
             const long long srow = rows[x];
             const int yg = y + y0;
             const int yc = min(max(yg, 0), a.obj.volNY - 1);
-            const float2 v = a.obj.vol[(size_t)(srow >= 0 ? srow : 0) * a.obj.volNY + yc];
+            const float2 v = a.obj.vol[(size_t)(srow >= 0 ? srow : 0) + yc];
             const bool in = srow >= 0 && yg == yc;
             m[i] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
         }
@@ -421,7 +440,7 @@ template <int N, int T> struct EpiMod {
         const long long srow = rows[pos];
         const int yg = line + y0;
         const int yc = min(max(yg, 0), a->obj.volNY - 1);
-        const float2 v = a->obj.vol[(size_t)(srow >= 0 ? srow : 0) * a->obj.volNY + yc];
+        const float2 v = a->obj.vol[(size_t)(srow >= 0 ? srow : 0) + yc];
         const bool in = srow >= 0 && yg == yc;
         fac[c][m] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
     }
@@ -449,7 +468,7 @@ template <int N, int T> struct EpiBwd {
         const long long srow = rows[pos];
         const int yg = line + y0;
         const int yc = min(max(yg, 0), a->obj.volNY - 1);
-        const float2 v = a->obj.vol[(size_t)(srow >= 0 ? srow : 0) * a->obj.volNY + yc];
+        const float2 v = a->obj.vol[(size_t)(srow >= 0 ? srow : 0) + yc];
         const bool in = srow >= 0 && yg == yc;
         fac[c][m] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
         tp[c][m] = tape[pos * N + line];
@@ -475,7 +494,7 @@ template <int N, int T> struct ResPoint {
         for (int i = 0; i < EPT; ++i) {
             const int e = tid + i * T;
             if (EPT * T == N * N || e < N * N) {
-                const int x = e / N, y = e - x * N;
+                const int x = res_div<N>(e), y = e - x * N;
                 const cf pc = pz ? pz[e] : car;
                 const cf phi = modulate_eps_s(f[x * P + y], pc, m[i], csh);
                 f[x * P + y] = phi;
@@ -493,7 +512,7 @@ template <int N, int T> struct ResPoint {
         for (int i = 0; i < EPT; ++i) {
             const int e = tid + i * T;
             if (EPT * T == N * N || e < N * N) {
-                const int x = e / N, y = e - x * N;
+                const int x = res_div<N>(e), y = e - x * N;
                 const cf G = f[x * P + y];
                 const cf phi = pz ? t[i] : cadd(t[i], car);
                 const cf q = cmulc(G, phi);
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
         cf* tape0 = a.tape ? a.tape + b * fsz : nullptr;           // slice z of this wavefield: tape0 + z * tape_stride
         res_sync();
         for (int e = tid; e < N * N; e += T) {
-            const int x = e / N, y = e - x * N;
+            const int x = res_div<N>(e), y = e - x * N;
             f[x * P + y] = a.probe[e];
         }
         if (tid < N) {
@@ -578,7 +597,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
 
         // ---- detector wave, loss, seed --------------------------------------------------------
         for (int e = tid; e < N * N; e += T) {
-            const int x = e / N, y = e - x * N;
+            const int x = res_div<N>(e), y = e - x * N;
             cf d = f[x * P + y];
             if (a.meas_dev && a.meas && !far && !a.pdet) {
                 const size_t o = b * fsz + e;
@@ -654,7 +673,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
         }
         if (a.gpsi0) {                                                   // the image now holds G(psi_0)
             for (int e = tid; e < N * N; e += T) {
-                const int x = e / N, y = e - x * N;
+                const int x = res_div<N>(e), y = e - x * N;
                 a.gpsi0[b * fsz + e] = f[x * P + y];
             }
         }
