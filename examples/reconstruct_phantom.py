@@ -1,8 +1,8 @@
 """A complete small reconstruction, the way the reference's driver scripts run one (cnn_propagator/reconstruct_fullfield.py):
 simulate a full-field dataset of a phantom with the product's forward model, write it as exchange/data, reconstruct with
 reconstruct_fullfield and compare with the phantom.  The detector distance decides how much of the phase the intensities
-carry: at 10 um (free_prop_cm=1e-3) 100 epochs recover delta to a correlation of 0.989 with the phantom (relative L2 error
-0.15) in 2.6 s on one MI355X; at 1 um the low spatial frequencies are barely encoded and the same run stalls at 0.82; in
+carry: at 10 um (free_prop_cm=1e-3) 100 epochs recover delta to a correlation of 0.988 with the phantom (relative L2 error
+0.16) in 2.6 s on one MI355X; at 1 um the low spatial frequencies are barely encoded and the same run stalls at 0.82; in
 the far field with a plane probe (one bright bin) it does not converge — properties of the measurement, the same for the
 reference.
 
