@@ -150,7 +150,7 @@ def self_launch(n_ranks):
     return rc or max((p.returncode or 0) for p in procs)
 
 
-def roofline_pass(solver, batch, hyper, n, mb, S):
+def roofline_pass(solver, batch, hyper, n, mb, S, conv=False):
     """One step with the sub-batch streams off and every launch bracketed by HIP events on the stream it is launched on."""
     eng = solver.eng
     eng.set_streams(1)
@@ -164,14 +164,17 @@ def roofline_pass(solver, batch, hyper, n, mb, S):
     eng.set_streams(-1)
     px = mb * n * n
     launches_per_step = {'row_fwd': S, 'col_prop': 2 * S, 'row_bwd': S, 'rot_adjoint': 1}
+    # the real-space propagator has one kernel per slice and direction (k_conv: 24 B/px forward, 40 B/px backward),
+    # timed under the same two classes; no transfer-function launches
+    byte_model = {k: v for k, v in BYTES_PER_PX.items() if not (conv and k == 'col_prop')}
     per_class = {}
-    for name, bpp in BYTES_PER_PX.items():
+    for name, bpp in byte_model.items():
         cnt, ms = prof[name]
         if cnt:
             nbytes = bpp * px * (S if name == 'rot_adjoint' else 1)
             per_class[name] = {'timed_launches': cnt, 'avg_ms': ms / cnt, 'bytes_per_launch': nbytes,
                                'GBps': nbytes / (ms / cnt * 1e-3) / 1e9, 'frac': nbytes / (ms / cnt * 1e-3) / HBM_PEAK,
-                               'avg_ms_rocprof_1stream': rocprof_avg_ms(name, n, mb)}
+                               'avg_ms_rocprof_1stream': None if conv else rocprof_avg_ms(name, n, mb)}
     if not per_class:
         return None
     share = {k: per_class[k]['avg_ms'] * launches_per_step[k] for k in per_class}
@@ -179,7 +182,7 @@ def roofline_pass(solver, batch, hyper, n, mb, S):
     # step and the adjoint row kernel are, at 24 ms each) and the tie goes to the one FURTHER from the roofline
     dom = min((k for k in share if share[k] >= 0.95 * max(share.values())), key=lambda k: per_class[k]['frac'])
     d = per_class[dom]
-    tb = pmc_traffic(dom, n, mb)
+    tb = None if conv else pmc_traffic(dom, n, mb)
     return {'bound': 'hbm', 'kernel': dom, 'achieved': d['GBps'], 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': d['frac'],
             'traffic': None if tb is None else tb / (d['avg_ms'] * 1e-3) / 1e9,
             'traffic_bytes_per_launch': tb, 'algorithmic_bytes_per_launch': d['bytes_per_launch'],
@@ -283,14 +286,14 @@ def main():
         elapsed = float(comm.allreduce_max_host(np.array([elapsed]))[0])
     groups = solver.eng.batch_groups(mb)
     S = n
-    roof = None if args.no_profile or args.propagator != 'fft' or args.rotation != 'nearest' else roofline_pass(solver, my_batches[0], hyper, n, mb, S)
+    roof = None if args.no_profile or args.rotation != 'nearest' else roofline_pass(solver, my_batches[0], hyper, n, mb, S, conv=args.propagator == 'conv')
     loss = solver.loss_and_grad(my_batches[0], want_loss=True)
     comm.Barrier()
 
     if rank == 0:
         slice_steps = world * mb * S * args.steps
         if roof is not None:
-            roof['whole_step_frac'] = 104.0 * n * n * (slice_steps / world) / elapsed / HBM_PEAK
+            roof['whole_step_frac'] = (72.0 if args.propagator == 'conv' else 104.0) * n * n * (slice_steps / world) / elapsed / HBM_PEAK
             roof['sub_batch_streams_in_timed_region'] = groups
         out = {'metric': 'multislice fwd+adjoint slice-steps/s (full Adam iteration: rotation, forward, loss, adjoint, '
                          'gradient exchange, regulariser+Adam)',

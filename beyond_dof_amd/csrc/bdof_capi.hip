@@ -1551,7 +1551,7 @@ static int conv_lds_bytes(const bdof_ctx* c) {
     return (TXH * (TYH | 1) + TXH * (BDOF_CONV_TY + 1)) * (int)sizeof(cf);
 }
 
-template <bool BWD, int H> static int launch_conv_h(bdof_ctx* c, ConvArgs& a) {
+template <bool BWD, int H> static int launch_conv_h(bdof_ctx* c, ConvArgs& a, ProfScope& ps) {
     const int lds = conv_lds_bytes(c);
     static bool attr_set[BDOF_MAX_DEVICES] = {};
     if (!attr_set[c->device % BDOF_MAX_DEVICES]) {
@@ -1560,18 +1560,18 @@ template <bool BWD, int H> static int launch_conv_h(bdof_ctx* c, ConvArgs& a) {
     }
     const int tiles = a.B * (a.NX / BDOF_CONV_TX) * (a.NY / BDOF_CONV_TY);
     const int grid = balanced_grid(c, tiles, 2);
-    hipLaunchKernelGGL((k_conv<BWD, H>), dim3(grid), dim3(BDOF_CONV_THREADS), lds, c->stream, a);
+    BDOF_LAUNCH(ps, (k_conv<BWD, H>), dim3(grid), dim3(BDOF_CONV_THREADS), lds, c->stream, a);
     return 0;
 }
 
 template <bool BWD> static int launch_conv(bdof_ctx* c, ConvArgs& a) {
-    ProfScope ps(c, BWD ? BDOF_K_ROW_BWD : BDOF_K_ROW_FWD);
+    ProfScope ps(c, BWD ? BDOF_K_ROW_BWD : BDOF_K_ROW_FWD, true);
     switch ((c->taps.ks - 1) / 2) {           // register-window fast paths for the common kernel sizes 5, 9, 17, 33
-        case 2: return launch_conv_h<BWD, 2>(c, a);
-        case 4: return launch_conv_h<BWD, 4>(c, a);
-        case 8: return launch_conv_h<BWD, 8>(c, a);
-        case 16: return launch_conv_h<BWD, 16>(c, a);
-        default: return launch_conv_h<BWD, 0>(c, a);
+        case 2: return launch_conv_h<BWD, 2>(c, a, ps);
+        case 4: return launch_conv_h<BWD, 4>(c, a, ps);
+        case 8: return launch_conv_h<BWD, 8>(c, a, ps);
+        case 16: return launch_conv_h<BWD, 16>(c, a, ps);
+        default: return launch_conv_h<BWD, 0>(c, a, ps);
     }
 }
 
