@@ -47,7 +47,14 @@ template <int SIGN> __device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2,
 //      four line transforms uses 2 in one of them and 1 in the other three: (3 x -1.71 + 6.72)e-8 — the defects cancel to
 //      a quarter at no cost in instructions.  The streaming engine rounds up in the inverse transform of the
 //      transfer-function kernel, the LDS-resident kernel in its inverse passes along x.
-template <int ROUND> __device__ __forceinline__ float mul_sqrt_half(float t) {
+// Building with -DBDOF_EXACT_CONSTANTS (BDOF_BUILD_FLAGS of __graft_entry__.build) takes the hi + lo pair everywhere: the
+// accuracy option for deep volumes (gradient error at 512 slices 1.61e-5 -> 1.15e-5 for +1.5 % step time).
+template <int ROUND_> __device__ __forceinline__ float mul_sqrt_half(float t) {
+#ifdef BDOF_EXACT_CONSTANTS
+    constexpr int ROUND = 0;
+#else
+    constexpr int ROUND = ROUND_;
+#endif
     if constexpr (ROUND == 0) return fmaf(t, 0.70710678118654752f, t * 1.2101617e-8f);
     else if constexpr (ROUND == 1) return t * 0.70710678118654752f;
     else return t * 0.70710682868957520f;
