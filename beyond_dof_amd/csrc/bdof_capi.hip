@@ -869,13 +869,14 @@ static cf unit_twiddle(double c, double s) {
 }
 
 static int upload_twiddle(bdof_ctx* c, int N, cf** dst) {
-    std::vector<cf> t(N);
+    std::vector<cf> t((size_t)N * BDOF_TWC);
     for (int j = 0; j < N; ++j) {
         double ang = -2.0 * M_PI * (double)j / (double)N;
         t[j] = unit_twiddle(std::cos(ang), std::sin(ang));
+        if (BDOF_TWC > 1) t[(size_t)N + j] = make_float2((float)(std::cos(ang) - (double)t[j].x), (float)(std::sin(ang) - (double)t[j].y));
     }
-    HIPC(c, hipMalloc((void**)dst, sizeof(cf) * N));
-    HIPC(c, hipMemcpyAsync(*dst, t.data(), sizeof(cf) * N, hipMemcpyHostToDevice, c->stream));
+    HIPC(c, hipMalloc((void**)dst, sizeof(cf) * t.size()));
+    HIPC(c, hipMemcpyAsync(*dst, t.data(), sizeof(cf) * t.size(), hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }

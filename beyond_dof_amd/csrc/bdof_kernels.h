@@ -227,9 +227,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * BDOF_TWC];
     FftTw<NY> tw;
-    __shared__ cf smem_tail[7 * C::T];
+    __shared__ cf smem_tail[7 * C::T * BDOF_TWC];
     tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -309,9 +309,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_pro
     typedef RowCfg<NX> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<NX>::LDS_CNT];
+    __shared__ cf smem_tw[FftTw<NX>::LDS_CNT * BDOF_TWC];
     FftTw<NX> tw;
-    __shared__ cf smem_tail[7 * C::T];
+    __shared__ cf smem_tail[7 * C::T * BDOF_TWC];
     tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NY / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -452,9 +452,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
     constexpr int S1 = FAR ? -1 : +1;     // direction of the first transform; the second is the opposite
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<N>::LDS_CNT];
+    __shared__ cf smem_tw[FftTw<N>::LDS_CNT * BDOF_TWC];
     FftTw<N> tw;
-    __shared__ cf smem_tail[7 * C::T];
+    __shared__ cf smem_tail[7 * C::T * BDOF_TWC];
     tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.R / C::TILE;
     double acc = 0.0, acc2 = 0.0;
@@ -591,9 +591,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * BDOF_TWC];
     FftTw<NY> tw;
-    __shared__ cf smem_tail[7 * C::T];
+    __shared__ cf smem_tail[7 * C::T * BDOF_TWC];
     tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1745,9 +1745,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_rea
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT];
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * BDOF_TWC];
     FftTw<NY> tw;
-    __shared__ cf smem_tail[7 * C::T];
+    __shared__ cf smem_tail[7 * C::T * BDOF_TWC];
     tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
