@@ -37,7 +37,7 @@ HBM_PEAK = 8.0e12
 # corrections); a process cannot collect them on itself, so the committed summary is read back here
 PMC_SUMMARY = os.path.join(ROOT, 'profiles', ROUND + '_pmc_traffic_bench.json')
 STATS_1STREAM = os.path.join(ROOT, 'profiles', ROUND + '_kernel_stats_1stream.csv')
-PMC_KERNEL = {'row_fwd': 'k_row_fwd<512, false, true', 'col_prop': 'k_row_prop<512>', 'row_bwd': 'k_row_bwd<512, 1',
+PMC_KERNEL = {'row_fwd': 'k_row_fwd<512, false, true', 'col_prop': 'k_row_prop<512', 'row_bwd': 'k_row_bwd<512, 1',
               'rot_adjoint': 'k_rot_adjoint'}
 
 
@@ -59,10 +59,12 @@ def rocprof_avg_ms(kernel_class, n, mb):
         return None
     import csv
     want = PMC_KERNEL[kernel_class]
+    calls = total = 0.0                       # a class may have several instances (the transfer-function step: forward and exact adjoint)
     for row in csv.DictReader(open(STATS_1STREAM)):
         if row['Name'].replace('void ', '').startswith(want):
-            return float(row['AverageNs']) * 1e-6
-    return None
+            calls += float(row['Calls'])
+            total += float(row['TotalDurationNs'])
+    return total / calls * 1e-6 if calls else None
 
 
 def make_phantom(n, seed=3):

@@ -382,7 +382,9 @@ static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf*
     ProfScope ps(c, BDOF_K_COL_PROP, true);
     RowPropArgs a{sub_field(c, in), sub_field(c, out), h, B, c->NY, scale, conj_h, c->twX};
     DISPATCH_N(c->NX, {
-        BDOF_LAUNCH(ps, (k_row_prop<N_>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
+        // the adjoint step runs the instance with exact transform constants (bdof_fft.h: that is where the gradient's error is made)
+        if (conj_h && BDOF_EX_ADJ) BDOF_LAUNCH(ps, (k_row_prop<N_, true>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
+        else BDOF_LAUNCH(ps, (k_row_prop<N_>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
     });
 }
 
@@ -869,11 +871,11 @@ static cf unit_twiddle(double c, double s) {
 }
 
 static int upload_twiddle(bdof_ctx* c, int N, cf** dst) {
-    std::vector<cf> t((size_t)N * BDOF_TWC);
+    std::vector<cf> t((size_t)N * 2);                     // hi, then lo (bdof_fft.h)
     for (int j = 0; j < N; ++j) {
         double ang = -2.0 * M_PI * (double)j / (double)N;
         t[j] = unit_twiddle(std::cos(ang), std::sin(ang));
-        if (BDOF_TWC > 1) t[(size_t)N + j] = make_float2((float)(std::cos(ang) - (double)t[j].x), (float)(std::sin(ang) - (double)t[j].y));
+        t[(size_t)N + j] = make_float2((float)(std::cos(ang) - (double)t[j].x), (float)(std::sin(ang) - (double)t[j].y));
     }
     HIPC(c, hipMalloc((void**)dst, sizeof(cf) * t.size()));
     HIPC(c, hipMemcpyAsync(*dst, t.data(), sizeof(cf) * t.size(), hipMemcpyHostToDevice, c->stream));

@@ -19,25 +19,30 @@ __device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - 
 __device__ __forceinline__ cf cmulc(cf a, cf b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 __device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s, a.y * s); }
 
-// -DBDOF_EXACT_TWIDDLES (implies BDOF_EXACT_CONSTANTS): twiddle tables come as hi + lo pairs (table[N + j] = the float32
-// rounding error of table[j], from the host's float64 values), so that the fixed tables stop acting as the same small
-// perturbation of every transform of a stack.  Gradient error at 512 slices 1.61e-5 -> 7.3e-6 for +11 % step time.
+// Twiddle tables come as hi + lo pairs (table[N + j] = the float32 rounding error of table[j], from the host's float64
+// values).  A transform instantiated with EX = true multiplies by hi + lo and takes sqrt(1/2) as a hi + lo pair too: the fixed
+// tables then stop acting as the same small perturbation of every transform of a stack (gradient error at 512 slices
+// 1.61e-5 -> 7.3e-6).  The adjoint kernels use it by default — that is where the error is made; the forward sweep rides on
+// its carrier.  -DBDOF_EXACT_TWIDDLES makes it the default of every transform (+11 % step time), -DBDOF_FAST_ADJOINT
+// switches it off everywhere.
 #ifdef BDOF_EXACT_TWIDDLES
-#define BDOF_TWC 2
 #ifndef BDOF_EXACT_CONSTANTS
 #define BDOF_EXACT_CONSTANTS 1
 #endif
+constexpr bool BDOF_EX_ALL = true;
 #else
-#define BDOF_TWC 1
+constexpr bool BDOF_EX_ALL = false;
+#endif
+#ifdef BDOF_FAST_ADJOINT
+constexpr bool BDOF_EX_ADJ = BDOF_EX_ALL;
+#else
+constexpr bool BDOF_EX_ADJ = true;
 #endif
 // u * (w + wl), the twiddle conjugated for the inverse transform
-template <int SIGN> __device__ __forceinline__ cf tw_mul(cf u, cf w, cf wl) {
+template <int SIGN, bool EX> __device__ __forceinline__ cf tw_mul(cf u, cf w, cf wl) {
     if (SIGN > 0) { w.y = -w.y; wl.y = -wl.y; }
-#ifdef BDOF_EXACT_TWIDDLES
-    return cadd(cmul(u, w), cmul(u, wl));
-#else
-    return cmul(u, w);
-#endif
+    if constexpr (EX) return cadd(cmul(u, w), cmul(u, wl));
+    else return cmul(u, w);
 }
 
 // multiply by SIGN*i
@@ -123,26 +128,27 @@ template <int N> struct FftTw {
     static constexpr int D1 = M1_R > 1 ? M1_R - 1 : 1, D2 = M2_R > 1 ? M2_R - 1 : 1;   // row lengths (never 0 as divisors)
     cf w[7];            // last stage, forward sign
     const cf* mid;      // LDS table of the middle stages
-    const cf* tail;     // LDS table [m-1][j] of the last stage (BDOF_EXACT_TWIDDLES: its lo parts follow at + 7 T, the middle
+    const cf* tail;     // LDS table [m-1][j] of the last stage (load<true>: its lo parts follow at + 7 T, the middle
                         // stages' at mid + LDS_CNT)
 
     // table[j] = exp(-2 pi i j / N), j in [0, N).  Must be called by every thread of the workgroup.
     // lds_mid: LDS_CNT slots; lds_tail: 7*N/8 slots laid out [m-1][j] = table[m*j] (also the tail stage's twiddles):
     // one cooperative fill, one barrier, and the per-lane last-stage factors are read back from LDS instead of being
     // gathered from global memory by every wave (kernel start-up is amortised over only ~2 tiles per workgroup).
+    template <bool LO = BDOF_EX_ALL>
     __device__ __forceinline__ void load(const cf* __restrict__ table, int tid, cf* lds_mid, cf* lds_tail) {
         constexpr int T = N / 8;
         for (int e = threadIdx.x; e < 7 * T; e += blockDim.x) {
             const int m = e / T + 1, j = e - (m - 1) * T;
             lds_tail[e] = table[m * j];
-            if (BDOF_TWC > 1) lds_tail[7 * T + e] = table[N + m * j];
+            if constexpr (LO) lds_tail[7 * T + e] = table[N + m * j];
         }
         for (int e = threadIdx.x; e < M1_CNT + M2_CNT; e += blockDim.x) {
             int k, m, step;
             if (e < M1_CNT) { k = e / D1; m = e % D1 + 1; step = N / (M1_P * M1_R); }
             else { const int f = e - M1_CNT; k = f / D2; m = f % D2 + 1; step = N / (M2_P * M2_R); }
             lds_mid[e] = table[m * k * step];
-            if (BDOF_TWC > 1) lds_mid[LDS_CNT + e] = table[N + m * k * step];
+            if constexpr (LO) lds_mid[LDS_CNT + e] = table[N + m * k * step];
         }
         mid = lds_mid;
         tail = lds_tail;
@@ -177,7 +183,7 @@ template <int N, int R, class L> __device__ __forceinline__ void stage_read(cf (
 }
 
 // WHICH: 0 = first stage (no twiddles), 1 / 2 = middle stage (LDS table), 3 = last stage (registers)
-template <int N, int SIGN, int R, int PP, int WHICH, int ROUND = 1>
+template <int N, int SIGN, int R, int PP, int WHICH, int ROUND = 1, bool EX = BDOF_EX_ALL>
 __device__ __forceinline__ void stage_compute(cf (&u)[8], const FftTw<N>& tw, int tid) {
     constexpr int T = N / 8, NB = 8 / R;
     typedef FftTw<N> TW;
@@ -186,14 +192,14 @@ __device__ __forceinline__ void stage_compute(cf (&u)[8], const FftTw<N>& tw, in
         if constexpr (WHICH == 3) {
 #pragma unroll
             for (int m = 1; m < R; ++m)
-                u[j * R + m] = tw_mul<SIGN>(u[j * R + m], tw.w[m - 1], BDOF_TWC > 1 ? tw.tail[(7 + m - 1) * T + tid] : tw.w[m - 1]);
+                u[j * R + m] = tw_mul<SIGN, EX>(u[j * R + m], tw.w[m - 1], EX ? tw.tail[(7 + m - 1) * T + tid] : tw.w[m - 1]);
         } else if constexpr (WHICH == 1 || WHICH == 2) {
             const int k = (tid + j * T) % PP;
             const cf* row = tw.mid + (WHICH == 1 ? TW::M1_OFF : TW::M2_OFF) + k * (R - 1);
 #pragma unroll
-            for (int m = 1; m < R; ++m) u[j * R + m] = tw_mul<SIGN>(u[j * R + m], row[m - 1], row[(BDOF_TWC > 1 ? TW::LDS_CNT : 0) + m - 1]);
+            for (int m = 1; m < R; ++m) u[j * R + m] = tw_mul<SIGN, EX>(u[j * R + m], row[m - 1], row[(EX ? TW::LDS_CNT : 0) + m - 1]);
         }
-        dftR<R, SIGN, ROUND>(u, j);
+        dftR<R, SIGN, EX ? 0 : ROUND>(u, j);
     }
 }
 
@@ -212,50 +218,50 @@ template <int N, int R, int PP, class L> __device__ __forceinline__ void stage_w
 // Full transform of one line.  u[m] <-> position tid + m*T on entry and on exit.
 // Unnormalised; SIGN = -1 forward DFT, +1 inverse.  lds.sync_w2r() orders a stage's stores
 // before the next stage's loads; lds.sync_r2w() orders loads before the stores that reuse the image.
-template <int N, int SIGN, int ROUND = 1, class L>
+template <int N, int SIGN, int ROUND = 1, bool EX = BDOF_EX_ALL, class L>
 __device__ __forceinline__ void line_fft(cf (&u)[8], const FftTw<N>& tw, int tid, L& lds) {
     typedef FftPlan<N> P;
-    stage_compute<N, SIGN, P::R0, 1, 0, ROUND>(u, tw, tid);
+    stage_compute<N, SIGN, P::R0, 1, 0, ROUND, EX>(u, tw, tid);
     lds.sync_r2w();
     stage_write<N, P::R0, 1>(u, tid, lds);
     lds.sync_w2r();
     stage_read<N, P::R1>(u, tid, lds);
-    stage_compute<N, SIGN, P::R1, P::R0, (P::NS == 2 ? 3 : 1), ROUND>(u, tw, tid);
+    stage_compute<N, SIGN, P::R1, P::R0, (P::NS == 2 ? 3 : 1), ROUND, EX>(u, tw, tid);
     if constexpr (P::NS > 2) {
         lds.sync_r2w();
         stage_write<N, P::R1, P::R0>(u, tid, lds);
         lds.sync_w2r();
         stage_read<N, P::R2>(u, tid, lds);
-        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, (P::NS == 3 ? 3 : 2), ROUND>(u, tw, tid);
+        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, (P::NS == 3 ? 3 : 2), ROUND, EX>(u, tw, tid);
     }
     if constexpr (P::NS > 3) {
         lds.sync_r2w();
         stage_write<N, P::R2, P::R0 * P::R1>(u, tid, lds);
         lds.sync_w2r();
         stage_read<N, P::R3>(u, tid, lds);
-        stage_compute<N, SIGN, P::R3, P::R0 * P::R1 * P::R2, 3, ROUND>(u, tw, tid);
+        stage_compute<N, SIGN, P::R3, P::R0 * P::R1 * P::R2, 3, ROUND, EX>(u, tw, tid);
     }
 }
 
 // All stages but the last; the last stage's inputs are left in the line's LDS image (no sync after the
 // final store: the caller's workgroup barrier orders it before the transposed readers).
-template <int N, int SIGN, int ROUND = 1, class L>
+template <int N, int SIGN, int ROUND = 1, bool EX = BDOF_EX_ALL, class L>
 __device__ __forceinline__ void line_fft_partial(cf (&u)[8], const FftTw<N>& tw, int tid, L& lds) {
     typedef FftPlan<N> P;
-    stage_compute<N, SIGN, P::R0, 1, 0, ROUND>(u, tw, tid);
+    stage_compute<N, SIGN, P::R0, 1, 0, ROUND, EX>(u, tw, tid);
     lds.sync_r2w();
     stage_write<N, P::R0, 1>(u, tid, lds);
     if constexpr (P::NS > 2) {
         lds.sync_w2r();
         stage_read<N, P::R1>(u, tid, lds);
-        stage_compute<N, SIGN, P::R1, P::R0, 1, ROUND>(u, tw, tid);
+        stage_compute<N, SIGN, P::R1, P::R0, 1, ROUND, EX>(u, tw, tid);
         lds.sync_r2w();
         stage_write<N, P::R1, P::R0>(u, tid, lds);
     }
     if constexpr (P::NS > 3) {
         lds.sync_w2r();
         stage_read<N, P::R2>(u, tid, lds);
-        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, 2, ROUND>(u, tw, tid);
+        stage_compute<N, SIGN, P::R2, P::R0 * P::R1, 2, ROUND, EX>(u, tw, tid);
         lds.sync_r2w();
         stage_write<N, P::R2, P::R0 * P::R1>(u, tid, lds);
     }
@@ -263,17 +269,17 @@ __device__ __forceinline__ void line_fft_partial(cf (&u)[8], const FftTw<N>& tw,
 
 // The last stage (radix 8, p = N/8) for butterfly j of a line whose image is `lds`; `tail` is the LDS copy
 // [m-1][j] of the twiddles exp(-2 pi i m j / N) (fill_tail_table).  On exit u[q] is the output at position j + q*N/8.
-template <int N, int SIGN, int ROUND = 1, class L>
+template <int N, int SIGN, int ROUND = 1, bool EX = BDOF_EX_ALL, class L>
 __device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* tail) {
     constexpr int T = N / 8;
     cf w[7], wl[7];
 #pragma unroll
     for (int m = 1; m < 8; ++m) {
         w[m - 1] = tail[(m - 1) * T + j];
-        wl[m - 1] = tail[((BDOF_TWC > 1 ? 7 : 0) + m - 1) * T + j];
+        wl[m - 1] = tail[((EX ? 7 : 0) + m - 1) * T + j];
     }
     stage_read<N, 8>(u, j, lds);
 #pragma unroll
-    for (int m = 1; m < 8; ++m) u[m] = tw_mul<SIGN>(u[m], w[m - 1], wl[m - 1]);
-    dft8<SIGN, ROUND>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+    for (int m = 1; m < 8; ++m) u[m] = tw_mul<SIGN, EX>(u[m], w[m - 1], wl[m - 1]);
+    dft8<SIGN, EX ? 0 : ROUND>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
 }

@@ -56,7 +56,7 @@ template <int T> struct RowLds {
 //   dst[(pos) * ld + r] = scale * out(row r, position pos),  pos = j + q*T
 // Called by all threads between two workgroup barriers.
 // ---------------------------------------------------------------------------------------------
-template <int N, int SIGN, int ROUND = 1>
+template <int N, int SIGN, int ROUND = 1, bool EX = BDOF_EX_ALL>
 __device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, size_t ld, float scale, const cf* tail) {
     typedef RowCfg<N> C;
 #pragma nounroll
@@ -65,7 +65,7 @@ __device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, 
         const int r = q % C::TILE, j = q / C::TILE;
         RowLds<C::T> lds{smem + r * C::RS};
         cf u[8];
-        last_stage<N, SIGN, ROUND>(u, j, lds, tail);
+        last_stage<N, SIGN, ROUND, EX>(u, j, lds, tail);
 #pragma unroll
         for (int m = 0; m < 8; ++m) dst[(size_t)(j + m * C::T) * ld + r] = cscale(u[m], scale);
     }
@@ -227,9 +227,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * BDOF_TWC];
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * (BDOF_EX_ALL ? 2 : 1)];
     FftTw<NY> tw;
-    __shared__ cf smem_tail[7 * C::T * BDOF_TWC];
+    __shared__ cf smem_tail[7 * C::T * (BDOF_EX_ALL ? 2 : 1)];
     tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -304,15 +304,16 @@ struct RowPropArgs {
     const cf* twiddle;
 };
 
-template <int NX>
+// EX: exact transform constants (hi + lo twiddles, bdof_fft.h) — the instance the adjoint sweep launches
+template <int NX, bool EX = BDOF_EX_ALL>
 __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_prop(RowPropArgs a) {
     typedef RowCfg<NX> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<NX>::LDS_CNT * BDOF_TWC];
+    __shared__ cf smem_tw[FftTw<NX>::LDS_CNT * (EX ? 2 : 1)];
     FftTw<NX> tw;
-    __shared__ cf smem_tail[7 * C::T * BDOF_TWC];
-    tw.load(a.twiddle, tid, smem_tw, smem_tail);
+    __shared__ cf smem_tail[7 * C::T * (EX ? 2 : 1)];
+    tw.template load<EX>(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NY / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -328,17 +329,17 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_pro
             for (int m = 0; m < 8; ++m) u[m] = src[tid + m * C::T];
 #pragma unroll
             for (int m = 0; m < 8; ++m) hv[m] = hrow[tid + m * C::T];
-            line_fft<NX, -1>(u, tw, tid, lds);
+            line_fft<NX, -1, 1, EX>(u, tw, tid, lds);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 cf t = hv[m];
                 if (a.conj_h) t.y = -t.y;
                 u[m] = cmul(u[m], cscale(t, a.scale));
             }
-            line_fft_partial<NX, +1, 2>(u, tw, tid, lds);      // constants rounded up here, down elsewhere (bdof_fft.h)
+            line_fft_partial<NX, +1, 2, EX>(u, tw, tid, lds);  // constants rounded up here, down elsewhere (bdof_fft.h)
         }
         __syncthreads();
-        transposed_tail<NX, +1, 2>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, smem_tail);
+        transposed_tail<NX, +1, 2, EX>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, smem_tail);
         __syncthreads();
     }
 }
@@ -452,9 +453,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
     constexpr int S1 = FAR ? -1 : +1;     // direction of the first transform; the second is the opposite
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<N>::LDS_CNT * BDOF_TWC];
+    __shared__ cf smem_tw[FftTw<N>::LDS_CNT * (BDOF_EX_ALL ? 2 : 1)];
     FftTw<N> tw;
-    __shared__ cf smem_tail[7 * C::T * BDOF_TWC];
+    __shared__ cf smem_tail[7 * C::T * (BDOF_EX_ALL ? 2 : 1)];
     tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.R / C::TILE;
     double acc = 0.0, acc2 = 0.0;
@@ -591,10 +592,12 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * BDOF_TWC];
+    // the transforms of the ADJOINT field run with exact constants (EX, bdof_fft.h); re-deriving phi from the tape does not
+    constexpr bool EX = BDOF_EX_ADJ;
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * (EX ? 2 : 1)];
     FftTw<NY> tw;
-    __shared__ cf smem_tail[7 * C::T * BDOF_TWC];
-    tw.load(a.twiddle, tid, smem_tw, smem_tail);
+    __shared__ cf smem_tail[7 * C::T * (EX ? 2 : 1)];
+    tw.template load<EX>(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
 #pragma unroll
                 for (int m = 0; m < 8; ++m) p[m] = PF ? modulate_eps(p[m], pc[m], db[m]) : modulate_eps_s(p[m], a.carrier, db[m], a.cshift);
             }
-            line_fft<NY, +1>(g, tw, tid, lds);
+            line_fft<NY, +1, 1, EX>(g, tw, tid, lds);
             float2* gdst = a.grot + (((size_t)b * a.grot_S + a.grot_z) * a.NX + x) * NY;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
@@ -647,11 +650,11 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
                 for (int m = 0; m < 8; ++m)
                     pd[tid + m * C::T] = GC ? cadd(g[m], cmulc(gam, make_float2(1.f + a.ac.cbm1.x, a.ac.cbm1.y))) : g[m];
             }
-            if (a.gout) line_fft_partial<NY, -1>(g, tw, tid, lds);
+            if (a.gout) line_fft_partial<NY, -1, 1, EX>(g, tw, tid, lds);
         }
         if (a.gout) {
             __syncthreads();
-            transposed_tail<NY, -1>(smem, a.gout + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
+            transposed_tail<NY, -1, 1, EX>(smem, a.gout + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
             __syncthreads();
         }
     }
@@ -1745,9 +1748,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_rea
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * BDOF_TWC];
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * (BDOF_EX_ALL ? 2 : 1)];
     FftTw<NY> tw;
-    __shared__ cf smem_tail[7 * C::T * BDOF_TWC];
+    __shared__ cf smem_tail[7 * C::T * (BDOF_EX_ALL ? 2 : 1)];
     tw.load(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

@@ -30,8 +30,9 @@ def phantom(shape):
     return d
 
 
-def data_from_phantom(orc, shape, n_theta):
-    """exchange/data of G18, (n_theta, Y, X) complex64: the oracle's forward model on the phantom, 1 um to the detector."""
+def data_from_phantom(orc, shape, n_theta, noise=0.0):
+    """exchange/data of G18, (n_theta, Y, X) complex64: the oracle's forward model on the phantom, 1 um to the detector;
+    noise: relative amplitude noise (seeded), as measured data have."""
     d = phantom(shape)
     coords = orc.rotation_lookup(list(shape), n_theta)
     one, zero = np.ones(shape[:2]), np.zeros(shape[:2])
@@ -41,4 +42,7 @@ def data_from_phantom(orc, shape, n_theta):
         w, _ = orc.multislice_propagate_batch_numpy(rot[..., 0], rot[..., 1], one, zero, 5000., 1e-7, 1e-4, rot[..., 0].shape,
                                                     return_probe_array=False)
         out.append(w[0])
-    return np.array(out).astype(np.complex64)
+    out = np.array(out)
+    if noise:
+        out = out * (1 + noise * np.random.default_rng(18).normal(size=out.shape))
+    return out.astype(np.complex64)

@@ -14,7 +14,8 @@ Run only in the build container (needs /root/reference, which never travels):
     python tests/golden/make_golden.py --g15      # G15 (reconstruct_fullfield's loop around np_funcs' FFT forward model)
     python tests/golden/make_golden.py --g16      # G16 (tensorflow_recon/create_noisy_data.py: Poisson noise, ptychography branch)
     python tests/golden/make_golden.py --g17      # G17 (reconstruct_ptychography's loop around np_funcs' FFT forward model)
-    python tests/golden/make_golden.py --g18      # G18 (G15 at BASELINE config 2's size, 256^3; ~10 min)
+    python tests/golden/make_golden.py --g18      # G18 (G15 at BASELINE config 2's size, 256^3; ~2 min)
+    python tests/golden/make_golden.py --g19      # G19 (G18 with 2 % amplitude noise on the data, as measured data have)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -821,7 +822,7 @@ def main_g14(fft=False):
     print('wrote', 'g17' if fft else 'g14')
 
 
-def main_g15(n=64):
+def main_g15(n=64, noise=0.0):
     """G15: reconstruct_fullfield at (64, 64, 64) around np_funcs' FFT forward; gradient by the oracle's analytic adjoint.
     n = 256 is G18: the same at BASELINE config 2's volume size (256^3, 256 slices).  There the measured data are not stored
     (4 x 256^2 complex values): generator and test both compute them with the oracle's forward model from the phantom formula
@@ -910,7 +911,7 @@ def main_g15(n=64):
                 store['prj'] = prj.astype('complex64')
                 g15['prj'] = store['prj']
             else:
-                store['prj'] = g13_inputs.data_from_phantom(orc, (n, n, n), n_theta)
+                store['prj'] = g13_inputs.data_from_phantom(orc, (n, n, n), n_theta, noise)
             np.random.seed(5)
             with contextlib.redirect_stdout(io.StringIO()):
                 ref_ff.reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, n_epochs=2, learning_rate=1e-7, minibatch_size=mb,
@@ -924,8 +925,9 @@ def main_g15(n=64):
             print('done: |delta - init| max =', g15['delta_moved_max'])
         finally:
             os.chdir(cwd)
-    np.savez_compressed(os.path.join(HERE, 'g15_reconstruct_fullfield_fft_64.npz' if n == 64 else 'g18_reconstruct_fullfield_fft_256.npz'), **g15)
-    print('wrote', 'g15' if n == 64 else 'g18')
+    name = 'g15_reconstruct_fullfield_fft_64.npz' if n == 64 else ('g19_reconstruct_fullfield_fft_256_noisy.npz' if noise else 'g18_reconstruct_fullfield_fft_256.npz')
+    np.savez_compressed(os.path.join(HERE, name), **g15)
+    print('wrote', name)
 
 
 def main_g16():
@@ -1053,6 +1055,8 @@ if __name__ == '__main__':
         main_g14(fft=True)
     elif '--g18' in sys.argv:
         main_g15(n=256)
+    elif '--g19' in sys.argv:
+        main_g15(n=256, noise=0.02)
     elif '--g16' in sys.argv:
         main_g16()
     else:

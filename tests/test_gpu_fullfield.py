@@ -266,20 +266,22 @@ def test_reconstruct_fullfield_vs_the_reference_loop_fft(tmp_path, monkeypatch):
     assert stats[2] <= 0.01 and stats[3] <= 5e-5, stats
 
 
-def test_reconstruct_fullfield_vs_the_reference_loop_at_cfg2_size(tmp_path, monkeypatch):
+@pytest.mark.parametrize('fixture,noise', [('g18_reconstruct_fullfield_fft_256.npz', 0.0), ('g19_reconstruct_fullfield_fft_256_noisy.npz', 0.02)])
+def test_reconstruct_fullfield_vs_the_reference_loop_at_cfg2_size(tmp_path, monkeypatch, fixture, noise):
     """Golden vector G18: the comparison of G15 at BASELINE config 2's volume size — 256^3, 256 slices, 4 angles in minibatches
     of 2, two epochs.  The data (an input: both sides only have to read the same array) come from the oracle's forward model
-    on a formula phantom, computed here as the generator did; the reference loop's volumes are stored on every eighth voxel."""
+    on a formula phantom, computed here as the generator did; the reference loop's volumes are stored on every eighth voxel.
+    G19 is the same with 2 % (seeded) amplitude noise on the data, the regime measured data are in."""
     import sys
     from beyond_dof_amd import h5io, tiffio
     from beyond_dof_amd.fullfield import reconstruct_fullfield
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
     sys.path.insert(0, gdir)
     import g13_inputs
-    g = np.load(os.path.join(gdir, 'g18_reconstruct_fullfield_fft_256.npz'))
+    g = np.load(os.path.join(gdir, fixture))
     n = 256
     init_d, init_b = g13_inputs.initial_guess((n, n, n))
-    prj = g13_inputs.data_from_phantom(orc, (n, n, n), 4)
+    prj = g13_inputs.data_from_phantom(orc, (n, n, n), 4, noise)
     monkeypatch.chdir(tmp_path)
     os.makedirs('case')
     h5io.write_dataset('case/data.h5', 'exchange/data', prj)
@@ -292,7 +294,7 @@ def test_reconstruct_fullfield_vs_the_reference_loop_at_cfg2_size(tmp_path, monk
     d, b = d[::8, ::8, ::8], b[::8, ::8, ::8]
     rel = lambda a, c: np.linalg.norm(a - c) / np.linalg.norm(c)
     stats = (np.abs(d - g['delta_sub']).max() / lr, rel(d, g['delta_sub']), np.abs(b - g['beta_sub']).max() / lr, rel(b, g['beta_sub']))
-    print('G18 stats', stats)
-    # measured: delta 2.1e-5, beta 8.2e-5 relative, no voxel more than 0.008 of a step away (64 slices, G15: 6.7e-6 — the float32
-    # adjoint sweep's error grows with depth)
-    assert stats[0] <= 0.05 and stats[1] <= 3e-5 and stats[3] <= 1.5e-4, stats
+    print('G18 stats' if not noise else 'G19 stats', stats)
+    # measured: G18 (noise-free data) delta 1.34e-5, beta 5.8e-5; G19 (2 % noise) delta 8.0e-6, beta 3.0e-5 — inside the north
+    # star's 1e-5 where the residual is not at the float32 floor (2.1e-5 / 1.68e-5 with -DBDOF_FAST_ADJOINT)
+    assert stats[0] <= 0.05 and stats[1] <= (1e-5 if noise else 2e-5) and stats[3] <= 1e-4, stats
