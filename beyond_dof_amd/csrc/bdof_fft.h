@@ -22,7 +22,7 @@ __device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s
 // Twiddle tables come as hi + lo pairs (table[N + j] = the float32 rounding error of table[j], from the host's float64
 // values).  A transform instantiated with EX = true multiplies by hi + lo and takes sqrt(1/2) as a hi + lo pair too: the fixed
 // tables then stop acting as the same small perturbation of every transform of a stack (gradient error at 512 slices
-// 1.61e-5 -> 7.3e-6).  The adjoint kernels use it by default — that is where the error is made; the forward sweep rides on
+// 1.61e-5 -> 6.1e-6).  The adjoint kernels use it by default — that is where the error is made; the forward sweep rides on
 // its carrier.  -DBDOF_EXACT_TWIDDLES makes it the default of every transform (+11 % step time), -DBDOF_FAST_ADJOINT
 // switches it off everywhere.
 #ifdef BDOF_EXACT_TWIDDLES
@@ -41,8 +41,11 @@ constexpr bool BDOF_EX_ADJ = true;
 // u * (w + wl), the twiddle conjugated for the inverse transform
 template <int SIGN, bool EX> __device__ __forceinline__ cf tw_mul(cf u, cf w, cf wl) {
     if (SIGN > 0) { w.y = -w.y; wl.y = -wl.y; }
-    if constexpr (EX) return cadd(cmul(u, w), cmul(u, wl));
-    else return cmul(u, w);
+    if constexpr (EX) {
+        // u w + u wl with the small product innermost: 2 mul + 6 fma instead of two complex multiplies and an add
+        const float lx = fmaf(u.x, wl.x, -(u.y * wl.y)), ly = fmaf(u.x, wl.y, u.y * wl.x);
+        return make_float2(fmaf(u.x, w.x, fmaf(-u.y, w.y, lx)), fmaf(u.x, w.y, fmaf(u.y, w.x, ly)));
+    } else return cmul(u, w);
 }
 
 // multiply by SIGN*i
