@@ -23,8 +23,8 @@ __device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s
 // values).  A transform instantiated with EX = true multiplies by hi + lo and takes sqrt(1/2) as a hi + lo pair too: the fixed
 // tables then stop acting as the same small perturbation of every transform of a stack (gradient error at 512 slices
 // 1.61e-5 -> 6.1e-6).  The adjoint kernels use it by default — that is where the error is made; the forward sweep rides on
-// its carrier.  -DBDOF_EXACT_TWIDDLES makes it the default of every transform (+11 % step time), -DBDOF_FAST_ADJOINT
-// switches it off everywhere.
+// its carrier.  -DBDOF_EXACT_TWIDDLES makes it the default of every transform (+3 % step time), -DBDOF_FAST_ADJOINT
+// switches it off everywhere (-3 %).
 #ifdef BDOF_EXACT_TWIDDLES
 #ifndef BDOF_EXACT_CONSTANTS
 #define BDOF_EXACT_CONSTANTS 1
