@@ -29,7 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ROUND = 'r02'
+ROUND = 'r03'
 # algorithmic bytes per pixel per launch (they sum to SURVEY §8(d)'s 104 B per slice-step)
 BYTES_PER_PX = {'row_fwd': 24.0, 'col_prop': 16.0, 'row_bwd': 40.0, 'rot_adjoint': 8.0}
 HBM_PEAK = 8.0e12
@@ -61,9 +61,13 @@ def rocprof_avg_ms(kernel_class, n, mb):
     want = PMC_KERNEL[kernel_class]
     calls = total = 0.0                       # a class may have several instances (the transfer-function step: forward and exact adjoint)
     for row in csv.DictReader(open(STATS_1STREAM)):
-        if row['Name'].replace('void ', '').startswith(want):
-            calls += float(row['Calls'])
+        name = row['Name'].replace('void ', '')
+        if name.startswith(want):
             total += float(row['TotalDurationNs'])
+            # the rotation adjoint is TWO kernels per call of the class (k_rot_adjoint, then k_rot_adjoint_heavy for the clamped
+            # border rows): their times add up, the calls are those of the first
+            if not (kernel_class == 'rot_adjoint' and name.startswith('k_rot_adjoint_heavy')):
+                calls += float(row['Calls'])
     return total / calls * 1e-6 if calls else None
 
 
@@ -119,37 +123,111 @@ def cpu_baseline(size, n_slice, seed=11):
 
 def self_launch(n_ranks):
     """`python bench.py --gpus N` outside a launcher: start N ranks of this same command, one per GPU.  This process only
-    spawns and waits — it never loads the HIP library — and rank 0's stdout is this process's stdout (one JSON line)."""
+    spawns and waits — it never loads the HIP library — and rank 0's stdout is this process's stdout (one JSON line).
+    The native control plane meets on a unix socket in a directory made here (0700, BDOF_RDZV): no port to lose between
+    picking it and using it.  The gloo rehearsal backend still needs a TCP port; a rank-0 bind failure there is retried
+    with a fresh one.  Every rank's stderr goes to a file of its own and is passed on afterwards, rank by rank."""
+    import shutil
     import socket
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n_ranks):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    try:
-        while any(p.poll() is None for p in procs):
-            time.sleep(0.2)
-            bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
-            if bad:                                    # one rank died: the others would wait for it forever
-                rc = bad[0]
-                break
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.terminate()
-        for p in procs:
-            try:
-                p.wait(timeout=30)
-            except subprocess.TimeoutExpired:
-                p.kill()
-    return rc or max((p.returncode or 0) for p in procs)
+    import tempfile
+    rc = 1
+    for attempt in range(3):
+        tmp = tempfile.mkdtemp(prefix='bdof_bench_')               # 0700
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        procs, errs = [], []
+        for r in range(n_ranks):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), BDOF_RDZV=os.path.join(tmp, 'rdzv.sock'))
+            env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            errs.append(open(os.path.join(tmp, 'rank{}.err'.format(r)), 'w+'))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
+        rc = 0
+        try:
+            while any(p.poll() is None for p in procs):
+                time.sleep(0.2)
+                bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+                if bad:                                    # one rank died: the others would wait for it forever
+                    rc = bad[0]
+                    break
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        rc = rc or max((p.returncode or 0) for p in procs)
+        texts = []
+        for r, f in enumerate(errs):
+            f.seek(0)
+            texts.append(f.read())
+            f.close()
+        shutil.rmtree(tmp, ignore_errors=True)
+        in_use = rc != 0 and any('EADDRINUSE' in t or 'ddress already in use' in t for t in texts)
+        if in_use and attempt < 2:
+            print('[bench] port {} was taken between picking and binding it: starting the ranks again'.format(port), file=sys.stderr)
+            continue
+        for r, t in enumerate(texts):
+            for line in t.splitlines():
+                print('[rank {}] {}'.format(r, line), file=sys.stderr)
+        break
+    return rc
+
+
+def rehearse_cpu(args, out):
+    """`--rehearse-cpu`: everything of an N-rank run that does not need a GPU — environment, rendezvous, schedule, barriers,
+    max-over-ranks timing, one JSON line from rank 0 — with the collectives on host arrays (gloo, or the native control
+    plane's socket star).  What tests/test_dist_gloo.py runs with 8 processes in the build container."""
+    from beyond_dof_amd.comm import SocketGroup, comm_backend, minibatch_schedule
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
+    mb = args.angles_per_gpu
+    sched = minibatch_schedule(args.n_theta, world, mb, rng=np.random.default_rng(1234))
+    mine = [chunk[rank * mb:(rank + 1) * mb] for chunk in sched]
+    if comm_backend() == 'gloo' and world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group('gloo')
+        def allmax(v):
+            t = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t[0])
+        def allsum(a):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+            dist.all_reduce(t)
+            return t.numpy()
+        barrier, close = dist.barrier, dist.destroy_process_group
+    else:
+        grp = SocketGroup(rank, world)
+        allmax = lambda v: float(np.max(grp.allgather(np.array([v]))))
+        allsum = lambda a: np.sum(grp.allgather(np.asarray(a)), axis=0)
+        barrier, close = grp.barrier, grp.close
+    barrier()
+    t0 = time.perf_counter()
+    g = np.zeros(1 << 16)
+    for i in range(args.warmup + args.steps):
+        g = allsum(np.full(1 << 16, float(rank + i)))              # stands in for the gradient exchange
+    barrier()
+    elapsed = allmax(time.perf_counter() - t0)
+    seen = allsum(np.bincount(np.concatenate(mine), minlength=args.n_theta).astype(np.float64))
+    if rank == 0:
+        expect = sum(range(world)) + world * (args.warmup + args.steps - 1)
+        out.write(json.dumps({'metric': 'rehearsal (no GPU work)', 'value': 0.0, 'unit': 'slice-steps/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': elapsed / max(1, args.steps) * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic', 'rehearsal': True,
+                          'config': {'workload': 'cpu rehearsal of the launch / rendezvous / schedule path', 'backend': comm_backend(),
+                                     'angles_covered': int((seen > 0).sum()), 'exchange_ok': bool(np.all(g == expect))}}) + '\n')
+        out.flush()
+    barrier()
+    close()
+    return 0
 
 
 def roofline_pass(solver, batch, hyper, n, mb, S, conv=False):
@@ -218,6 +296,7 @@ def main():
                     help="'bilinear': the TF twin's tf_rotate instead of the cnn variant's fused nearest-neighbour tables, for comparison")
     ap.add_argument('--propagator', default='fft', choices=['fft', 'conv'],
                     help="'conv': the reference entry points' truncated real-space kernel (17 taps), for comparison")
+    ap.add_argument('--rehearse-cpu', action='store_true', help='launch, rendezvous, schedule and timing path of an N-rank run without GPU work')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -228,6 +307,8 @@ def main():
     sys.stdout.flush()
     real_stdout = os.fdopen(os.dup(1), 'w')
     os.dup2(2, 1)
+    if args.rehearse_cpu:
+        return rehearse_cpu(args, real_stdout)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -286,6 +367,17 @@ def main():
     elapsed = time.perf_counter() - t0
     if comm.size > 1:
         elapsed = float(comm.allreduce_max_host(np.array([elapsed]))[0])
+    # where the tail of a step goes (rotation adjoint, gradient exchange, Adam, all-gather), from stream-ordered time stamps in
+    # two extra steps after the timed region; max over ranks
+    solver.time_tail = True
+    tail = []
+    for i in range(2):
+        run(args.warmup + args.steps + i)
+        tail.append(solver.tail_ms())
+    solver.time_tail = False
+    tail_ms = float(np.mean(tail))
+    if comm.size > 1:
+        tail_ms = float(comm.allreduce_max_host(np.array([tail_ms]))[0])
     groups = solver.eng.batch_groups(mb)
     S = n
     roof = None if args.no_profile or args.rotation != 'nearest' else roofline_pass(solver, my_batches[0], hyper, n, mb, S, conv=args.propagator == 'conv')
@@ -310,7 +402,10 @@ def main():
                           'exchange': ('none (1 rank)' if world == 1 and not getattr(comm, 'always_reduce', False) else
                                        '{} ({} slab(s), {})'.format(comm.backend, n_slabs, 'reduce-scatter + sharded Adam + all-gather'
                                                                     if sharded else 'all-reduce')),
-                          'allreduce_slabs': n_slabs, 'sharded_adam': bool(sharded), 'propagator': args.propagator, 'rotation': args.rotation,
+                          'allreduce_slabs': n_slabs, 'sharded_adam': bool(sharded), 'exchange_ms': tail_ms, 'tail_tuning_ms': solver.tuned,
+                          'exchange_ms_note': 'tail of a step on the ctx stream: rotation adjoint + gradient exchange + Adam (+ all-gather), '
+                                              'slab-pipelined; max over ranks, two steps after the timed region',
+                          'propagator': args.propagator, 'rotation': args.rotation,
                           'adjoint': 'recompute (tape-free)' if args.recompute else 'tape',
                           'hbm_used_GiB': solver.ctx.mem_used() / 2.0 ** 30},
                'roofline': roof}

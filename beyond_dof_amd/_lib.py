@@ -26,8 +26,12 @@ _SIGNATURES = {
     'bdof_sync': (ctypes.c_int, [_vp]),
     'bdof_stream': (_vp, [_vp]),
     'bdof_device_count': (ctypes.c_int, []),
+    'bdof_device_pci_bus_id': (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
+    'bdof_timer_mark': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'bdof_timer_elapsed': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     'bdof_configure': (ctypes.c_int, [_vp] + [ctypes.c_int] * 5),
     'bdof_set_physics': (ctypes.c_int, [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
+    'bdof_set_physics_f64': (ctypes.c_int, [_vp, _vp, _vp]),
     'bdof_set_probe': (ctypes.c_int, [_vp, _vp, ctypes.c_double, ctypes.c_double]),
     'bdof_set_meas_mode': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_probe_stack_supported': (ctypes.c_int, [_vp]),

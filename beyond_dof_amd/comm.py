@@ -17,9 +17,10 @@ Device collectives share one interface, stream-ordered against a bdof ctx:
   comm.wait(ctx, t)                                     the ctx stream waits for that collective
 """
 import ctypes
+import json
 import os
-import pickle
 import socket
+import stat
 import struct
 import time
 
@@ -95,19 +96,89 @@ def _recv_msg(sock):
     return _recv_exact(sock, n)
 
 
+def _encode(obj):
+    """Wire form of the few things the control plane carries — None, bytes, numpy arrays, JSON-able scalars / lists / dicts.
+    No pickle: a peer's message is parsed, never executed."""
+    if obj is None:
+        return b'N'
+    if isinstance(obj, (bytes, bytearray)):
+        return b'B' + bytes(obj)
+    if isinstance(obj, np.ndarray):
+        a = np.ascontiguousarray(obj)
+        if a.dtype.hasobject:
+            raise TypeError('object arrays are not sent over the rendezvous socket')
+        head = json.dumps({'dtype': a.dtype.str, 'shape': list(a.shape)}).encode()
+        return b'A' + struct.pack('<I', len(head)) + head + a.tobytes()
+    if isinstance(obj, (np.integer, np.floating)):
+        obj = obj.item()
+    return b'J' + json.dumps(obj).encode()
+
+
+def _decode(data):
+    tag, body = data[:1], data[1:]
+    if tag == b'N':
+        return None
+    if tag == b'B':
+        return bytes(body)
+    if tag == b'A':
+        (n,) = struct.unpack('<I', body[:4])
+        head = json.loads(body[4:4 + n].decode())
+        return np.frombuffer(body[4 + n:], dtype=np.dtype(head['dtype'])).reshape(head['shape']).copy()
+    if tag == b'J':
+        return json.loads(body.decode())
+    if tag == b'L':
+        items, off = [], 0
+        while off < len(body):
+            (n,) = struct.unpack('<Q', body[off:off + 8])
+            items.append(_decode(body[off + 8:off + 8 + n]))
+            off += 8 + n
+        return items
+    raise ValueError('malformed rendezvous message (tag {!r})'.format(tag))
+
+
+def _encode_list(items):
+    return b'L' + b''.join(struct.pack('<Q', len(e)) + e for e in items)
+
+
+def rendezvous_dir():
+    """A directory only this user can enter (0700, owned by us): $XDG_RUNTIME_DIR when the session has one, else
+    /tmp/bdof-<uid>.  A socket in plain /tmp could be pre-created or bound by another local user."""
+    base = os.environ.get('XDG_RUNTIME_DIR')
+    if base and os.path.isdir(base) and os.stat(base).st_uid == os.getuid():
+        d = os.path.join(base, 'bdof')
+    else:
+        d = '/tmp/bdof-{}'.format(os.getuid())
+    try:
+        os.makedirs(d, mode=0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError('rendezvous directory {} is not a private directory of uid {} (mode {:o}, owner {})'.format(
+            d, os.getuid(), st.st_mode & 0o777, st.st_uid))
+    return d
+
+
 def rendezvous_path():
     """One node, one job per (MASTER_ADDR, MASTER_PORT) — the launcher's own key for the job (torch.distributed.run
-    exports both; bench.py's self-launch picks a free port).  BDOF_RDZV overrides the path."""
+    exports both; bench.py's self-launch passes a socket in a directory of its own through BDOF_RDZV)."""
     p = os.environ.get('BDOF_RDZV')
     if p:
         return p
-    return '/tmp/bdof_rdzv_{}_{}_{}.sock'.format(os.getuid(), os.environ.get('MASTER_ADDR', '127.0.0.1'),
-                                                 os.environ.get('MASTER_PORT', '29500'))
+    return os.path.join(rendezvous_dir(), 'rdzv_{}_{}.sock'.format(os.environ.get('MASTER_ADDR', '127.0.0.1'),
+                                                                   os.environ.get('MASTER_PORT', '29500')))
+
+
+def _peer_uid(sock):
+    """uid of the process at the other end of a unix-domain socket (SO_PEERCRED)."""
+    cred = sock.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize('3i'))
+    return struct.unpack('3i', cred)[1]
 
 
 class SocketGroup(object):
-    """Star of unix-domain stream sockets on rank 0: rendezvous + small host-side collectives (pickled objects).
-    Rank 0 binds the path (a stale file of a dead job is replaced), the others connect with retries."""
+    """Star of unix-domain stream sockets on rank 0: rendezvous + small host-side collectives (None / bytes / numpy arrays /
+    JSON-able values, see _encode).  Rank 0 binds the path (a stale file of a dead job is replaced), the others connect with
+    retries; both ends check that the peer runs under the same uid (SO_PEERCRED)."""
 
     def __init__(self, rank, size, path=None, timeout=None):
         self.rank, self.size = int(rank), int(size)
@@ -129,7 +200,10 @@ class SocketGroup(object):
                 while len(self.peers) < self.size - 1:
                     conn, _ = srv.accept()
                     conn.settimeout(timeout)
-                    r, n = pickle.loads(_recv_msg(conn))
+                    if _peer_uid(conn) != os.getuid():
+                        conn.close()
+                        raise RuntimeError('rendezvous {}: a process of uid {} connected'.format(self.path, _peer_uid(conn)))
+                    r, n = [int(v) for v in _decode(_recv_msg(conn))]
                     if n != self.size or not (0 < r < self.size) or r in self.peers:
                         conn.close()
                         raise RuntimeError('rendezvous {}: unexpected peer (rank {}, world {}), this job has world {}'.format(
@@ -153,10 +227,15 @@ class SocketGroup(object):
                 try:
                     s.connect(self.path)
                     s.settimeout(timeout)
-                    _send_msg(s, pickle.dumps((self.rank, self.size)))
+                    if _peer_uid(s) != os.getuid():
+                        raise RuntimeError('rendezvous {}: the listener runs under another uid'.format(self.path))
+                    _send_msg(s, _encode([self.rank, self.size]))
                     if _recv_msg(s) == b'ok':        # a dying stale listener would close instead
                         self.sock = s
                         break
+                except RuntimeError:
+                    s.close()
+                    raise
                 except (OSError, ConnectionError):
                     pass
                 s.close()
@@ -169,13 +248,14 @@ class SocketGroup(object):
         if self.size == 1:
             return [obj]
         if self.rank == 0:
-            items = [obj] + [pickle.loads(_recv_msg(self.peers[r])) for r in range(1, self.size)]
-            blob = pickle.dumps(items, protocol=pickle.HIGHEST_PROTOCOL)
+            mine = _encode(obj)
+            enc = [mine] + [_recv_msg(self.peers[r]) for r in range(1, self.size)]
+            blob = _encode_list(enc)
             for r in range(1, self.size):
                 _send_msg(self.peers[r], blob)
-            return items
-        _send_msg(self.sock, pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
-        return pickle.loads(_recv_msg(self.sock))
+            return _decode(blob)
+        _send_msg(self.sock, _encode(obj))
+        return _decode(_recv_msg(self.sock))
 
     def bcast(self, obj, root=0):
         return self.allgather(obj if self.rank == root else None)[root]
@@ -217,7 +297,7 @@ class RcclComm(object):
         if self._h is not None:
             self._destroy()
         lib = ctx.lib
-        where = self.group.allgather((socket.gethostname(), int(ctx.device)))
+        where = [tuple(w) for w in self.group.allgather([socket.gethostname(), int(ctx.device)])]
         if len(set(where)) != len(where):
             raise RuntimeError('RCCL needs one device per rank, got {} — rehearse several ranks on one GPU with '
                                'BDOF_COMM_BACKEND=gloo'.format(where))
@@ -232,6 +312,14 @@ class RcclComm(object):
         if rc != 0:
             raise RuntimeError('bdof_comm_create failed ({}): {}'.format(rc, (lib.bdof_comm_last_error(None) or b'').decode()))
         self._h, self._lib, self._device = h.value, lib, ctx.device
+        # one line per rank on stderr: a wrong rank -> GPU map (two ranks on one device's neighbour, a masked device list) shows
+        # here and nowhere else
+        bus = ctypes.create_string_buffer(64)
+        lib.bdof_device_pci_bus_id(int(ctx.device), bus, 64)
+        import sys
+        print('[bdof] rank {}/{} (local {}) pid {}: device {} pci {} rccl communicator of {} ranks ready'.format(
+            self.rank, self.size, self.local_rank, os.getpid(), ctx.device, bus.value.decode() or '?', lib.bdof_comm_size(self._h)),
+            file=sys.stderr, flush=True)
 
     def _check(self, rc):
         if rc != 0:

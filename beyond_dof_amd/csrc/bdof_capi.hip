@@ -23,6 +23,7 @@
 #define BDOF_ERR_SIZE (-3)
 
 #define BDOF_MAX_GROUPS 4
+#define BDOF_N_TIMERS 16
 #define BDOF_MAX_DEVICES 64
 struct bdof_ctx {
     int device = 0;
@@ -33,6 +34,7 @@ struct bdof_ctx {
     int n_side = -1;                             // -1: not probed yet
     std::vector<hipStream_t> side_all;           // every candidate created (kept until the ctx dies)
     hipEvent_t ev_fork = nullptr, ev_join[BDOF_MAX_GROUPS - 1] = {};
+    hipEvent_t timer[BDOF_N_TIMERS] = {};        // bdof_timer_mark
     int n_streams = -1;                          // -1 auto (1 or 2), else the number of groups to split a batch in
     int sub_b0 = 0, sub_part = 0;
     hipStream_t sub_stream = nullptr;
@@ -68,9 +70,14 @@ struct bdof_ctx {
     cf *hsT = nullptr, *hdetT = nullptr, *twR = nullptr, *res_carrier = nullptr;
     int meas_dev = 0;                           // bdof_set_meas_mode
     cf *pstack = nullptr, *pdet = nullptr, *pdetT = nullptr;      // carrier field of a localised probe (bdof_set_probe_stack); pdetT = det transposed
+    double2 *pdet64 = nullptr, *pdetT64 = nullptr;                // the same planes in float64 (bdof_set_probe_field): the residual |d| - m is formed in float64
     // generic-size engine (rocFFT): one plan pair per batch size
     bool generic = false;
     std::map<int, std::pair<rocfft_plan, rocfft_plan>> gplans;
+    // float64 adjoint sweep (bdof_configure flag 64; generic engine)
+    bool adj64 = false, have_h64 = false;
+    std::map<int, std::pair<rocfft_plan, rocfft_plan>> gplans64;
+    double2 *g64 = nullptr, *hs64 = nullptr, *hdet64 = nullptr;
     rocfft_execution_info ginfo = nullptr;
     void* gwork = nullptr;
     size_t gwork_sz = 0;
@@ -383,8 +390,8 @@ static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf*
     RowPropArgs a{sub_field(c, in), sub_field(c, out), h, B, c->NY, scale, conj_h, c->twX};
     DISPATCH_N(c->NX, {
         // the adjoint step runs the instance with exact transform constants (bdof_fft.h: that is where the gradient's error is made)
-        if (conj_h && BDOF_EX_ADJ) BDOF_LAUNCH(ps, (k_row_prop<N_, true>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
-        else BDOF_LAUNCH(ps, (k_row_prop<N_>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
+        if (conj_h ? BDOF_EX_ADJ : BDOF_EX_FWD_B) BDOF_LAUNCH(ps, (k_row_prop<N_, true>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
+        else BDOF_LAUNCH(ps, (k_row_prop<N_, false>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
     });
 }
 
@@ -434,7 +441,7 @@ static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool 
     ProfScope ps(c, BDOF_K_LOSS);
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NX,
                in_scale, out_scale, seed_scale, carrier, c->twY, pfield, c->meas_dev, nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0),
-               c->meas_dev ? (dref_override ? *dref_override : meas_dref(c)) : 0.f};
+               c->meas_dev ? (dref_override ? *dref_override : meas_dref(c)) : 0.f, pfield && pfield == c->pdet ? c->pdet64 : nullptr};
     int grid = 0;
     DISPATCH_N(c->NY, {
         grid = rows_grid<N_>(c, B, c->NX);
@@ -452,7 +459,7 @@ static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* ou
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NY,
                in_scale, out_scale, seed_scale, carrier_det(c), c->twX, pfield, 0,
                gc ? c->gcar + c->sub_b0 : nullptr, gc ? c->gt0 + c->sub_b0 : nullptr,
-               d2(carrier_end(c) * ((double)c->NX * (double)c->NY)), d2(carrier_end(c)), 0.f};
+               d2(carrier_end(c) * ((double)c->NX * (double)c->NY)), d2(carrier_end(c)), 0.f, pfield && pfield == c->pdetT ? c->pdetT64 : nullptr};
     int grid = 0;
     DISPATCH_N(c->NX, {
         grid = rows_grid<N_>(c, B, c->NY);
@@ -563,14 +570,16 @@ static bool g_rocfft_ready = false;
         if (s_ != rocfft_status_success) return fail((c), BDOF_ERR_STATE, std::string(#call) + ": rocfft status " + std::to_string((int)s_)); \
     } while (0)
 
-static int generic_plans(bdof_ctx* c, int B, rocfft_plan* fwd, rocfft_plan* inv) {
+static int generic_plans(bdof_ctx* c, int B, rocfft_plan* fwd, rocfft_plan* inv, bool dbl = false) {
     if (!g_rocfft_ready) { RFC(c, rocfft_setup()); g_rocfft_ready = true; }
-    auto it = c->gplans.find(B);
-    if (it == c->gplans.end()) {
+    auto& plans = dbl ? c->gplans64 : c->gplans;
+    const rocfft_precision prec = dbl ? rocfft_precision_double : rocfft_precision_single;
+    auto it = plans.find(B);
+    if (it == plans.end()) {
         const size_t lengths[2] = {(size_t)c->NY, (size_t)c->NX};      // fastest dimension first
         rocfft_plan pf = nullptr, pi = nullptr;
-        RFC(c, rocfft_plan_create(&pf, rocfft_placement_inplace, rocfft_transform_type_complex_forward, rocfft_precision_single, 2, lengths, (size_t)B, nullptr));
-        RFC(c, rocfft_plan_create(&pi, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, rocfft_precision_single, 2, lengths, (size_t)B, nullptr));
+        RFC(c, rocfft_plan_create(&pf, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec, 2, lengths, (size_t)B, nullptr));
+        RFC(c, rocfft_plan_create(&pi, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec, 2, lengths, (size_t)B, nullptr));
         size_t w1 = 0, w2 = 0;
         RFC(c, rocfft_plan_get_work_buffer_size(pf, &w1));
         RFC(c, rocfft_plan_get_work_buffer_size(pi, &w2));
@@ -582,7 +591,7 @@ static int generic_plans(bdof_ctx* c, int B, rocfft_plan* fwd, rocfft_plan* inv)
             HIPC(c, hipMalloc(&c->gwork, need));
             c->gwork_sz = need;
         }
-        it = c->gplans.emplace(B, std::make_pair(pf, pi)).first;
+        it = plans.emplace(B, std::make_pair(pf, pi)).first;
     }
     if (!c->ginfo) {
         RFC(c, rocfft_execution_info_create(&c->ginfo));
@@ -650,7 +659,7 @@ static int generic_forward(bdof_ctx* c, int B, void* out_wave, bool keep_tape) {
     if (out_wave) {
         const size_t n = (size_t)B * c->NX * c->NY;
         GLossArgs la{c->bufA, (cf*)out_wave, nullptr, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
-                     make_float2((float)a.real(), (float)a.imag()), 0.f, c->pdet, 0, 0.f, nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+                     make_float2((float)a.real(), (float)a.imag()), 0.f, c->pdet, 0, 0.f, nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0), nullptr};
         hipLaunchKernelGGL(k_g_loss, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, la);
     }
     return 0;
@@ -666,15 +675,44 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
     std::complex<double> a;
     if ((r = generic_forward_sweep(c, B, true, pf, pi, &a))) return r;
     const int egrid = g_elem_grid(c, n);
+    const bool f64 = c->adj64;
+    if (f64 && !c->have_h64) return fail(c, BDOF_ERR_STATE, "float64 adjoint: bdof_set_physics_f64 has not been called");
     {
         ProfScope ps(c, BDOF_K_LOSS);
-        const bool gc = use_adj_carrier(c);
+        const bool gc = use_adj_carrier(c) && !f64;
         GLossArgs la{c->bufA, (cf*)out_wave, meas, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
                      make_float2((float)a.real(), (float)a.imag()), 2.f / ((float)B * (float)c->NX * (float)c->NY), c->pdet, c->meas_dev,
-                     c->meas_dev ? meas_dref(c) : 0.f, gc ? c->gcar : nullptr, gc ? c->gt0 : nullptr, d2(a), d2(carrier_end(c))};
+                     c->meas_dev ? meas_dref(c) : 0.f, gc ? c->gcar : nullptr, gc ? c->gt0 : nullptr, d2(a), d2(carrier_end(c)), c->pdet ? c->pdet64 : nullptr,
+                     f64 ? c->g64 : nullptr, c->meas_dev ? std::abs(c->a0) : 0.0};
         hipLaunchKernelGGL(k_g_loss, dim3(egrid), dim3(256), 0, c->stream, la);
     }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, egrid, 1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
+    if (f64) {
+        // float64 adjoint sweep: g64 holds the seed G(d)
+        rocfft_plan pf64, pi64;
+        if ((r = generic_plans(c, B, &pf64, &pi64, true))) return r;
+        void* b64[1] = {c->g64};
+        auto prop64 = [&](const double2* h) -> int {
+            ProfScope ps(c, BDOF_K_COL_PROP);
+            RFC(c, rocfft_execute(pf64, b64, nullptr, c->ginfo));
+            hipLaunchKernelGGL(k_g_hmul64, dim3(egrid), dim3(256), 0, c->stream, c->g64, h, B, c->NX, c->NY, 1);
+            RFC(c, rocfft_execute(pi64, b64, nullptr, c->ginfo));
+            return 0;
+        };
+        if (c->det_mode == BDOF_DET_NEAR) { if ((r = prop64(c->hdet64))) return r; }
+        else if (c->det_mode == BDOF_DET_FAR) RFC(c, rocfft_execute(pi64, b64, nullptr, c->ginfo));
+        for (int z = c->S - 1; z >= 0; --z) {
+            const bool prop_after = z < c->S - 1 || (tf_all && c->det_mode != BDOF_DET_FAR);
+            if (prop_after && (r = prop64(c->hs64))) return r;
+            ProfScope ps(c, BDOF_K_ROW_BWD);
+            GBwd64Args ba{c->g64, c->tape + (size_t)z * fld, c->grot, c->obj, B, c->NX, c->NY, z, (double)c->k,
+                          d2(carrier_z(c, z) * (1.0 + c->cbm1)), c->pstack ? 1 : 0};
+            hipLaunchKernelGGL(k_g_bwd64, dim3(egrid), dim3(256), 0, c->stream, ba);
+        }
+        // G(psi_0) for bdof_probe_grad, where the float32 sweep leaves it
+        hipLaunchKernelGGL(k_d_to_f, dim3(egrid), dim3(256), 0, c->stream, c->g64, c->bufA, B * c->NX, c->NY, 0);
+        return 0;
+    }
     // adjoint of the detector step: bufA now holds the seed G(d)
     void* buf[1] = {c->bufA};
     if (c->det_mode == BDOF_DET_NEAR) {
@@ -694,8 +732,9 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
 }
 
 // ---- LDS-resident engine ---------------------------------------------------------------------------
-template <int N, int T, int WPE> static int resident_launch_t(bdof_ctx* c, const ResArgs& a, int grid) {
-    const size_t lds = sizeof(cf) * ((size_t)N * (N | 1) + N) + sizeof(long long) * 3 * N;
+template <int N, int T, int WPE> static int resident_launch_t(bdof_ctx* c, const ResArgs& a, int grid, int* waves) {
+    *waves = T / 64;
+    const size_t lds = sizeof(cf) * ((size_t)N * (N | 1) + 2 * N) + sizeof(long long) * 3 * N;
     static bool attr_set[BDOF_MAX_DEVICES] = {};      // the attribute is per device (a process may hold ctxs on several)
     if (!attr_set[c->device % BDOF_MAX_DEVICES]) {
         HIPC(c, hipFuncSetAttribute((const void*)k_resident<N, T, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -704,8 +743,8 @@ template <int N, int T, int WPE> static int resident_launch_t(bdof_ctx* c, const
     hipLaunchKernelGGL((k_resident<N, T, WPE>), dim3(grid), dim3(T), lds, c->stream, a);
     return 0;
 }
-template <int N> static int resident_launch(bdof_ctx* c, const ResArgs& a, int grid) {
-    return resident_launch_t<N, ResPlan<N>::T, ResPlan<N>::WPE>(c, a, grid);
+template <int N> static int resident_launch(bdof_ctx* c, const ResArgs& a, int grid, int* waves) {
+    return resident_launch_t<N, ResPlan<N>::T, ResPlan<N>::WPE>(c, a, grid, waves);
 }
 
 // One workgroup per wavefield: against the streaming kernels (sizes with a fused plan) the resident engine wins once the
@@ -732,23 +771,23 @@ static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, b
     ResArgs a{c->probe, c->hsT, c->hdetT, grad ? c->tape : nullptr, (size_t)c->Bmax * c->NX * c->NY, c->grot, c->obj, c->res_carrier,
               carrier_det(c), c->pstack, c->pdet, meas, (cf*)out_wave, c->partial, c->twR, B, c->S, c->det_mode,
               c->variant == BDOF_VARIANT_TF_ALL ? 1 : 0, grad ? 1 : 0, c->k, 2.f / ((float)B * (float)c->NX * (float)c->NY), c->meas_dev,
-              c->meas_dev ? meas_dref(c) : 0.f, grad ? c->gpsi0 : nullptr};
+              c->meas_dev ? meas_dref(c) : 0.f, grad ? c->gpsi0 : nullptr, c->pdet ? c->pdet64 : nullptr};
     const int grid = B < c->npartial ? B : c->npartial;
-    int r = 0;
+    int r = 0, waves = 1;
     switch (c->NX) {
-        case 32: r = resident_launch<32>(c, a, grid); break;
-        case 36: r = resident_launch<36>(c, a, grid); break;
-        case 48: r = resident_launch<48>(c, a, grid); break;
-        case 64: r = resident_launch<64>(c, a, grid); break;
-        case 72: r = resident_launch<72>(c, a, grid); break;
-        case 80: r = resident_launch<80>(c, a, grid); break;
-        case 96: r = resident_launch<96>(c, a, grid); break;
-        case 128: r = resident_launch<128>(c, a, grid); break;
+        case 32: r = resident_launch<32>(c, a, grid, &waves); break;
+        case 36: r = resident_launch<36>(c, a, grid, &waves); break;
+        case 48: r = resident_launch<48>(c, a, grid, &waves); break;
+        case 64: r = resident_launch<64>(c, a, grid, &waves); break;
+        case 72: r = resident_launch<72>(c, a, grid, &waves); break;
+        case 80: r = resident_launch<80>(c, a, grid, &waves); break;
+        case 96: r = resident_launch<96>(c, a, grid, &waves); break;
+        case 128: r = resident_launch<128>(c, a, grid, &waves); break;
         default: return fail(c, BDOF_ERR_SIZE, "no resident plan for this size");
     }
     if (r) return r;
     if (meas)
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, grid, 1.0 / ((double)B * c->NX * c->NY),
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, grid * waves, 1.0 / ((double)B * c->NX * c->NY),
                            c->loss_dev);
     HIPC(c, hipGetLastError());
     return 0;
@@ -770,6 +809,30 @@ int bdof_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int bdof_device_pci_bus_id(int device, char* out, int len) {
+    if (!out || len < 16) return BDOF_ERR_ARG;
+    out[0] = 0;
+    return (int)hipDeviceGetPCIBusId(out, len, device);
+}
+
+// stream-ordered time stamps on the ctx stream: bdof_timer_mark(slot) now, bdof_timer_elapsed(a, b) after a sync
+int bdof_timer_mark(bdof_ctx* c, int slot) {
+    if (!c || slot < 0 || slot >= BDOF_N_TIMERS) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    if (!c->timer[slot]) HIPC(c, hipEventCreate(&c->timer[slot]));
+    HIPC(c, hipEventRecord(c->timer[slot], c->stream));
+    return 0;
+}
+int bdof_timer_elapsed(bdof_ctx* c, int slot_a, int slot_b, double* ms) {
+    if (!c || !ms || slot_a < 0 || slot_a >= BDOF_N_TIMERS || slot_b < 0 || slot_b >= BDOF_N_TIMERS) return BDOF_ERR_ARG;
+    if (!c->timer[slot_a] || !c->timer[slot_b]) return fail(c, BDOF_ERR_STATE, "bdof_timer_elapsed: slot never marked");
+    HIPC(c, hipEventSynchronize(c->timer[slot_b]));
+    float f = 0.f;
+    HIPC(c, hipEventElapsedTime(&f, c->timer[slot_a], c->timer[slot_b]));
+    *ms = (double)f;
+    return 0;
 }
 
 int bdof_ctx_create(bdof_ctx** out, int device, void* stream) {
@@ -802,16 +865,21 @@ int bdof_ctx_create(bdof_ctx** out, int device, void* stream) {
 static void free_generic(bdof_ctx* c) {
     for (auto& kv : c->gplans) { (void)rocfft_plan_destroy(kv.second.first); (void)rocfft_plan_destroy(kv.second.second); }
     c->gplans.clear();
+    for (auto& kv : c->gplans64) { (void)rocfft_plan_destroy(kv.second.first); (void)rocfft_plan_destroy(kv.second.second); }
+    c->gplans64.clear();
+    for (double2** q : {&c->g64, &c->hs64, &c->hdet64}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    c->have_h64 = false;
     if (c->ginfo) { (void)rocfft_execution_info_destroy(c->ginfo); c->ginfo = nullptr; }
     if (c->gwork) { (void)hipFree(c->gwork); c->gwork = nullptr; c->gwork_sz = 0; }
 }
 
 static void free_workspace(bdof_ctx* c) {
     free_generic(c);
-    void* ptrs[] = {c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->taps_dev, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->gpsi0, c->partial, c->loss_dev};
+    void* ptrs[] = {c->pdet64, c->pdetT64, c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->taps_dev, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->gpsi0, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
     c->pstack = c->pdet = c->pdetT = nullptr;
+    c->pdet64 = c->pdetT64 = nullptr;
     c->resident = false;
     c->bufC = c->conv_scal = nullptr;
     c->taps_dev = nullptr;
@@ -834,6 +902,7 @@ void bdof_ctx_destroy(bdof_ctx* c) {
     if (c->mod) (void)hipFree(c->mod);
     if (c->cbar_dev) (void)hipFree(c->cbar_dev);
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto& e : c->timer) if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : c->side_all) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     for (int i = 0; i < BDOF_MAX_GROUPS - 1; ++i)
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
@@ -886,7 +955,7 @@ static int upload_twiddle(bdof_ctx* c, int N, cf** dst) {
 int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) {
     if (!c) return BDOF_ERR_ARG;
     if (NY < 1 || NX < 1 || S < 1 || Bmax < 1) return fail(c, BDOF_ERR_ARG, "NY, NX, S and Bmax must be >= 1");
-    const bool generic = (with_grad & 2) != 0 || !supported_n(NY) || !supported_n(NX);
+    const bool generic = (with_grad & (2 | 64)) != 0 || !supported_n(NY) || !supported_n(NX);
     if (generic && (size_t)NY * NX > ((size_t)1 << 26)) return fail(c, BDOF_ERR_SIZE, "wavefield too large");
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipStreamSynchronize(c->stream));
@@ -894,7 +963,8 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     c->NY = NY; c->NX = NX; c->S = S; c->Bmax = Bmax; c->with_grad = (with_grad & 1) != 0;
     c->generic = generic;
     c->recompute = (with_grad & 16) != 0 && !generic;      // the streaming engine's option; the others keep their tapes
-    c->resident = (with_grad & 6) == 0 && NX == NY && resident_supported(NX) && !std::getenv("BDOF_NO_RESIDENT");
+    c->adj64 = (with_grad & 64) != 0 && (with_grad & 1) != 0;
+    c->resident = (with_grad & (6 | 64)) == 0 && NX == NY && resident_supported(NX) && !std::getenv("BDOF_NO_RESIDENT");
     c->res_always = (with_grad & 8) != 0 || std::getenv("BDOF_FORCE_RESIDENT");
     c->res_dirty = true;
     c->have_physics = c->have_probe = c->tape_valid = false;
@@ -927,8 +997,14 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
         HIPC(c, hipMalloc((void**)&c->gcar, sizeof(double2) * (size_t)Bmax));
         HIPC(c, hipMalloc((void**)&c->gt0, sizeof(double2) * (size_t)Bmax));
     }
+    if (c->adj64) {
+        HIPC(c, hipMalloc((void**)&c->g64, sizeof(double2) * fld));
+        HIPC(c, hipMalloc((void**)&c->hs64, sizeof(double2) * NX * NY));
+        HIPC(c, hipMalloc((void**)&c->hdet64, sizeof(double2) * NX * NY));
+    }
     c->npartial = c->ncu * 16 + 64;
-    HIPC(c, hipMalloc((void**)&c->partial, sizeof(double) * 2 * c->npartial));
+    // the resident kernel leaves one pair per workgroup AND wave (up to 16 waves)
+    HIPC(c, hipMalloc((void**)&c->partial, sizeof(double) * 2 * c->npartial * (c->resident ? 16 : 1)));
     HIPC(c, hipMalloc((void**)&c->loss_dev, sizeof(double)));
     HIPC(c, hipMemsetAsync(c->loss_dev, 0, sizeof(double), c->stream));
     return 0;
@@ -977,7 +1053,22 @@ int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det
     c->det_mode = det_mode;
     c->variant = variant;
     c->have_physics = true;
+    c->have_h64 = false;             // float64 adjoint: the caller follows up with bdof_set_physics_f64
     c->mod_dirty = true;
+    return 0;
+}
+
+int bdof_set_physics_f64(bdof_ctx* c, const double* hs, const double* hs_det) {
+    if (!c || !hs) return BDOF_ERR_ARG;
+    if (!c->adj64) return fail(c, BDOF_ERR_STATE, "bdof_set_physics_f64 needs bdof_configure with flag 64 (float64 adjoint sweep)");
+    if (!c->have_physics) return fail(c, BDOF_ERR_STATE, "bdof_set_physics has not been called");
+    if (c->det_mode == BDOF_DET_NEAR && !hs_det) return fail(c, BDOF_ERR_ARG, "hs_det required for BDOF_DET_NEAR");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const size_t bytes = sizeof(double2) * (size_t)c->NX * c->NY;
+    HIPC(c, hipMemcpy(c->hs64, hs, bytes, hipMemcpyHostToDevice));
+    if (hs_det) HIPC(c, hipMemcpy(c->hdet64, hs_det, bytes, hipMemcpyHostToDevice));
+    c->have_h64 = true;
     return 0;
 }
 
@@ -1013,6 +1104,8 @@ int bdof_set_probe_stack(bdof_ctx* c, const float* stack, const float* det) {
     if (c->pstack) { (void)hipFree(c->pstack); c->pstack = nullptr; }
     if (c->pdet) { (void)hipFree(c->pdet); c->pdet = nullptr; }
     if (c->pdetT) { (void)hipFree(c->pdetT); c->pdetT = nullptr; }
+    if (c->pdet64) { (void)hipFree(c->pdet64); c->pdet64 = nullptr; }          // a host-supplied stack comes in float32 only
+    if (c->pdetT64) { (void)hipFree(c->pdetT64); c->pdetT64 = nullptr; }
     c->mod_dirty = true;
     if (!stack && !det) return 0;
     if (!stack || !det) return fail(c, BDOF_ERR_ARG, "bdof_set_probe_stack: both arrays or neither");
@@ -1082,9 +1175,16 @@ int bdof_set_probe_field(bdof_ctx* c, const double* probe, const double* hT, con
     if (c->pstack) { (void)hipFree(c->pstack); c->pstack = nullptr; }
     if (c->pdet) { (void)hipFree(c->pdet); c->pdet = nullptr; }
     if (c->pdetT) { (void)hipFree(c->pdetT); c->pdetT = nullptr; }
+    if (c->pdet64) { (void)hipFree(c->pdet64); c->pdet64 = nullptr; }
+    if (c->pdetT64) { (void)hipFree(c->pdetT64); c->pdetT64 = nullptr; }
     PF_HIP(hipMalloc((void**)&c->pstack, fld * (size_t)c->S));
     PF_HIP(hipMalloc((void**)&c->pdet, fld));
     PF_HIP(hipMalloc((void**)&c->pdetT, fld));
+    static const bool no_f64_det = std::getenv("BDOF_NO_F64_DET") != nullptr;      // A/B switch: residual from float32 planes as before
+    if (!no_f64_det) {
+        PF_HIP(hipMalloc((void**)&c->pdet64, dbytes));
+        PF_HIP(hipMalloc((void**)&c->pdetT64, dbytes));
+    }
     const int grid = g_elem_grid(c, n);
     void* buf[1] = {dp};
     auto step = [&](const double2* h) -> int {
@@ -1105,6 +1205,11 @@ int bdof_set_probe_field(bdof_ctx* c, const double* probe, const double* hT, con
     }
     hipLaunchKernelGGL(k_d_to_f, dim3(grid), dim3(256), 0, c->stream, dp, c->pdet, c->NX, c->NY, 0);
     hipLaunchKernelGGL(k_d_to_f, dim3(grid), dim3(256), 0, c->stream, dp, c->pdetT, c->NX, c->NY, 1);
+    // ... and unrounded: the detector kernels add the scattered wave to these and take |d| - m in float64 (loss_seed_f64)
+    if (c->pdet64) {
+        hipLaunchKernelGGL(k_d_copy, dim3(grid), dim3(256), 0, c->stream, dp, c->pdet64, c->NX, c->NY, 0);
+        hipLaunchKernelGGL(k_d_copy, dim3(grid), dim3(256), 0, c->stream, dp, c->pdetT64, c->NX, c->NY, 1);
+    }
     PF_HIP(hipGetLastError());
     PF_HIP(hipStreamSynchronize(c->stream));
 #undef PF_TRY
@@ -1315,7 +1420,7 @@ int bdof_field_loss_seed(bdof_ctx* c, void* field, const float* meas, int FX, in
     const size_t n = (size_t)FX * FY;
     const int egrid = g_elem_grid(c, n);
     GLossArgs la{(cf*)field, nullptr, meas, c->partial, 1, FX, FY, 0, make_float2(0.f, 0.f), (float)(2.0 / (double)n), nullptr, 0, 0.f,
-                 nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+                 nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0), nullptr};
     hipLaunchKernelGGL(k_g_loss, dim3(egrid), dim3(256), 0, c->stream, la);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, egrid, 1.0 / (double)n, c->loss_dev);
     HIPC(c, hipGetLastError());
@@ -1962,8 +2067,15 @@ int bdof_mask_shrink(bdof_ctx* c, const void* x, float* mask, size_t n, float th
 
 int bdof_gather_fields(bdof_ctx* c, void* dst, const void* src, const int* idx, int B, size_t bytes_per_field) {
     if (!c || !dst || !src || !idx || B < 1) return BDOF_ERR_ARG;
-    if (bytes_per_field % 16) return fail(c, BDOF_ERR_SIZE, "bdof_gather_fields: fields must be multiples of 16 bytes");
+    if (bytes_per_field % 4) return fail(c, BDOF_ERR_SIZE, "bdof_gather_fields: fields must be multiples of 4 bytes");
     HIPC(c, hipSetDevice(c->device));
+    if (bytes_per_field % 16) {
+        const size_t n4 = bytes_per_field / 4;
+        const int gx4 = (int)std::min<size_t>((n4 + 255) / 256, 64);
+        hipLaunchKernelGGL(k_gather_fields4, dim3(gx4, B < 1024 ? B : 1024), dim3(256), 0, c->stream, (float*)dst, (const float*)src, idx, B, n4);
+        HIPC(c, hipGetLastError());
+        return 0;
+    }
     const size_t n16 = bytes_per_field / 16;
     const int gx = (int)std::min<size_t>((n16 + 255) / 256, 64);
     hipLaunchKernelGGL(k_gather_fields, dim3(gx, B < 1024 ? B : 1024), dim3(256), 0, c->stream, (float4*)dst, (const float4*)src, idx, B, n16);

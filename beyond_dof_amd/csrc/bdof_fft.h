@@ -22,21 +22,38 @@ __device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s
 // Twiddle tables come as hi + lo pairs (table[N + j] = the float32 rounding error of table[j], from the host's float64
 // values).  A transform instantiated with EX = true multiplies by hi + lo and takes sqrt(1/2) as a hi + lo pair too: the fixed
 // tables then stop acting as the same small perturbation of every transform of a stack (gradient error at 512 slices
-// 1.61e-5 -> 6.1e-6).  The adjoint kernels use it by default — that is where the error is made; the forward sweep rides on
-// its carrier.  -DBDOF_EXACT_TWIDDLES makes it the default of every transform (+3 % step time), -DBDOF_FAST_ADJOINT
-// switches it off everywhere (-3 %).
-#ifdef BDOF_EXACT_TWIDDLES
+// 1.61e-5 -> 6.1e-6; reconstructed delta against the reference's loop at 256^3 on noise-free data 2.1e-5 -> 1.17e-5 with the
+// adjoint transforms exact -> 6.0e-6 with every transform exact).  Since round 3 EVERY transform is exact by default (parity
+// with the reference comes before the 2.8 % of step time it costs); -DBDOF_FAST_FORWARD takes the forward sweep's back to
+// plain float32 tables (round 2's default), -DBDOF_FAST_ADJOINT with it the adjoint sweep's too.
+#ifdef BDOF_FAST_FORWARD
+constexpr bool BDOF_EX_ALL = false;
+#else
 #ifndef BDOF_EXACT_CONSTANTS
 #define BDOF_EXACT_CONSTANTS 1
 #endif
 constexpr bool BDOF_EX_ALL = true;
-#else
-constexpr bool BDOF_EX_ALL = false;
 #endif
 #ifdef BDOF_FAST_ADJOINT
 constexpr bool BDOF_EX_ADJ = BDOF_EX_ALL;
 #else
 constexpr bool BDOF_EX_ADJ = true;
+#endif
+// per kernel of the FORWARD sweep (experiments: -DBDOF_FAST_FORWARD -DBDOF_EXACT_FWD_A / _B / _DET switch single ones back on)
+#ifdef BDOF_EXACT_FWD_A
+constexpr bool BDOF_EX_FWD_A = true;
+#else
+constexpr bool BDOF_EX_FWD_A = BDOF_EX_ALL;
+#endif
+#ifdef BDOF_EXACT_FWD_B
+constexpr bool BDOF_EX_FWD_B = true;
+#else
+constexpr bool BDOF_EX_FWD_B = BDOF_EX_ALL;
+#endif
+#ifdef BDOF_EXACT_DET
+constexpr bool BDOF_EX_DET = true;
+#else
+constexpr bool BDOF_EX_DET = BDOF_EX_ALL;
 #endif
 // u * (w + wl), the twiddle conjugated for the inverse transform
 template <int SIGN, bool EX> __device__ __forceinline__ cf tw_mul(cf u, cf w, cf wl) {

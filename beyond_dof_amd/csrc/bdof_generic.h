@@ -65,6 +65,9 @@ struct GLossArgs {
     double2* gcar;       // nullable [B]: adjoint carrier (AdjCarrier, bdof_kernels.h) — far field with a plane-wave carrier
     double2* gt0;
     double2 carrier_dd, a_end;
+    const double2* pdet64;   // nullable: `pdet` in float64 (loss_seed_f64)
+    double2* seed64;         // nullable [B][NX][NY]: float64 adjoint sweep (bdof_configure flag 64) — detector wave, residual and
+    double meas_ref;         // seed all formed in float64 and left here un-rounded; meas_ref: what the host subtracted (meas_dev)
 };
 
 __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
@@ -75,6 +78,22 @@ __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
         const size_t r = idx / a.NY;
         const int x = r % a.NX, b = r / a.NX;
         cf d = a.field[idx];
+        if (a.seed64 && a.meas) {
+            const bool dc = x == 0 && y == 0;
+            double2 p = make_double2(0.0, 0.0);
+            if (a.pdet64) p = a.pdet64[(size_t)x * a.NY + y];
+            else if (a.pdet) { const cf q = a.pdet[(size_t)x * a.NY + y]; p = make_double2((double)q.x, (double)q.y); }
+            else if (!a.far || dc) p = a.carrier_dd;
+            const size_t oi = a.far ? ((size_t)b * a.NY + y) * a.NX + x : idx;
+            const double dx = p.x + (double)d.x, dy = p.y + (double)d.y;
+            const double ab = sqrt(dx * dx + dy * dy), rr = ab - ((double)a.meas[oi] + a.meas_ref);
+            acc += rr * rr;
+            acc2 += rr * ab;
+            const double f = ab > 0.0 ? (double)a.seed_scale * rr / ab : 0.0;
+            a.seed64[idx] = make_double2(dx * f, dy * f);
+            if (a.out_wave) a.out_wave[oi] = make_float2((float)dx, (float)dy);
+            continue;
+        }
         if (a.meas_dev && a.meas && !a.far && !a.pdet) {
             const size_t oidx = idx;
             if (a.out_wave) a.out_wave[oidx] = cadd(d, a.carrier);
@@ -83,6 +102,13 @@ __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
             continue;
         }
         const cf e0 = d;
+        if (a.pdet64 && a.meas) {
+            const size_t oi = a.far ? ((size_t)b * a.NY + y) * a.NX + x : idx;
+            cf dw;
+            a.field[idx] = loss_seed_f64(d, a.pdet64[(size_t)x * a.NY + y], a.meas[oi], a.seed_scale, acc, acc2, dw);
+            if (a.out_wave) a.out_wave[oi] = dw;
+            continue;
+        }
         if (a.pdet) d = cadd(d, a.pdet[(size_t)x * a.NY + y]);
         else if (!a.far || (x == 0 && y == 0)) d = cadd(d, a.carrier);
         const size_t oidx = a.far ? ((size_t)b * a.NY + y) * a.NX + x : idx;
@@ -153,12 +179,66 @@ __global__ __launch_bounds__(256) void k_g_bwd(GBwdArgs a) {
 }
 
 
+// ---- float64 adjoint sweep (bdof_configure flag 64) -------------------------------------------------------------------------
+// The adjoint field G is as large as the wave itself and has no known part to split off (it is driven by the data's noise), so
+// its float32 transform chain sets a floor of ~3e-6 under the gradient (64 slices) — and Adam's first step of every epoch,
+// lr g / (|g| + 1e-8), turns an absolute error of 1e-8 at a voxel where the gradient changes sign into a fraction of a whole
+// step.  With this option the seed, the adjoint transforms (rocFFT double precision), the transfer function and
+// the products conj(phi) G are float64; the forward sweep (scattered wave on its carrier) and the tape stay float32.
+struct GBwd64Args {
+    double2* g;          // G(phi_z) in, G(psi_z) out
+    const cf* tape;      // phi_z (scattered part, or the full phi with a carrier field)
+    float2* grot;
+    ObjView obj;
+    int B, NX, NY, z;
+    double k;
+    double2 carrier;     // constant part of phi_z
+    int full_tape;
+};
+__global__ __launch_bounds__(256) void k_g_bwd64(GBwd64Args a) {
+    const size_t n = (size_t)a.B * a.NX * a.NY;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = idx % a.NY;
+        const size_t r = idx / a.NY;
+        const int x = r % a.NX, b = r / a.NX;
+        const double2 G = a.g[idx];
+        const cf e = a.tape[idx];
+        const double px = (double)e.x + (a.full_tape ? 0.0 : a.carrier.x), py = (double)e.y + (a.full_tape ? 0.0 : a.carrier.y);
+        const double tx = G.x * px + G.y * py, ty = G.y * px - G.x * py;             // G conj(phi)
+        a.grot[(((size_t)b * a.obj.S + a.z) * a.NX + x) * a.NY + y] = make_float2((float)(a.k * ty), (float)(-a.k * tx));
+        const float2 m1 = g_mod_value(a.obj, b, x, y, a.z, a.NX);
+        const double cx = 1.0 + (double)m1.x, cy = (double)m1.y;
+        a.g[idx] = make_double2(G.x * cx + G.y * cy, G.y * cx - G.x * cy);           // G conj(c)
+    }
+}
+// field[b][kx][ky] *= h[ky][kx] (or its conjugate), float64
+__global__ __launch_bounds__(256) void k_g_hmul64(double2* field, const double2* h, int B, int NX, int NY, int conj_h) {
+    const size_t n = (size_t)B * NX * NY;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ky = idx % NY;
+        const int kx = (idx / NY) % NX;
+        double2 t = h[(size_t)ky * NX + kx];
+        if (conj_h) t.y = -t.y;
+        const double2 v = field[idx];
+        field[idx] = make_double2(v.x * t.x - v.y * t.y, v.x * t.y + v.y * t.x);
+    }
+}
+__global__ __launch_bounds__(256) void k_d_scale(double2* f, size_t n, double s) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        f[i] = make_double2(f[i].x * s, f[i].y * s);
+}
+
 // ---- float64 helpers of bdof_set_probe_field: the carrier field of a localised probe, propagated on the device ------------
 __global__ __launch_bounds__(256) void k_d_mul(double2* __restrict__ f, const double2* __restrict__ h, size_t n, double scale) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const double2 a = f[i], b = h[i];
         f[i] = make_double2((a.x * b.x - a.y * b.y) * scale, (a.x * b.y + a.y * b.x) * scale);
     }
+}
+__global__ __launch_bounds__(256) void k_d_copy(const double2* __restrict__ src, double2* __restrict__ dst, int n0, int n1, int transposed) {
+    const size_t n = (size_t)n0 * n1;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x)
+        dst[transposed ? (idx % n1) * (size_t)n0 + idx / n1 : idx] = src[idx];
 }
 // dst[i] = (float2) src[i]; transposed: dst[j * n0 + i] = src[i * n1 + j] for an [n0][n1] source
 __global__ __launch_bounds__(256) void k_d_to_f(const double2* __restrict__ src, cf* __restrict__ dst, int n0, int n1, int transposed) {

@@ -227,10 +227,11 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * (BDOF_EX_ALL ? 2 : 1)];
+    constexpr bool EX = BDOF_EX_FWD_A;
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * (EX ? 2 : 1)];
     FftTw<NY> tw;
-    __shared__ cf smem_tail[7 * C::T * (BDOF_EX_ALL ? 2 : 1)];
-    tw.load(a.twiddle, tid, smem_tw, smem_tail);
+    __shared__ cf smem_tail[7 * C::T * (EX ? 2 : 1)];
+    tw.template load<EX>(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -252,20 +253,20 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
 #pragma unroll
                 for (int m = 0; m < 8; ++m) pc[m] = a.pz[(size_t)x * NY + tid + m * C::T];
                 if constexpr (INV) {
-                    if (!a.real_in) line_fft<NY, +1>(u, tw, tid, lds);
+                    if (!a.real_in) line_fft<NY, +1, 1, EX>(u, tw, tid, lds);
 #pragma unroll
                     for (int m = 0; m < 8; ++m) u[m] = unmodulate_eps(cscale(u[m], a.in_scale), pc[m], db[m], make_float2(0.f, 0.f));
                 } else {
-                    if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
+                    if constexpr (!FIRST) line_fft<NY, +1, 1, EX>(u, tw, tid, lds);
 #pragma unroll
                     for (int m = 0; m < 8; ++m) u[m] = modulate_eps(u[m], pc[m], db[m]);
                 }
             } else if constexpr (INV) {
-                if (!a.real_in) line_fft<NY, +1>(u, tw, tid, lds);
+                if (!a.real_in) line_fft<NY, +1, 1, EX>(u, tw, tid, lds);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) u[m] = unmodulate_eps(cscale(u[m], a.in_scale), a.carrier, db[m], a.cshift);
             } else {
-                if constexpr (!FIRST) line_fft<NY, +1>(u, tw, tid, lds);
+                if constexpr (!FIRST) line_fft<NY, +1, 1, EX>(u, tw, tid, lds);
 #pragma unroll
                 for (int m = 0; m < 8; ++m) u[m] = modulate_eps_s(u[m], a.carrier, db[m], a.cshift);
             }
@@ -275,9 +276,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
                 for (int m = 0; m < 8; ++m) pdst[tid + m * C::T] = u[m];
             }
             if constexpr (TSTORE) {
-                line_fft_partial<NY, -1>(u, tw, tid, lds);
+                line_fft_partial<NY, -1, 1, EX>(u, tw, tid, lds);
             } else {
-                line_fft<NY, -1>(u, tw, tid, lds);
+                line_fft<NY, -1, 1, EX>(u, tw, tid, lds);
                 cf* dst = a.out + (size_t)(row0 + r) * NY;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) dst[tid + m * C::T] = u[m];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
         }
         if constexpr (TSTORE) {
             __syncthreads();
-            transposed_tail<NY, -1>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
+            transposed_tail<NY, -1, 1, EX>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
             __syncthreads();
         }
     }
@@ -396,6 +397,7 @@ struct LossArgs {
     double2 carrier_dd;  // a_end * NX * NY in float64 (= `carrier`)
     double2 a_end;       // a_end: constant part of phi_{S-1}
     float dref;          // meas_dev: |carrier| - reference subtracted by the host (loss_seed_dev)
+    const double2* pfield64;   // nullable: `pfield` in float64 — the residual is then formed in float64 (loss_seed_f64)
 };
 
 // Adjoint carrier.  With a plane-wave probe and a far-field detector nearly all of the detector wave sits in ONE bin (DC,
@@ -446,6 +448,20 @@ __device__ __forceinline__ cf loss_seed_dev(cf e, cf a, float abs_a, float mdev,
     return make_float2(d.x * f, d.y * f);
 }
 
+// Carrier FIELD at the detector (localised probe): the wave is d = p + e with p the probe's own propagation, known in float64
+// (bdof_set_probe_field), and e the scattered part that came through the float32 transforms.  Rounding p to float32 first
+// costs 6e-8 |d| — 3e-6 of a 2 % residual, the largest single term of the gradient's error in far-field ptychography
+// (tools/precision_model.py) — so |d| - m is formed here in float64 and only the finished seed is rounded.
+__device__ __forceinline__ cf loss_seed_f64(cf e, double2 p, float m, float seed_scale, double& acc, double& acc2, cf& d_out) {
+    const double dx = p.x + (double)e.x, dy = p.y + (double)e.y;
+    const double ab = sqrt(dx * dx + dy * dy), r = ab - (double)m;
+    acc += r * r;
+    acc2 += r * ab;
+    const double f = ab > 0.0 ? (double)seed_scale * r / ab : 0.0;
+    d_out = make_float2((float)dx, (float)dy);
+    return make_float2((float)(dx * f), (float)(dy * f));
+}
+
 // FAR = false: inverse FFT first (rows of L1); FAR = true: forward FFT first (rows of L2).
 template <int N, bool FAR, bool TSTORE>
 __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss(LossArgs a) {
@@ -453,10 +469,11 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
     constexpr int S1 = FAR ? -1 : +1;     // direction of the first transform; the second is the opposite
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<N>::LDS_CNT * (BDOF_EX_ALL ? 2 : 1)];
+    constexpr bool EX = BDOF_EX_DET;
+    __shared__ cf smem_tw[FftTw<N>::LDS_CNT * (EX ? 2 : 1)];
     FftTw<N> tw;
-    __shared__ cf smem_tail[7 * C::T * (BDOF_EX_ALL ? 2 : 1)];
-    tw.load(a.twiddle, tid, smem_tw, smem_tail);
+    __shared__ cf smem_tail[7 * C::T * (EX ? 2 : 1)];
+    tw.template load<EX>(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.R / C::TILE;
     double acc = 0.0, acc2 = 0.0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -475,12 +492,20 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
 #pragma unroll
                 for (int m = 0; m < 8; ++m) mm[m] = a.meas[off + tid + m * C::T];
             }
-            line_fft<N, S1>(u, tw, tid, lds);
+            line_fft<N, S1, 1, EX>(u, tw, tid, lds);
 #pragma unroll
             for (int m = 0; m < 8; ++m) u[m] = cscale(u[m], a.in_scale);
             const bool dev = !FAR && a.meas_dev && a.meas && !a.pfield;
             cf e0 = make_float2(0.f, 0.f);        // FAR: scattered part of the DC bin
-            if (dev) {
+            if (a.pfield64 && a.meas) {
+                const double2* pf = a.pfield64 + (size_t)(r0 + r) * N;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    cf dw;
+                    u[m] = loss_seed_f64(u[m], pf[tid + m * C::T], mm[m], a.seed_scale, acc, acc2, dw);
+                    if (a.out_wave) a.out_wave[off + tid + m * C::T] = dw;
+                }
+            } else if (dev) {
                 // u is still the scattered part: the seed comes from (e, a) directly, the detector wave is a + e
                 const float abs_a = sqrtf(a.carrier.x * a.carrier.x + a.carrier.y * a.carrier.y);
                 if (a.out_wave) {
@@ -526,9 +551,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
             }
             if (a.out_hyb) {
                 if constexpr (TSTORE) {
-                    line_fft_partial<N, -S1>(u, tw, tid, lds);
+                    line_fft_partial<N, -S1, 1, EX>(u, tw, tid, lds);
                 } else {
-                    line_fft<N, -S1>(u, tw, tid, lds);
+                    line_fft<N, -S1, 1, EX>(u, tw, tid, lds);
 #pragma unroll
                     for (int m = 0; m < 8; ++m) a.out_hyb[off + tid + m * C::T] = cscale(u[m], a.out_scale);
                 }
@@ -537,7 +562,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
         if constexpr (TSTORE) {
             if (a.out_hyb) {
                 __syncthreads();
-                transposed_tail<N, -S1>(smem, a.out_hyb + (size_t)b * N * a.R + r0, a.R, a.out_scale, smem_tail);
+                transposed_tail<N, -S1, 1, EX>(smem, a.out_hyb + (size_t)b * N * a.R + r0, a.R, a.out_scale, smem_tail);
                 __syncthreads();
             }
         }
@@ -594,10 +619,12 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     // the transforms of the ADJOINT field run with exact constants (EX, bdof_fft.h); re-deriving phi from the tape does not
     constexpr bool EX = BDOF_EX_ADJ;
-    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * (EX ? 2 : 1)];
+    constexpr bool EXP = BDOF_EX_FWD_A;       // A_z's own inverse transform, repeated here bit for bit (HIST 1)
+    constexpr bool LO = EX || EXP;
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * (LO ? 2 : 1)];
     FftTw<NY> tw;
-    __shared__ cf smem_tail[7 * C::T * (EX ? 2 : 1)];
-    tw.template load<EX>(a.twiddle, tid, smem_tw, smem_tail);
+    __shared__ cf smem_tail[7 * C::T * (LO ? 2 : 1)];
+    tw.template load<LO>(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -624,7 +651,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
 #pragma unroll
                 for (int m = 0; m < 8; ++m) pc[m] = a.pz[(size_t)x * NY + tid + m * C::T];
             }
-            if constexpr (HIST == 1 || HIST == 3) line_fft<NY, +1>(p, tw, tid, lds);   // psi_hat_z -> psi_z (scattered part)
+            if constexpr (HIST == 1 || HIST == 3) line_fft<NY, +1, 1, EXP>(p, tw, tid, lds);   // psi_hat_z -> psi_z (scattered part)
             if constexpr (HIST == 3) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) p[m] = cscale(p[m], a.tape_scale);
@@ -1071,6 +1098,17 @@ __global__ __launch_bounds__(256) void k_gather_fields(float4* __restrict__ dst,
         const float4* s = src + (size_t)idx[b] * n16;
         float4* d = dst + (size_t)b * n16;
         for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
+    }
+}
+
+// the same in 4-byte words, for fields whose size is not a multiple of 16 bytes (a 75 x 75 projection after ::ds_level
+// downsampling, a 35 x 35 probe on the generic engine): such fields do not start on 16-byte boundaries either
+__global__ __launch_bounds__(256) void k_gather_fields4(float* __restrict__ dst, const float* __restrict__ src,
+                                                         const int* __restrict__ idx, int B, size_t n4) {
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        const float* s = src + (size_t)idx[b] * n4;
+        float* d = dst + (size_t)b * n4;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) d[i] = s[i];
     }
 }
 
@@ -1748,10 +1786,11 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_rea
     typedef RowCfg<NY> C;
     __shared__ cf smem[C::LDS_CF];
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
-    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * (BDOF_EX_ALL ? 2 : 1)];
+    constexpr bool EX = BDOF_EX_DET;
+    __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * (EX ? 2 : 1)];
     FftTw<NY> tw;
-    __shared__ cf smem_tail[7 * C::T * (BDOF_EX_ALL ? 2 : 1)];
-    tw.load(a.twiddle, tid, smem_tw, smem_tail);
+    __shared__ cf smem_tail[7 * C::T * (EX ? 2 : 1)];
+    tw.template load<EX>(a.twiddle, tid, smem_tw, smem_tail);
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -1764,10 +1803,10 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_rea
             const cf* src = a.in + (size_t)(row0 + r) * NY;
 #pragma unroll
             for (int m = 0; m < 8; ++m) u[m] = src[tid + m * C::T];
-            line_fft_partial<NY, -1>(u, tw, tid, lds);
+            line_fft_partial<NY, -1, 1, EX>(u, tw, tid, lds);
         }
         __syncthreads();
-        transposed_tail<NY, -1>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
+        transposed_tail<NY, -1, 1, EX>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
         __syncthreads();
     }
 }

@@ -12,6 +12,16 @@
 #pragma once
 #include "bdof_generic.h"
 
+// Exact twiddles (hi + lo pairs) in the ADJOINT passes of this kernel, what the streaming kernels run by default: measured in
+// round 3 on far-field ptychography (golden vector G17's configuration, 64^2 x 64 slices): gradient error 1.86e-6 -> 1.70e-6 for
+// +2.3 % (72^2) / +3.3 % (64^2) kernel time — the float32 rounding of the transforms themselves is the floor here, not the
+// tables (tools/precision_model.py).  Off by default; -DBDOF_RES_EXACT_ADJOINT switches it on.
+#ifdef BDOF_RES_EXACT_ADJOINT
+constexpr bool BDOF_EX_RES = BDOF_EX_ADJ;
+#else
+constexpr bool BDOF_EX_RES = false;
+#endif
+
 template <int N> struct ResPlan;      // radices of the Stockham passes of one line, and the workgroup size
 template <> struct ResPlan<32> { static constexpr int n = 2, R0 = 8, R1 = 4, R2 = 1, T = 64, WPE = 2; static constexpr bool FUSE = true; };
 template <> struct ResPlan<36> { static constexpr int n = 2, R0 = 4, R1 = 9, R2 = 1, T = 128, WPE = 2; static constexpr bool FUSE = true; };
@@ -139,7 +149,9 @@ struct EpiNone {
     __device__ __forceinline__ cf post(int, int, int, int, cf v) { return v; }
 };
 
-template <int N, int R, int NS, int SIGN, bool ALONG_Y, int T, class Epi>
+// EX: exact transform constants — the twiddle table's lo parts (tw[N + j], bdof_fft.h) are multiplied in as well; the passes of
+// the ADJOINT sweep run with it (the gradient's error is made there, the forward sweep rides on its carrier).
+template <int N, int R, int NS, int SIGN, bool ALONG_Y, int T, bool EX = false, class Epi>
 __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid, Epi& epi) {
     // every index below is invariant across slices: without this the compiler hoists the address math of all 16 passes
     // out of the slice loop and keeps it in registers (250+ VGPRs, spills).  Recomputing it per pass is a few VALU ops.
@@ -166,9 +178,8 @@ __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid, Epi& epi)
                 const int k = j % NS;
 #pragma unroll
                 for (int m = 1; m < R; ++m) {
-                    cf w = tw[k * m * (N / (NS * R))];
-                    if constexpr (SIGN > 0) w.y = -w.y;
-                    u[c][m] = cmul(u[c][m], w);
+                    const int ti = k * m * (N / (NS * R));
+                    u[c][m] = tw_mul<SIGN, EX>(u[c][m], tw[ti], tw[(EX ? N : 0) + ti]);
                 }
             }
             res_dft<R, SIGN, 0>(u[c]);
@@ -192,7 +203,7 @@ __device__ __forceinline__ void res_pass(cf* f, const cf* tw, int tid, Epi& epi)
 // Wave-local Stockham pass: lane (li, j) of wave w holds butterfly j of line w * LPW + li.  In place without a barrier: every
 // lane of the wave has issued its reads before any lane's write (one instruction stream), and only this wave touches
 // these lines while the line direction does not change.
-template <int N, int R, int NS, int SIGN, bool ALONG_Y, int L, int LPW, class Epi>
+template <int N, int R, int NS, int SIGN, bool ALONG_Y, int L, int LPW, bool EX = false, class Epi>
 __device__ __forceinline__ void res_wpass(cf* f, const cf* tw, int tid, Epi& epi) {
     asm volatile("" : "+v"(tid));
     constexpr int P = N | 1, ES = ALONG_Y ? 1 : P, NBL = N / R;
@@ -214,9 +225,8 @@ __device__ __forceinline__ void res_wpass(cf* f, const cf* tw, int tid, Epi& epi
         if constexpr (NS > 1) {
 #pragma unroll
             for (int m = 1; m < R; ++m) {
-                cf w = tw[k * m * (N / (NS * R))];
-                if constexpr (SIGN > 0) w.y = -w.y;
-                u[m] = cmul(u[m], w);
+                const int ti = k * m * (N / (NS * R));
+                u[m] = tw_mul<SIGN, EX>(u[m], tw[ti], tw[(EX ? N : 0) + ti]);
             }
         }
         res_dft<R, SIGN, 0>(u);
@@ -234,14 +244,14 @@ __device__ __forceinline__ void res_wpass(cf* f, const cf* tw, int tid, Epi& epi
 }
 
 // both passes of every line of one direction (two-pass plans only); no workgroup barrier inside
-template <int N, int SIGN, bool ALONG_Y, class Epi> __device__ __forceinline__ void res_wlines(cf* f, const cf* tw, int tid, Epi& epi) {
+template <int N, int SIGN, bool ALONG_Y, bool EX = false, class Epi> __device__ __forceinline__ void res_wlines(cf* f, const cf* tw, int tid, Epi& epi) {
     typedef ResPlan<N> Pl;
     static_assert(Pl::n == 2, "wave-local lines are written for two-pass plans");
     constexpr int L = ResWave<N>::L, LPW = ResWave<N>::LPW;
     static_assert(L >= N / Pl::R0 && L >= N / Pl::R1 && L * LPW <= 64, "lanes per line");
     EpiNone none;
-    res_wpass<N, Pl::R0, 1, SIGN, ALONG_Y, L, LPW>(f, tw, tid, none);
-    res_wpass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, L, LPW>(f, tw, tid, epi);
+    res_wpass<N, Pl::R0, 1, SIGN, ALONG_Y, L, LPW, EX>(f, tw, tid, none);
+    res_wpass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, L, LPW, EX>(f, tw, tid, epi);
 }
 
 // radix and butterflies per thread of the LAST pass of a line (the one that carries an epilogue)
@@ -251,36 +261,36 @@ template <int N, int T> struct ResLast {
     static constexpr int CNT = (N * (N / R) + T - 1) / T;
 };
 
-template <int N, int T, int SIGN, bool ALONG_Y, class Epi>
+template <int N, int T, int SIGN, bool ALONG_Y, bool EX = false, class Epi>
 __device__ __forceinline__ void res_lines(cf* f, const cf* tw, int tid, Epi& epi) {
     typedef ResPlan<N> Pl;
     EpiNone none;
-    res_pass<N, Pl::R0, 1, SIGN, ALONG_Y, T>(f, tw, tid, none);
+    res_pass<N, Pl::R0, 1, SIGN, ALONG_Y, T, EX>(f, tw, tid, none);
     if constexpr (Pl::n > 2) {
-        res_pass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, T>(f, tw, tid, none);
-        res_pass<N, Pl::R2, Pl::R0 * Pl::R1, SIGN, ALONG_Y, T>(f, tw, tid, epi);
+        res_pass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, T, EX>(f, tw, tid, none);
+        res_pass<N, Pl::R2, Pl::R0 * Pl::R1, SIGN, ALONG_Y, T, EX>(f, tw, tid, epi);
     } else {
-        res_pass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, T>(f, tw, tid, epi);
+        res_pass<N, Pl::R1, Pl::R0, SIGN, ALONG_Y, T, EX>(f, tw, tid, epi);
     }
 }
 
 // un-normalised 2-D DFT of the field image f[x * P + y], SIGN = -1 forward, +1 inverse; `epi` rides on the last pass
-template <int N, int T, int SIGN, class Epi> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid, Epi& epi) {
+template <int N, int T, int SIGN, bool EX = false, class Epi> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid, Epi& epi) {
     EpiNone none;
     if constexpr (ResWave<N>::L > 0) {
         static_assert(T >= 64 * ((N + ResWave<N>::LPW - 1) / ResWave<N>::LPW), "not enough waves for the lines");
-        res_wlines<N, SIGN, true>(f, tw, tid, none);
+        res_wlines<N, SIGN, true, EX>(f, tw, tid, none);
         res_sync();
-        res_wlines<N, SIGN, false>(f, tw, tid, epi);
+        res_wlines<N, SIGN, false, EX>(f, tw, tid, epi);
         res_sync();
     } else {
-        res_lines<N, T, SIGN, true>(f, tw, tid, none);
-        res_lines<N, T, SIGN, false>(f, tw, tid, epi);
+        res_lines<N, T, SIGN, true, EX>(f, tw, tid, none);
+        res_lines<N, T, SIGN, false, EX>(f, tw, tid, epi);
     }
 }
-template <int N, int T, int SIGN> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid) {
+template <int N, int T, int SIGN, bool EX = false> __device__ __forceinline__ void res_fft2(cf* f, const cf* tw, int tid) {
     EpiNone none;
-    res_fft2<N, T, SIGN>(f, tw, tid, none);
+    res_fft2<N, T, SIGN, EX>(f, tw, tid, none);
 }
 
 struct ResArgs {
@@ -301,13 +311,14 @@ struct ResArgs {
     const cf* pdet;
     const float* meas;     // nullable; real detectors [b][x][y], far field [b][ky][kx]
     cf* out_wave;          // nullable; same order as meas
-    double* partial;       // [2 * gridDim.x]
+    double* partial;       // [2 * gridDim.x * T / 64]: per workgroup and wave, (sum r^2, sum r |d|)
     const cf* twiddle;     // [N] exp(-2 pi i k / N)
     int B, S, det_mode, tf_all, do_grad;
     float k, seed_scale;
     int meas_dev;          // `meas` holds m - |carrier_det| (loss_seed_dev, bdof_kernels.h)
     float dref;
     cf* gpsi0;             // nullable [B][N][N]: G(psi_0), the probe gradient per wavefield
+    const double2* pdet64; // nullable: `pdet` in float64 — the residual |d| - m is then formed in float64 (loss_seed_f64)
 };
 
 // transfer-function multiply folded into the last pass of the forward transform: the thread writing element (kx, ky)
@@ -353,30 +364,31 @@ template <int N, int T, bool CONJ, class Epi, class Mid>
 __device__ __forceinline__ void res_prop(cf* f, const cf* hT, const cf* tw, int tid, Epi& epi, Mid&& mid) {
     EpiH<N, T, CONJ> eh;
     eh.hT = hT;
+    constexpr bool EX = CONJ && BDOF_EX_RES;        // the adjoint step's transforms are exact (bdof_fft.h)
     if constexpr (ResWave<N>::L > 0) {
         // wave-local lines: the inverse transform runs x first, so that a column goes forward, x h, and back in one wave
         static_assert(!Epi::active, "the wave-local form carries no point-wise epilogue");
         EpiNone none;
-        res_wlines<N, -1, true>(f, tw, tid, none);
+        res_wlines<N, -1, true, EX>(f, tw, tid, none);
         res_sync();
-        res_wlines<N, -1, false>(f, tw, tid, eh);
-        res_wlines<N, +1, false>(f, tw, tid, none);
+        res_wlines<N, -1, false, EX>(f, tw, tid, eh);
+        res_wlines<N, +1, false, EX>(f, tw, tid, none);
         res_sync();
         {   // the last line set, its two passes written out so that `mid` sits before the lighter (radix R1) one
             typedef ResPlan<N> Pl;
             constexpr int L = ResWave<N>::L, LPW = ResWave<N>::LPW;
-            res_wpass<N, Pl::R0, 1, +1, true, L, LPW>(f, tw, tid, none);
+            res_wpass<N, Pl::R0, 1, +1, true, L, LPW, EX>(f, tw, tid, none);
             mid();
-            res_wpass<N, Pl::R1, Pl::R0, +1, true, L, LPW>(f, tw, tid, none);
+            res_wpass<N, Pl::R1, Pl::R0, +1, true, L, LPW, EX>(f, tw, tid, none);
         }
         res_sync();
     } else {
-        res_fft2<N, T, -1>(f, tw, tid, eh);
+        res_fft2<N, T, -1, EX>(f, tw, tid, eh);
         res_epi_prefetch<N, T>(tid, epi);
         EpiNone none;
-        res_lines<N, T, +1, true>(f, tw, tid, none);
+        res_lines<N, T, +1, true, EX>(f, tw, tid, none);
         mid();
-        res_lines<N, T, +1, false>(f, tw, tid, epi);
+        res_lines<N, T, +1, false, EX>(f, tw, tid, epi);
     }
 }
 template <int N, int T, bool CONJ, class Epi>
@@ -534,10 +546,9 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
     extern __shared__ __align__(16) unsigned char res_smem[];
     cf* f = reinterpret_cast<cf*>(res_smem);
     cf* tw = f + N * P;
-    long long* rowbuf = reinterpret_cast<long long*>(tw + N);      // [3][N] object rows of slices z, z+1, z+2 (ring)
+    long long* rowbuf = reinterpret_cast<long long*>(tw + 2 * N);  // [3][N] object rows of slices z, z+1, z+2 (ring)
     const int tid = threadIdx.x;
-    for (int e = tid; e < N; e += T) tw[e] = a.twiddle[e];
-    double acc = 0.0, acc2 = 0.0;
+    for (int e = tid; e < 2 * N; e += T) tw[e] = a.twiddle[e];      // hi parts, then lo parts (upload_twiddle)
     const bool far = a.det_mode == BDOF_DET_FAR;
     const size_t fsz = (size_t)N * N;
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
@@ -596,6 +607,13 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
         else if (far) res_fft2<N, T, -1>(f, tw, tid);
 
         // ---- detector wave, loss, seed --------------------------------------------------------
+        // The sums of this wavefield are reduced per wave right here and added to the wave's slot of `partial` in global memory
+        // (same lane every time: a plain read-modify-write, fixed order).  They used to be carried in registers to the end of
+        // the kernel — values that live across both sweeps get spilled, and hipcc 7.2 placed the spill of the zero-initialised
+        // accumulators in the flow block of an `if (tid < N)` region, BEFORE exec was restored: waves with no lane in that
+        // region never stored them and reloaded whatever an earlier kernel had left in that scratch slot (loss off by 5 % at
+        // N = 128, depending on what ran before).  tools/check_spills.py scans the ISA of every kernel for that pattern.
+        double acc = 0.0, acc2 = 0.0;
         for (int e = tid; e < N * N; e += T) {
             const int x = res_div<N>(e), y = e - x * N;
             cf d = f[x * P + y];
@@ -606,11 +624,28 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                                              a.meas[o], a.seed_scale, acc, acc2, a.dref);
                 continue;
             }
+            if (a.pdet64 && a.meas) {
+                const size_t o = b * fsz + (far ? y * N + x : e);
+                cf dw;
+                f[x * P + y] = loss_seed_f64(d, a.pdet64[e], a.meas[o], a.seed_scale, acc, acc2, dw);
+                if (a.out_wave) a.out_wave[o] = dw;
+                continue;
+            }
             if (a.pdet) d = cadd(d, a.pdet[e]);
             else if (!far || e == 0) d = cadd(d, a.carrier_det);
             const size_t o = b * fsz + (far ? y * N + x : e);
             if (a.out_wave) a.out_wave[o] = d;
             if (a.meas) f[x * P + y] = loss_seed(d, a.meas[o], a.seed_scale, acc, acc2);
+        }
+        if (a.meas) {
+            acc = wave_reduce_sum(acc);
+            acc2 = wave_reduce_sum(acc2);
+            if ((tid & 63) == 0) {
+                double* pw = a.partial + 2 * ((size_t)blockIdx.x * (T / 64) + (tid >> 6));
+                const bool first = b == (int)blockIdx.x;
+                pw[0] = (first ? 0.0 : pw[0]) + acc;
+                pw[1] = (first ? 0.0 : pw[1]) + acc2;
+            }
         }
         if (!a.do_grad || !a.meas) continue;
 
@@ -631,7 +666,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
             Pipe::load_field(tape0 + (size_t)(a.S - 1) * a.tape_stride, tid, t);
         }
         if (a.det_mode == BDOF_DET_NEAR) res_prop<N, T, true>(f, a.hdetT, tw, tid);
-        else if (far) res_fft2<N, T, +1>(f, tw, tid);                  // F^H = un-normalised inverse
+        else if (far) res_fft2<N, T, +1, BDOF_EX_RES>(f, tw, tid);     // F^H = un-normalised inverse
         for (int z = a.S - 1; z >= 0; --z) {
             const long long r2 = Pipe::row_of(a, b, z - 2, tid);
             const bool prop_after = z < a.S - 1 || (a.tf_all && !far);
@@ -678,18 +713,5 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
             }
         }
     }
-    if (a.meas) {
-        __shared__ double w1[16], w2[16];
-        acc = wave_reduce_sum(acc);
-        acc2 = wave_reduce_sum(acc2);
-        __syncthreads();
-        if ((tid & 63) == 0) { w1[tid >> 6] = acc; w2[tid >> 6] = acc2; }
-        __syncthreads();
-        if (tid == 0) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int i = 0; i < T / 64; ++i) { s1 += w1[i]; s2 += w2[i]; }
-            a.partial[2 * blockIdx.x] = s1;
-            a.partial[2 * blockIdx.x + 1] = s2;
-        }
-    }
 }
+

@@ -25,17 +25,22 @@ class MultisliceEngine(object):
     """One wavefield geometry (NY x NX x S) on one GPU."""
 
     def __init__(self, ny, nx, n_slice, batch_max, with_grad=True, device=0, stream=None, force_generic=False, engine='auto',
-                 recompute=None, no_grot=False):
+                 recompute=None, no_grot=False, adjoint64=None):
         """Engines (include/bdof.h, bdof_configure): powers of two in 64..1024 run on the fused streaming kernels; small
         square fields (32..128, e.g. the 72 x 72 ptychography probe) on the LDS-resident kernel when there is no fused plan
         or the batch is large; every other size on the generic engine (rocFFT).  engine='generic' (= force_generic=True),
-        'streaming' (never resident) or 'resident' (resident for every batch size) pin the choice for cross-checks."""
+        'streaming' (never resident) or 'resident' (resident for every batch size) pin the choice for cross-checks.
+        adjoint64=True (env BDOF_ADJOINT64=1): the adjoint sweep in float64 (bdof_configure flag 64; generic engine) — the
+        accuracy option for reconstructions that must follow the reference's float64 loop voxel by voxel."""
         if engine not in ('auto', 'generic', 'streaming', 'resident'):
             raise ValueError('engine must be auto, generic, streaming or resident')
         force_generic = force_generic or engine == 'generic'
         if recompute is None:
             recompute = bool(int(os.environ.get('BDOF_RECOMPUTE', '0')))
         self.recompute = bool(recompute)
+        if adjoint64 is None:
+            adjoint64 = bool(int(os.environ.get('BDOF_ADJOINT64', '0')))
+        self.adjoint64 = bool(adjoint64) and bool(with_grad)
         self.ctx = _lib.Context(device, stream)
         self.lib = self.ctx.lib
         self.h = self.ctx.handle
@@ -44,7 +49,7 @@ class MultisliceEngine(object):
         self.ctx.check(self.lib.bdof_configure(self.h, self.ny, self.nx, self.n_slice, self.batch_max,
                                                int(bool(with_grad)) | (2 if (force_generic or os.environ.get('BDOF_FORCE_GENERIC')) else 0)
                                                | (4 if engine == 'streaming' else 0) | (8 if engine == 'resident' else 0)
-                                               | (16 if self.recompute else 0) | (32 if no_grot else 0)))
+                                               | (16 if self.recompute else 0) | (32 if no_grot else 0) | (64 if self.adjoint64 else 0)))
         self._engine_arg = 'generic' if force_generic else engine
         self._device = device
         self.det_mode = _lib.DET_NONE
@@ -85,6 +90,12 @@ class MultisliceEngine(object):
         self.ctx.check(self.lib.bdof_set_physics(self.h, k, hs.ctypes.data, hdet.ctypes.data if hdet is not None else None,
                                                  h00.ctypes.data, hdet00.ctypes.data if hdet00 is not None else None,
                                                  det, _VARIANT[variant]))
+        if self.adjoint64:
+            hs64 = util.device_transfer_function(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, field_shape=field_shape, dtype=np.complex128)
+            hd64 = None
+            if det == _lib.DET_NEAR:
+                hd64 = util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, dtype=np.complex128)
+            self.ctx.check(self.lib.bdof_set_physics_f64(self.h, hs64.ctypes.data, hd64.ctypes.data if hd64 is not None else None))
         if getattr(self, '_probe_args', None) is not None:
             self.set_probe(*self._probe_args)      # the carrier (field, calibration) of the probe depends on the physics
 
@@ -184,11 +195,16 @@ class MultisliceEngine(object):
         self.probe_stack, self.probe_gain = False, 1.0
         self._set_meas_mode(0j)
 
+    residual_split = True      # False: amplitudes go to the device as they are (a probe that changes between steps)
+
     def _set_meas_mode(self, a0):
         """Residual splitting at the detector (include/bdof.h, bdof_set_meas_mode): with a plane-wave carrier and a real-space
-        detector the measured amplitudes go to the device as m - |a0|."""
+        detector the measured amplitudes go to the device as m - |a0|.  The amplitudes a caller keeps resident on the device
+        are laid out for the reference in force when they were uploaded (meas_layout), so a probe that is re-set between
+        steps (probe_type='optimizable') must not move it: the solvers switch the splitting off for that case
+        (residual_split = False) before they upload."""
         self.meas_ref = 0.0
-        if a0 != 0 and self.det_mode != _lib.DET_FAR and not os.environ.get('BDOF_NO_RESIDUAL_SPLIT'):
+        if a0 != 0 and self.det_mode != _lib.DET_FAR and self.residual_split and not os.environ.get('BDOF_NO_RESIDUAL_SPLIT'):
             self.meas_ref = abs(a0)
         self.ctx.check(self.lib.bdof_set_meas_mode(self.h, 1 if self.meas_ref else 0))
 

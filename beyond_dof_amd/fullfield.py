@@ -71,6 +71,11 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
     # 'fft' (default): transfer-function propagator of np_funcs.py; 'conv': truncated real-space kernel of propagation.py,
     # the reference's own choice in this entry point, with `kernel_size` taps per axis
     propagator = kwargs.get('propagator', 'fft')
+    # 'float64': the adjoint sweep in float64 (bdof_configure flag 64, transfer-function propagator only) — follows the
+    # reference's float64 loop voxel by voxel where float32's 3e-6 on the gradient is too coarse
+    adjoint_precision = kwargs.get('adjoint_precision', 'float32')
+    if adjoint_precision not in ('float32', 'float64'):
+        raise ValueError("adjoint_precision must be 'float32' or 'float64'")
     # gradient accumulation over n_batch_per_update minibatches exists only in the TF twin (tensorflow_recon/fullfield.py:
     # 413-425); the cnn variant accepts the keyword and ignores it (default 5!), so it is opt-in here
     accumulate = bool(kwargs.get('accumulate_gradients', False))
@@ -141,7 +146,12 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
             obj_delta[...] = 0
         obj_size = obj_delta.shape
 
-        if probe_type in ('plane', 'point'):
+        if probe_type == 'point':
+            # cnn_propagator/fullfield.py:298-301 fills in a plane wave for 'point' with the note "this should be in spherical
+            # coordinates": the spherical-wave propagator is out of scope here (simulation.py refuses it too), and silently
+            # reconstructing with the plane-wave one would be a different experiment
+            raise ValueError("probe_type='point' (spherical-wave propagator) is not supported; use 'plane', 'fixed' or 'optimizable'")
+        if probe_type == 'plane':
             probe_real, probe_imag = np.ones([dim_y, dim_x]), np.zeros([dim_y, dim_x])
         elif probe_type == 'optimizable':
             if probe_initial is not None:
@@ -165,7 +175,7 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
         solver = FullfieldSolver(dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm * ds_level,
                                  free_prop_cm=free_prop_cm, probe_real=probe_real, probe_imag=probe_imag, variant=variant,
                                  comm=comm, device=comm.local_rank, coord_ls=coord_ls, propagator=propagator, kernel_size=kernel_size,
-                                 rotation=rotation, theta=theta)
+                                 rotation=rotation, theta=theta, adjoint64=adjoint_precision == 'float64')
         solver.set_volume(obj_delta, obj_beta)
         solver.set_mask(mask)
         solver.set_measurements(np.abs(prj))

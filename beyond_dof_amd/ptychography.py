@@ -76,6 +76,10 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
     # 'fft' (default): transfer-function propagator of np_funcs.py; 'conv': truncated real-space kernel of propagation.py,
     # the reference's own choice in this entry point, with `kernel_size` taps per axis
     propagator = kwargs.get('propagator', 'fft')
+    # 'float64': the adjoint sweep in float64 (bdof_configure flag 64, transfer-function propagator only)
+    adjoint_precision = kwargs.get('adjoint_precision', 'float32')
+    if adjoint_precision not in ('float32', 'float64'):
+        raise ValueError("adjoint_precision must be 'float32' or 'float64'")
 
     print_flush('Reading data...', 0, rank)
     f = h5io.File(os.path.join(save_path, fname))
@@ -150,7 +154,8 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
 
         solver = PtychoSolver(this_obj_size, this_probe_size, this_probe_pos, n_theta, minibatch_size, energy_ev,
                               psize_cm * ds_level, probe_real, probe_imag, variant=variant, comm=comm, device=comm.local_rank,
-                              coord_ls=coord_ls, propagator=propagator, kernel_size=kwargs.get('kernel_size', 17))
+                              coord_ls=coord_ls, propagator=propagator, kernel_size=kwargs.get('kernel_size', 17),
+                              adjoint64=adjoint_precision == 'float64')
         solver.set_volume(obj_delta, obj_beta)
         solver.tune_tail()
         # the diffraction amplitudes stay on the device when they fit (ptychography.py:295 reads them from the file per step)

@@ -42,6 +42,8 @@ class _VolumeSolver(object):
         self._plan = None
         self.tuned = None
         self._acc = 0              # minibatches accumulated in self.g since the last update (n_batch_per_update)
+        self._epoch_plan = None    # shard layout of the Adam moments since the last reset_moments (None: none taken yet)
+        self._g_shards = None      # slabs whose gradient is reduced on this rank's 1/size only (after a sharded step)
         self.probe = None          # enable_probe_optimization
         self.comm.attach(self.ctx)
 
@@ -67,6 +69,7 @@ class _VolumeSolver(object):
         self.ctx.check(lib.bdof_memset(h, self.m.ptr, 0, self.m.nbytes))
         self.ctx.check(lib.bdof_memset(h, self.v.ptr, 0, self.v.nbytes))
         self._acc = 0
+        self._epoch_plan = None
 
     def bcast_volume(self, root=0):
         """Rank `root`'s volume to every rank (the init_*_temp.npy hand-over of ptychography.py:169-208)."""
@@ -80,6 +83,13 @@ class _VolumeSolver(object):
         return loss.value
 
     def gradient_to_host(self):
+        """The gradient of the last step / loss_and_grad as (g_delta, g_beta), each (Y, X, Z).  After a sharded step every rank
+        holds the reduced gradient of its own 1/size of each slab only: the parts are gathered first."""
+        if self._g_shards:
+            per_x = self.dim_z * self.dim_y * 2
+            for x0, nx in self._g_shards:
+                self.comm.wait(self.ctx, self.comm.start_allgather(self.ctx, self.g, x0 * per_x, (nx // self.comm.size) * per_x))
+            self._g_shards = None
         self.ctx.sync()
         return util.rows_to_volume(self.g.download())
 
@@ -132,8 +142,33 @@ class _VolumeSolver(object):
         self.cur = 1 - self.cur
         self._bind_volume()
 
+    def _whole_volume_guard(self):
+        """adam_update runs Adam on the whole volume with this rank's moments: wrong once a sharded step has left them valid
+        on 1/size of every slab only."""
+        if self._epoch_plan is not None and self._epoch_plan[1] is not None:
+            raise RuntimeError('adam_update() after a sharded step(): the Adam moments of this epoch are sharded over the ranks '
+                               '(call reset_moments() first, or keep using step())')
+        self._epoch_plan = ('taken', None)
+
+    time_tail = False          # True: every _tail is bracketed by stream-ordered time stamps (bdof_timer_mark slots 0 / 1)
+
+    def tail_ms(self):
+        """Duration of the last tail on the ctx stream (rotation adjoint + exchange + Adam + all-gather), with time_tail on."""
+        ms = ctypes.c_double(0)
+        self.ctx.check(self.ctx.lib.bdof_timer_elapsed(self.ctx.handle, 0, 1, ctypes.byref(ms)))
+        return ms.value
+
     def _tail(self, produce, i_update, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, clip=True, use_mask=True,
               n_slabs=None, sharded=None, flip=True, n_acc=1):
+        if not self.time_tail:
+            return self._tail_run(produce, i_update, learning_rate, alpha_d, alpha_b, gamma, clip, use_mask, n_slabs, sharded, flip, n_acc)
+        lib, h = self.ctx.lib, self.ctx.handle
+        self.ctx.check(lib.bdof_timer_mark(h, 0))
+        self._tail_run(produce, i_update, learning_rate, alpha_d, alpha_b, gamma, clip, use_mask, n_slabs, sharded, flip, n_acc)
+        self.ctx.check(lib.bdof_timer_mark(h, 1))
+
+    def _tail_run(self, produce, i_update, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, clip=True, use_mask=True,
+                  n_slabs=None, sharded=None, flip=True, n_acc=1):
         """produce(x0, nx): enqueue the kernels that leave this rank's gradient of x-planes [x0, x0+nx) in self.g.
         Then exchange + regulariser + Adam (+ mask, clip), slab by slab.  g_scale = 1 / (size * n_acc)
         (grads /= size, fullfield.py:351; accumulated minibatches are averaged, tensorflow_recon/fullfield.py:424)."""
@@ -147,7 +182,17 @@ class _VolumeSolver(object):
                 self._flip()
             return
         n_slabs, sharded = self.tail_plan(n_slabs, sharded)
+        # Sharded form: the Adam moments (and, after the reduce-scatter, the gradient) are valid on this rank's 1/size of every
+        # slab only, so the shard layout must not move while the moments live — i.e. until the next reset_moments().  The
+        # all-reduce form keeps them whole on every rank, whatever its slab count.
+        layout = (n_slabs, True) if sharded else None
+        if self._epoch_plan is None:
+            self._epoch_plan = ('taken', layout)
+        elif self._epoch_plan[1] != layout:
+            raise RuntimeError('the exchange plan changed from {} to {} inside an epoch: the Adam moments are sharded by the first one '
+                               '(call reset_moments() first)'.format(self._epoch_plan[1], layout))
         slabs = self.slab_bounds(n_slabs)
+        self._g_shards = list(slabs) if sharded else None
         per_x = self.dim_z * self.dim_y * 2                  # floats per x-plane of the gradient / volume
         size, rank = comm.size, comm.rank
         tickets, gathers = [None] * len(slabs), []
@@ -178,7 +223,7 @@ class _VolumeSolver(object):
         if flip:
             self._flip()
 
-    def tune_tail(self, candidates=(1, 8), reps=2):
+    def tune_tail(self, candidates=(1, 8, 16, 32), reps=2):
         """Pick the number of slabs of the pipelined tail by timing it on this machine and process layout (the collective,
         the streams it runs on and the kernels either side interact in ways that differ between runtimes).  Dry run with
         learning rate 0 on a zeroed rotated-frame gradient: the gradient buffer, the spare volume buffer and the Adam
@@ -196,6 +241,7 @@ class _VolumeSolver(object):
                 plans.append(p)
         times = []
         for p in plans:
+            self._epoch_plan = None                           # dry runs: the moments are scratch (zeroed again below)
             self._dry_tail(*p)                                # first use: communicator / stream set-up
             self.ctx.sync()
             self.comm.Barrier()
@@ -204,6 +250,7 @@ class _VolumeSolver(object):
                 self._dry_tail(*p)
             self.ctx.sync()
             times.append(time.perf_counter() - t0)
+        self._g_shards = None
         worst = self.comm.allreduce_max_host(np.array(times))
         self._plan = plans[int(np.argmin(worst))]
         self.tuned = {'{}slab{}'.format(p[0], '_sharded' if p[1] else ''): float(t) / reps for p, t in zip(plans, worst)}
@@ -231,7 +278,16 @@ class _VolumeSolver(object):
         self.probe_t = 0
         self._pacc = 0
         self.eng.enable_probe_grad(True)
+        # The resident amplitudes were laid out as m - |a0| for the probe in force at set_measurements (residual splitting,
+        # engine._set_meas_mode).  A probe that moves every step would leave that reference behind — every residual biased by
+        # |a0_new| - |a0_old|, or by |a0| itself once the carrier changes kind — so the splitting is switched off here and
+        # amplitudes that are already resident are put back to plain m.
+        old_ref = getattr(self.eng, 'meas_ref', 0.0)
+        self.eng.residual_split = False
         self.eng.set_probe(self.probe.real, self.probe.imag)
+        if old_ref and getattr(self, 'meas', None) is not None:
+            self.ctx.sync()
+            self.meas.upload((self.meas.download().astype(np.float64) + old_ref).astype(np.float32))
 
     def _probe_collect(self):
         """Add this minibatch's probe gradient to the device accumulator (call after every loss_grad)."""
@@ -271,7 +327,7 @@ class _VolumeSolver(object):
 class FullfieldSolver(_VolumeSolver):
     def __init__(self, dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm, free_prop_cm=None,
                  probe_real=None, probe_imag=None, variant='numpy_skip_last', comm=None, device=0, stream=None,
-                 coord_ls=None, propagator='fft', kernel_size=17, recompute=None, rotation='nearest', theta=None):
+                 coord_ls=None, propagator='fft', kernel_size=17, recompute=None, rotation='nearest', theta=None, adjoint64=None):
         """propagator='fft': the transfer-function step of np_funcs.py (north-star path); 'conv': the truncated real-space
         kernel of propagation.py, what cnn_propagator/fullfield.py:87,102 calls (kernel_size taps per axis).
         rotation='nearest': the cnn variant's lookup tables, fused into the kernels (cnn_propagator/util.py:294-402);
@@ -280,6 +336,8 @@ class FullfieldSolver(_VolumeSolver):
         (bdof_rotate_bilinear), its adjoint is a gather (bdof_rotate_bilinear_adjoint)."""
         self.conv = propagator == 'conv'
         self.bilinear = rotation == 'bilinear'
+        if adjoint64 and self.conv:
+            raise ValueError("adjoint64 (float64 adjoint sweep) runs with the transfer-function propagator only")
         if rotation not in ('nearest', 'bilinear'):
             raise ValueError("rotation must be 'nearest' or 'bilinear'")
         if self.bilinear and theta is None:
@@ -288,7 +346,7 @@ class FullfieldSolver(_VolumeSolver):
         self.n_theta, self.mb = int(n_theta), int(minibatch_size)
         self.comm = comm or PseudoComm()
         self.eng = MultisliceEngine(self.dim_y, self.dim_x, self.dim_z, self.mb, with_grad=True, device=device, stream=stream,
-                                    recompute=recompute)
+                                    recompute=recompute, adjoint64=adjoint64)
         self.ctx = self.eng.ctx
         self.eng.set_physics(energy_ev, psize_cm, free_prop_cm, variant=variant)
         if self.conv:
@@ -380,6 +438,7 @@ class FullfieldSolver(_VolumeSolver):
 
     def adam_update(self, i_batch, learning_rate, alpha_d=0.0, alpha_b=0.0, gamma=0.0, clip=True, use_mask=True):
         """Regulariser + Adam on the gradient in self.g (whole volume, no exchange)."""
+        self._whole_volume_guard()
         self._adam_slab(i_batch, learning_rate, alpha_d, alpha_b, gamma, clip, use_mask, None, 1.0 / self.comm.size)
         self._flip()
 
@@ -432,8 +491,11 @@ class PtychoSolver(_VolumeSolver):
     Adam moments, rotation tables, all diffraction amplitudes; windows are cut by index math inside the kernels."""
 
     def __init__(self, obj_size, probe_size, probe_pos, n_theta, minibatch_size, energy_ev, psize_cm, probe_real, probe_imag,
-                 variant='numpy_skip_last', comm=None, device=0, stream=None, coord_ls=None, propagator='fft', kernel_size=17):
+                 variant='numpy_skip_last', comm=None, device=0, stream=None, coord_ls=None, propagator='fft', kernel_size=17,
+                 adjoint64=None):
         self.conv = propagator == 'conv'
+        if adjoint64 and self.conv:
+            raise ValueError("adjoint64 (float64 adjoint sweep) runs with the transfer-function propagator only")
         self.dim_y, self.dim_x, self.dim_z = [int(s) for s in obj_size]
         self.py, self.px = int(probe_size[0]), int(probe_size[1])
         self.n_theta, self.mb = int(n_theta), int(minibatch_size)
@@ -445,7 +507,8 @@ class PtychoSolver(_VolumeSolver):
         from .engine import RESIDENT_SIZES
         pin = 'resident' if (self.py == self.px and self.py in RESIDENT_SIZES and not self.conv
                              and not os.environ.get('BDOF_NO_RESIDENT_PIN')) else 'auto'
-        self.eng = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream, engine=pin)
+        self.eng = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream, engine=pin,
+                                    adjoint64=adjoint64)
         self.ctx = self.eng.ctx
         self.eng.set_physics(energy_ev, psize_cm, 'inf', variant=variant)   # free_prop_cm='inf', ptychography.py:76
         if self.conv:
@@ -530,5 +593,6 @@ class PtychoSolver(_VolumeSolver):
                                 yoff=pos[:, 0] - self.half[0], conv=self.conv)
 
     def adam_update(self, i_batch, learning_rate, clip=True):
+        self._whole_volume_guard()
         self._adam_slab(i_batch, learning_rate, 0.0, 0.0, 0.0, clip, False, None, 1.0 / self.comm.size)
         self._flip()

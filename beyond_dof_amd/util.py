@@ -68,15 +68,16 @@ def get_kernel_tile(dist_nm, lmbda_nm, voxel_nm, tile_shape, field_shape, pi=PI)
     return np.exp(1j * k * dist_nm) * np.exp(-1j * pi * lmbda_nm * dist_nm * (uu ** 2 + vv ** 2))
 
 
-def device_transfer_function(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI, field_shape=None):
-    """H prepared for libbdof: un-shifted [ky][kx], 1/(NX*NY) folded in, complex64.  field_shape: the (ny, nx) wavefield is a
-    tile of a larger field whose propagator it applies (get_kernel_tile)."""
+def device_transfer_function(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI, field_shape=None, dtype=np.complex64):
+    """H prepared for libbdof: un-shifted [ky][kx], 1/(NX*NY) folded in, complex64 (complex128: the float64 adjoint sweep's
+    table, bdof_set_physics_f64).  field_shape: the (ny, nx) wavefield is a tile of a larger field whose propagator it applies
+    (get_kernel_tile)."""
     if field_shape is None:
         h = get_kernel(dist_nm, lmbda_nm, voxel_nm, (ny, nx), pi=pi)
     else:
         h = get_kernel_tile(dist_nm, lmbda_nm, voxel_nm, (ny, nx), field_shape, pi=pi)
     hs = np.fft.ifftshift(h) / float(nx * ny)
-    return np.ascontiguousarray(hs.astype(np.complex64))
+    return np.ascontiguousarray(hs.astype(dtype))
 
 
 def transfer_function_dc(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI, field_shape=None):

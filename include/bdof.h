@@ -38,6 +38,11 @@ const char* bdof_last_error(const bdof_ctx* ctx);
 int bdof_sync(bdof_ctx* ctx);
 void* bdof_stream(bdof_ctx* ctx);   /* the ctx's hipStream_t, for ordering foreign work (collectives) against it */
 int bdof_device_count(void);
+int bdof_device_pci_bus_id(int device, char* out, int len);      /* "0000:c1:00.0": which physical GPU a rank really got */
+/* Stream-ordered time stamps on the ctx stream (16 slots): mark now, read the interval after the work has run — how the
+ * bench reports the tail of a step (rotation adjoint, gradient exchange, Adam) without a host synchronisation inside it. */
+int bdof_timer_mark(bdof_ctx* ctx, int slot);
+int bdof_timer_elapsed(bdof_ctx* ctx, int slot_a, int slot_b, double* ms);
 
 /* Workspace for wavefields of NY x NX, S slices, up to Bmax wavefields per launch.  Three engines sit behind the same calls:
  *   - fused streaming kernels (hand-written FFTs, field in HBM): NY, NX powers of two in 64..1024;
@@ -48,7 +53,11 @@ int bdof_device_count(void);
  * with_grad bits: 0 allocate the tape (S fields per wavefield) and the rotated-frame gradient; 1 force the generic-size
  * engine (cross-checks); 2 never use the resident engine; 3 use it for every batch size; 4 (value 16) tape-free adjoint of the
  * streaming engine: 3 tape fields instead of S, the forward wave is marched back beside the adjoint field;
- * 5 (value 32) no rotated-frame gradient workspace (range sweeps with caller-owned buffers, bdof_adjoint_range).
+ * 5 (value 32) no rotated-frame gradient workspace (range sweeps with caller-owned buffers, bdof_adjoint_range);
+ * 6 (value 64) float64 adjoint sweep (accuracy option; runs on the generic-size engine whatever the size): seed, adjoint
+ * transforms (rocFFT double precision), transfer function and the products conj(phi) G in float64, forward sweep and tape in
+ * float32 — what autograd's float64 tape gives the reference (cnn_propagator/fullfield.py:329, ptychography.py:248);
+ * follow bdof_set_physics with bdof_set_physics_f64.
  * Replaces the per-call allocations of multislice_propagate_batch_numpy
  * (cnn_propagator/np_funcs.py:20,43) and of autograd's tape (cnn_propagator/fullfield.py:329). */
 int bdof_configure(bdof_ctx* ctx, int NY, int NX, int S, int Bmax, int with_grad);
@@ -60,6 +69,10 @@ int bdof_configure(bdof_ctx* ctx, int NY, int NX, int S, int Bmax, int with_grad
  * ifftshift(H)[0][0] in float64 — the factor a constant wave picks up in one step (carrier splitting, below). */
 int bdof_set_physics(bdof_ctx* ctx, double k, const float* hs, const float* hs_det, const double* h00, const double* hdet00,
                      int det_mode, int variant);
+
+/* The same two tables in float64 (HOST arrays of complex128, layout and 1/(NX*NY) scaling of hs / hs_det) for the float64
+ * adjoint sweep of bdof_configure flag 64; call after every bdof_set_physics. */
+int bdof_set_physics_f64(bdof_ctx* ctx, const double* hs, const double* hs_det);
 
 /* Probe wavefront (np_funcs.py:20-21; cnn_propagator/fullfield.py:276-314), split as probe = a0 + eps: `probe_eps` is
  * the HOST array [NX][NY] complex of eps, a0 any complex constant (0 for a general probe, the plane-wave amplitude for a
@@ -220,7 +233,8 @@ int bdof_adam_step_slab(bdof_ctx* ctx, const void* x_old, void* x_new, const voi
                         int NXv, int NZv, int NYv, float g_scale, float alpha_d, float alpha_b, float gamma,
                         float lr, float b1, float b2, float eps, int i_batch, int clip, int x0, int nx);
 
-/* dst[b] = src[idx[b]] for B fields of bytes_per_field bytes (a multiple of 16; idx: device int32 [B]) in one launch:
+/* dst[b] = src[idx[b]] for B fields of bytes_per_field bytes (a multiple of 4; 16-byte copies when it is a multiple of 16;
+ * idx: device int32 [B]) in one launch:
  * this_prj_batch = prj[this_ind_batch] (cnn_propagator/fullfield.py:344) on the device-resident stack of amplitudes. */
 int bdof_gather_fields(bdof_ctx* ctx, void* dst, const void* src, const int* idx, int B, size_t bytes_per_field);
 

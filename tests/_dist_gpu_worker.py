@@ -22,12 +22,14 @@ def main(out_dir):
     from beyond_dof_amd.comm import TorchComm, get_comm, minibatch_schedule
     from beyond_dof_amd.solver import FullfieldSolver
     from beyond_dof_amd import util
-    comm = get_comm()                      # BDOF_COMM_BACKEND=gloo in the environment
-    assert isinstance(comm, TorchComm)
+    from beyond_dof_amd.comm import RcclComm, comm_backend
+    comm = get_comm()                      # BDOF_COMM_BACKEND=gloo in the environment (rccl: one device per rank, >= 2 GPUs)
+    assert isinstance(comm, RcclComm if comm_backend() == 'rccl' else TorchComm)
+    device = comm.local_rank if comm_backend() == 'rccl' else 0
     sharded = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
     n, n_theta, mb, meas, init_d = problem()
     coords = util.rotation_lookup([n, n, n], n_theta)
-    s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, coord_ls=coords, comm=comm, device=0)
+    s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=1e-4, coord_ls=coords, comm=comm, device=device)
     s.set_measurements(meas)
     s.set_volume(init_d, 0.1 * init_d)
     s.reset_moments()

@@ -24,10 +24,12 @@ def main(out_dir, sharded):
     from beyond_dof_amd.comm import get_comm
     from beyond_dof_amd.solver import PtychoSolver
     from beyond_dof_amd import util
+    from beyond_dof_amd.comm import comm_backend
     comm = get_comm()
+    device = comm.local_rank if comm_backend() == 'rccl' else 0
     n, n_theta, psz, pos, init_d, meas, pr, pi = problem()
     mb = len(pos) // comm.size
-    s = PtychoSolver((n, n, n), psz, pos, n_theta, mb, 5000., 1e-7, pr, pi, comm=comm, device=0,
+    s = PtychoSolver((n, n, n), psz, pos, n_theta, mb, 5000., 1e-7, pr, pi, comm=comm, device=device,
                      coord_ls=util.rotation_lookup([n, n, n], n_theta))
     s.set_volume(init_d, 0.1 * init_d)
     s.bcast_volume(0)

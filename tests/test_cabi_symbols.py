@@ -78,3 +78,15 @@ def test_bench_self_launch_fails_loudly_without_a_gpu():
     assert r.returncode != 0
     assert b'no CPU fallback' in r.stderr
     assert r.stdout.strip() == b''
+
+
+def test_no_spill_under_restricted_exec():
+    """The gfx950 ISA of every kernel holds no register spill that is stored just before `s_or_b64 exec, exec, ...` restores the
+    mask of a divergent region (tools/check_spills.py): hipcc 7.2 produced two in k_resident<128> in round 3, and the waves that
+    had no lane in the region reloaded stale scratch — a loss 5 % off, depending on what had run on the CU before.  Compiles the
+    device code once (about a minute, no GPU needed)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_spills
+    hits = check_spills.scan(check_spills.device_isa())
+    assert not hits, hits[:5]

@@ -147,3 +147,48 @@ def test_solver_tail_plan_without_a_gpu():
     s.dim_x = 512
     assert s.tail_plan(n_slabs=3, sharded=False) == (3, False)
     assert sum(nx for _, nx in s.slab_bounds(3)) == 512
+
+
+def test_control_plane_messages_are_parsed_not_executed(tmp_path):
+    """The rendezvous socket carries None / bytes / numpy arrays / JSON values in a typed encoding (no pickle), lives in a
+    directory only this user can enter, and both ends check the peer's uid (round-2 advice)."""
+    from beyond_dof_amd import comm
+    for obj in (None, b'\x00\x01' * 64, [3, 'host', 1.5], {'a': [1, 2]}, 7):
+        assert comm._decode(comm._encode(obj)) == obj
+    a = np.arange(12, dtype=np.float32).reshape(3, 4)
+    b = comm._decode(comm._encode(a))
+    assert b.dtype == a.dtype and np.array_equal(a, b)
+    items = comm._decode(comm._encode_list([comm._encode(None), comm._encode(a), comm._encode([1, 2])]))
+    assert items[0] is None and np.array_equal(items[1], a) and items[2] == [1, 2]
+    with pytest.raises(TypeError):
+        comm._encode(np.array([object()]))
+    with pytest.raises(ValueError):
+        comm._decode(b'\x80\x04junk')                 # a pickle stream is just a malformed message
+    src = open(comm.__file__).read()
+    assert 'import pickle' not in src and 'pickle.loads' not in src
+    d = comm.rendezvous_dir()
+    st = os.stat(d)
+    assert st.st_uid == os.getuid() and (st.st_mode & 0o077) == 0
+    os.environ.pop('BDOF_RDZV', None)
+    assert os.path.dirname(comm.rendezvous_path()) == d
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('backend', ['rccl', 'gloo'])
+def test_bench_self_launch_eight_ranks_rehearsal(backend):
+    """`python bench.py --gpus 8` end to end without a GPU (--rehearse-cpu): the parent starts eight ranks, they meet (native
+    control plane: socket star in a private directory; gloo: TCP store), cover the 200 angles of cfg3 between them, exchange
+    through the backend, take the max-over-ranks time, and rank 0 prints exactly one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR', 'BDOF_RDZV')}
+    env['BDOF_COMM_BACKEND'] = backend
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--rehearse-cpu', '--steps', '3', '--warmup', '1'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['rehearsal'] and d['config']['angles_covered'] == 200 and d['config']['exchange_ok']

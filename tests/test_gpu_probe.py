@@ -88,17 +88,21 @@ def test_device_probe_field_equals_host_propagation():
         assert rel(res[0][k], res[1][k]) <= 2e-7, (k, rel(res[0][k], res[1][k]))
 
 
-def test_probe_optimization_steps_follow_the_oracle():
+@pytest.mark.parametrize('fp,p_start,plr', [(1e-4, 1.0, 1e-3), (None, 0.9, 2e-2)])
+def test_probe_optimization_steps_follow_the_oracle(fp, p_start, plr):
     """Three steps of FullfieldSolver with an optimisable probe (object AND probe updated) against the same loop on the
-    oracle: object by cnn_propagator/util.py:280-291, probe by a standard Adam on (probe_real, probe_imag)."""
+    oracle: object by cnn_propagator/util.py:280-291, probe by a standard Adam on (probe_real, probe_imag).
+    Second case: the probe starts at 0.9 of the true one and moves 2 % per step on a real-space detector — its mean, the
+    reference the resident amplitudes would be split against (m - |a0|), drifts by 6 %: the loss stays the oracle's only
+    because the solver switches the splitting off for a moving probe (round-2 advice: it did not)."""
     from beyond_dof_amd.solver import FullfieldSolver
     rng = np.random.default_rng(2)
-    n, n_theta, mb, fp = 64, 6, 2, 1e-4
+    n, n_theta, mb = 64, 6, 2
     od = rng.uniform(0, 2e-6, size=(n, n, n))
     ob = 0.1 * od
     coords = orc.rotation_lookup([n, n, n], n_theta)
     idx = np.array([1, 4])
-    pr0 = 1 + 0.02 * rng.normal(size=(n, n))
+    pr0 = p_start * (1 + 0.02 * rng.normal(size=(n, n)))
     pi0 = 0.02 * rng.normal(size=(n, n))
     rot = np.stack([orc.apply_rotation(np.stack([od, ob], axis=3), coords[j]) for j in idx])
     true_pr, true_pi = np.ones((n, n)), np.zeros((n, n))
@@ -109,7 +113,6 @@ def test_probe_optimization_steps_follow_the_oracle():
     s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=fp, coord_ls=coords, probe_real=pr0, probe_imag=pi0)
     s.set_volume(od, ob)
     s.set_measurements(prj)
-    plr = 1e-3
     s.enable_probe_optimization(pr0, pi0, plr)
     x = np.array([od, ob])
     m = v = None

@@ -155,3 +155,69 @@ def test_tiled_gradient_slab_object():
     rl, rgd, rgb, _ = _torch_tiled_loss_grad(delta, 0.1 * delta, probe, meas, tile, halo, seg, tp.taper)
     assert abs(loss - rl) <= 1e-5 * abs(rl)
     assert rel(gd, rgd.sum(axis=2)) <= 2e-4 and rel(gb, rgb.sum(axis=2)) <= 2e-4
+
+
+def _cfg4_inputs(n, r_zp=256.0, half=256.0):
+    """BASELINE cfg4's inputs (tools/bench_cfg4.py): a zone plate of radius r_zp whose outermost zone is 4 pixels wide, delta
+    5e-5 in the open zones, and a square probe of 2 * half pixels with 32-pixel raised-cosine edges, zero-padded into n^2."""
+    t = np.arange(n, dtype=np.float64)
+    r2 = (t[:, None] - n / 2) ** 2 + (t[None, :] - n / 2) ** 2
+    zone = (np.floor(r2 / (2 * r_zp * 4.0)).astype(np.int64) % 2 == 0) & (r2 < r_zp ** 2)
+    slab = np.where(zone, 5e-5, 0.0)
+    edge = np.clip((half + 16. - np.abs(t - n / 2)) / 32., 0., 1.)
+    soft = 0.5 - 0.5 * np.cos(np.pi * edge)
+    return slab, soft[:, None] * soft[None, :]
+
+
+def test_cfg4_tiles_512_on_the_4096_field_vs_float64():
+    """BASELINE configs[3] at its stated shape: a 512^2 probe zero-padded into a 4096^2 field through a zone-plate slab, tiles of
+    512^2 with a 64-pixel halo (121 tiles in one batch, default stitch interval), 96 slices — against the float64 whole-field
+    propagation of np_funcs.py:36-43 (H from the oracle's golden-pinned get_kernel; scipy's threaded FFT, the 4096^2 complex128
+    transforms take ~0.15 s each on the box's cores).  Forward wave within the north star's 1e-5."""
+    import scipy.fft as sfft
+    from beyond_dof_amd.tiling import TiledPropagator
+    n, S = 4096, 96
+    slab, probe = _cfg4_inputs(n)
+    tp = TiledPropagator((n, n), S, 5000., 1e-7, tile=512, halo=64)
+    assert tp.n_tiles == 121 and tp.core == 384 and tp.taper == 32 and tp.seg == int(0.5 * 32 / 0.124) and len(tp.segments()) == 1
+    tp.set_object_slab(slab, 0.1 * slab)
+    out = tp.forward(probe, np.zeros_like(probe))
+    del tp
+    k = 2. * orc.PI * 1.0 / (1240. / 5000.)
+    h = np.fft.ifftshift(orc.get_kernel(1.0, 1240. / 5000., np.array([1., 1., 1.]), (n, n)))
+    cmod = np.exp(1j * k * slab) * np.exp(-k * 0.1 * slab)
+    w = probe.astype(np.complex64).astype(np.complex128)
+    for z in range(S):
+        w = w * cmod
+        if z < S - 1:
+            w = sfft.ifft2(sfft.fft2(w, workers=-1) * h, workers=-1)
+    e_wave, e_int = rel(out, w), rel(np.abs(out) ** 2, np.abs(w) ** 2)
+    print('cfg4 tiles 512/64 on 4096^2 x 96 slices vs float64: wave', e_wave, 'intensity', e_int)
+    assert e_wave <= 1e-5 and e_int <= 1e-5, (e_wave, e_int)      # measured 5.8e-6 (round 2, before the exact forward transforms)
+
+
+def test_cfg4_tile_size_two_ranges_and_gradient_vs_oracle():
+    """The 512^2 / 64 plan on a field the float64 oracle can differentiate: 1024^2 (9 tiles), 80 slices of a (FY, FX, S) object
+    under the zone plate's aperture = two stitch ranges (64 + 16).  Forward against the whole-field oracle, loss and gradient
+    (bdof_adjoint_range at tile 512, stitch adjoints, overlap-add of the tiles' gradient rows) against the oracle's
+    hand-derived adjoint of the whole-field model, variant tf_all."""
+    from beyond_dof_amd.tiling import TiledPropagator
+    n, S = 1024, 80
+    slab, probe = _cfg4_inputs(n, r_zp=128.0, half=160.0)
+    rng = np.random.default_rng(4)
+    delta = slab[:, :, None] * rng.uniform(0.5, 1.0, size=(1, 1, S))      # the plate, its strength varying from slice to slice
+    beta = 0.1 * delta
+    tp = TiledPropagator((n, n), S, 5000., 1e-7, tile=512, halo=64, slices_per_exchange=64, variant='tf_all', with_grad=True)
+    assert tp.n_tiles == 9 and tp.segments() == [(0, 64), (64, 16)]
+    tp.set_object(delta, beta)
+    out = tp.forward(probe, np.zeros_like(probe))
+    zero = np.zeros_like(probe)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta[None], beta[None], probe, zero, 5000., 1e-7, None, (1,) + delta.shape, variant='tf_all',
+                                                  return_probe_array=False)
+    assert rel(out, ref[0]) <= 1e-5, rel(out, ref[0])
+    meas = (np.abs(ref[0]) * (1 + 0.02 * rng.normal(size=probe.shape))).astype(np.float32).astype(np.float64)
+    loss, gd, gb = tp.loss_and_grad(probe, zero, meas)
+    wl, wgd, wgb = orc.multislice_loss_and_grad(delta[None], beta[None], probe, zero, 5000., 1e-7, meas[None], None, 'tf_all')
+    e = (abs(loss - wl) / abs(wl), rel(gd, wgd[0]), rel(gb, wgb[0]))
+    print('tile 512 gradient vs the whole-field oracle: loss', e[0], 'g_delta', e[1], 'g_beta', e[2])
+    assert e[0] <= 1e-5 and e[1] <= 2e-4 and e[2] <= 2e-4, e

@@ -152,3 +152,15 @@ def test_rotation_tables_square_and_non_square():
     assert len(pairs) == size[1] * size[2]                        # every (x, z) once
     theirs = orc.rotation_lookup(size, 1)[0]
     assert len(set(map(tuple, theirs))) < size[1] * size[2]       # the reference's enumeration repeats pairs
+
+
+def test_point_probe_is_refused_by_both_entry_points(tmp_path):
+    """probe_type='point' needs the spherical-wave propagator (cnn_propagator/fullfield.py:298-301 says so itself): refused by
+    reconstruct_fullfield as by the simulators, before anything touches a GPU."""
+    import pytest
+    from beyond_dof_amd import h5io
+    from beyond_dof_amd.fullfield import reconstruct_fullfield
+    h5io.write_dataset(str(tmp_path / 'data.h5'), 'exchange/data', np.ones((2, 8, 8), dtype=np.complex64))
+    with pytest.raises(ValueError, match='point'):
+        reconstruct_fullfield('data.h5', save_path=str(tmp_path), n_epochs=1, minibatch_size=1, probe_type='point',
+                              initial_guess=[np.zeros((8, 8, 8)), np.zeros((8, 8, 8))])

@@ -39,5 +39,7 @@ for it in range(1 + steps):
 s.ctx.sync()
 dt = (time.perf_counter() - t0) / steps
 px = ps * ps
-print('probe %d^2, %d positions, %d slices: %.2f ms per Adam step, %.0f slice-steps/s, %.1f GB/s at 104 B/px' %
-      (ps, mb, n, dt * 1e3, mb * n / dt, 104.0 * px * mb * n / dt / 1e9))
+# the LDS-resident kernel moves 40 B per pixel per slice-step (modulation factor 8 + tape write 8; tape read 8 + factor 8 +
+# gradient write 8) — that is the figure its roofline fraction is priced at, not the streaming engines' 104 B
+print('probe %d^2, %d positions, %d slices: %.2f ms per Adam step, %.0f slice-steps/s, %.1f GB/s at the resident kernel\'s 40 B/px (%.3f of 8 TB/s)' %
+      (ps, mb, n, dt * 1e3, mb * n / dt, 40.0 * px * mb * n / dt / 1e9, 40.0 * px * mb * n / dt / 8e12))
