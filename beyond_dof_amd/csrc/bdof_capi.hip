@@ -65,6 +65,11 @@ struct bdof_ctx {
     std::complex<double> ksum{1.0, 0.0};
     float k_conv = 0.f;
     cf *bufC = nullptr, *conv_scal = nullptr;
+    // carrier field of the real-space propagator (bdof_set_conv_probe_stack): p_0 .. p_S, float32 planes [S + 1][NX][NY]; the
+    // detector plane of p_S in float64; corner pixels of p_0 and p_S (the renormalisation s = p_0[0,0] / psi_S[0,0,0])
+    cf* cstack = nullptr;
+    double2* cdet64 = nullptr;
+    std::complex<double> c_p0{0.0, 0.0}, c_pS{0.0, 0.0};
     // LDS-resident engine (small square fields, bdof_resident.h)
     bool resident = false, res_dirty = true, res_always = false;
     cf *hsT = nullptr, *hdetT = nullptr, *twR = nullptr, *res_carrier = nullptr;
@@ -435,13 +440,17 @@ static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* t
 }
 
 // Real-space detector on L1 rows.  Returns the grid (= number of partial sums when meas != null).
+// pf64 / pscale: a float64 carrier field of the caller's own and its complex factor (the real-space propagator's planes and
+// renormalisation); by default the ctx's pdet64 goes with pfield == pdet
+static const double2 kOne = {1.0, 0.0};
 static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool tstore, cf* out_wave, const float* meas,
                             float in_scale, float out_scale, float seed_scale, cf carrier, const cf* pfield = nullptr,
-                            const float* dref_override = nullptr) {
+                            const float* dref_override = nullptr, const double2* pf64 = nullptr, double2 pscale = kOne) {
     ProfScope ps(c, BDOF_K_LOSS);
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NX,
                in_scale, out_scale, seed_scale, carrier, c->twY, pfield, c->meas_dev, nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0),
-               c->meas_dev ? (dref_override ? *dref_override : meas_dref(c)) : 0.f, pfield && pfield == c->pdet ? c->pdet64 : nullptr};
+               c->meas_dev ? (dref_override ? *dref_override : meas_dref(c)) : 0.f,
+               pf64 ? pf64 : (pfield && pfield == c->pdet ? c->pdet64 : nullptr), pscale};
     int grid = 0;
     DISPATCH_N(c->NY, {
         grid = rows_grid<N_>(c, B, c->NX);
@@ -453,13 +462,14 @@ static int launch_loss_real(bdof_ctx* c, int B, const cf* in, cf* out_hyb, bool 
 
 // Far-field detector on L2 rows; the seed goes back transposed into L1.
 static int launch_loss_far(bdof_ctx* c, int B, const cf* in, cf* out_hyb, cf* out_wave, const float* meas, float in_scale,
-                           float out_scale, float seed_scale, const cf* pfield = nullptr) {
+                           float out_scale, float seed_scale, const cf* pfield = nullptr, const double2* pf64 = nullptr, double2 pscale = kOne) {
     ProfScope ps(c, BDOF_K_LOSS);
     const bool gc = meas && out_hyb && use_adj_carrier(c);
     LossArgs a{sub_field(c, in), sub_field(c, out_hyb), sub_field(c, out_wave), sub_field(c, meas), c->partial + 2 * c->sub_part, B, c->NY,
                in_scale, out_scale, seed_scale, carrier_det(c), c->twX, pfield, 0,
                gc ? c->gcar + c->sub_b0 : nullptr, gc ? c->gt0 + c->sub_b0 : nullptr,
-               d2(carrier_end(c) * ((double)c->NX * (double)c->NY)), d2(carrier_end(c)), 0.f, pfield && pfield == c->pdetT ? c->pdetT64 : nullptr};
+               d2(carrier_end(c) * ((double)c->NX * (double)c->NY)), d2(carrier_end(c)), 0.f,
+               pf64 ? pf64 : (pfield && pfield == c->pdetT ? c->pdetT64 : nullptr), pscale};
     int grid = 0;
     DISPATCH_N(c->NX, {
         grid = rows_grid<N_>(c, B, c->NY);
@@ -659,7 +669,8 @@ static int generic_forward(bdof_ctx* c, int B, void* out_wave, bool keep_tape) {
     if (out_wave) {
         const size_t n = (size_t)B * c->NX * c->NY;
         GLossArgs la{c->bufA, (cf*)out_wave, nullptr, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
-                     make_float2((float)a.real(), (float)a.imag()), 0.f, c->pdet, 0, 0.f, nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0), nullptr};
+                     make_float2((float)a.real(), (float)a.imag()), 0.f, c->pdet, 0, 0.f, nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0), nullptr,
+                     nullptr, 0.0, make_double2(0.0, 0.0)};
         hipLaunchKernelGGL(k_g_loss, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, la);
     }
     return 0;
@@ -683,7 +694,7 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
         GLossArgs la{c->bufA, (cf*)out_wave, meas, c->partial, B, c->NX, c->NY, c->det_mode == BDOF_DET_FAR,
                      make_float2((float)a.real(), (float)a.imag()), 2.f / ((float)B * (float)c->NX * (float)c->NY), c->pdet, c->meas_dev,
                      c->meas_dev ? meas_dref(c) : 0.f, gc ? c->gcar : nullptr, gc ? c->gt0 : nullptr, d2(a), d2(carrier_end(c)), c->pdet ? c->pdet64 : nullptr,
-                     f64 ? c->g64 : nullptr, c->meas_dev ? std::abs(c->a0) : 0.0};
+                     f64 ? c->g64 : nullptr, c->meas_dev ? std::abs(c->a0) : 0.0, make_double2(0.0, 0.0)};
         hipLaunchKernelGGL(k_g_loss, dim3(egrid), dim3(256), 0, c->stream, la);
     }
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, egrid, 1.0 / ((double)B * c->NX * c->NY), c->loss_dev);
@@ -875,13 +886,14 @@ static void free_generic(bdof_ctx* c) {
 
 static void free_workspace(bdof_ctx* c) {
     free_generic(c);
-    void* ptrs[] = {c->pdet64, c->pdetT64, c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->taps_dev, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->gpsi0, c->partial, c->loss_dev};
+    void* ptrs[] = {c->cstack, c->cdet64, c->pdet64, c->pdetT64, c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->taps_dev, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->gpsi0, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
     c->pstack = c->pdet = c->pdetT = nullptr;
     c->pdet64 = c->pdetT64 = nullptr;
     c->resident = false;
     c->bufC = c->conv_scal = nullptr;
+    c->cstack = nullptr; c->cdet64 = nullptr;
     c->taps_dev = nullptr;
     c->have_conv = false;
     c->twY = c->twX = c->hs = c->hdet = c->hcomb = c->probe = c->bufA = c->bufB = c->tape = nullptr;
@@ -1420,7 +1432,7 @@ int bdof_field_loss_seed(bdof_ctx* c, void* field, const float* meas, int FX, in
     const size_t n = (size_t)FX * FY;
     const int egrid = g_elem_grid(c, n);
     GLossArgs la{(cf*)field, nullptr, meas, c->partial, 1, FX, FY, 0, make_float2(0.f, 0.f), (float)(2.0 / (double)n), nullptr, 0, 0.f,
-                 nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0), nullptr};
+                 nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0), nullptr, nullptr, 0.0, make_double2(0.0, 0.0)};
     hipLaunchKernelGGL(k_g_loss, dim3(egrid), dim3(256), 0, c->stream, la);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, egrid, 1.0 / (double)n, c->loss_dev);
     HIPC(c, hipGetLastError());
@@ -1686,23 +1698,35 @@ template <bool BWD> static int launch_conv(bdof_ctx* c, ConvArgs& a) {
 // forward sweep of the conv propagator; leaves psi_S (eps part) in bufB and the scalars in conv_scal
 static int conv_forward_sweep(bdof_ctx* c, int B, bool tape) {
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
-    const size_t n = (size_t)B * c->NX * c->NY;
+    const size_t n = (size_t)B * c->NX * c->NY, plane = (size_t)c->NX * c->NY;
     const int egrid = (int)std::min<size_t>((n + 255) / 256, (size_t)c->ncu * 16);
+    const bool cs = c->cstack != nullptr;           // carrier field: eps is the scattered wave alone, padded with zeros
+    const cf zero = make_float2(0.f, 0.f);
     ObjView obj = c->obj;
     cf* cur = tape ? c->tape : c->bufA;
-    ConvInitArgs ia{c->probe, cur, obj, B, c->NX, c->NY, conv_carrier(c, 0)};
+    ConvInitArgs ia{c->probe, cur, obj, B, c->NX, c->NY, conv_carrier(c, 0), cs ? c->cstack : nullptr};
     hipLaunchKernelGGL(k_conv_init, dim3(egrid), dim3(256), 0, c->stream, ia);
     int r;
     for (int z = 0; z < c->S; ++z) {
         const bool last = z == c->S - 1;
         cf* out = last ? c->bufB : (tape ? c->tape + (size_t)(z + 1) * fld : (cur == c->bufA ? c->bufC : c->bufA));
-        ConvArgs a{cur, out, nullptr, nullptr, obj, B, c->NX, c->NY, last ? -1 : z + 1, conv_pad(c, z), conv_carrier(c, z + 1),
-                   c->k_conv, c->taps_dev, c->taps.ks};
+        ConvArgs a{cur, out, nullptr, nullptr, obj, B, c->NX, c->NY, last ? -1 : z + 1, cs ? zero : conv_pad(c, z), conv_carrier(c, z + 1),
+                   c->k_conv, c->taps_dev, c->taps.ks, cs && !last ? c->cstack + (size_t)(z + 1) * plane : nullptr};
         if ((r = launch_conv<false>(c, a))) return r;
         cur = out;
     }
-    hipLaunchKernelGGL(k_conv_scalars, dim3(1), dim3(64), 0, c->stream, c->bufB, conv_carrier(c, c->S), c->probe,
-                       conv_carrier(c, 0), c->conv_scal);
+    hipLaunchKernelGGL(k_conv_scalars, dim3(1), dim3(64), 0, c->stream, c->bufB, cs ? cfl(c->c_pS) : conv_carrier(c, c->S), c->probe,
+                       cs ? cfl(c->c_p0) : conv_carrier(c, 0), c->conv_scal);
+    return 0;
+}
+
+// carrier field: the renormalisation s = p_0[0,0] / (p_S[0,0] + eps_S[0,0,0]) in float64 (one 8-byte read-back)
+static int conv_scale64(bdof_ctx* c, double2* s64) {
+    cf e0;
+    HIPC(c, hipMemcpyAsync(&e0, c->bufB, sizeof(cf), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const std::complex<double> sd = c->c_p0 / (c->c_pS + std::complex<double>(e0.x, e0.y));
+    *s64 = make_double2(sd.real(), sd.imag());
     return 0;
 }
 
@@ -1717,6 +1741,26 @@ static int conv_check(bdof_ctx* c, int B, const int* angle_of_b) {
 
 extern "C" {
 
+int bdof_set_conv_probe_stack(bdof_ctx* c, const float* stack, const double* det64, double p0_re, double p0_im, double pS_re, double pS_im) {
+    if (!c) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->cstack) { (void)hipFree(c->cstack); c->cstack = nullptr; }
+    if (c->cdet64) { (void)hipFree(c->cdet64); c->cdet64 = nullptr; }
+    if (!stack && !det64) return 0;
+    if (!stack || !det64) return fail(c, BDOF_ERR_ARG, "bdof_set_conv_probe_stack: both arrays or neither");
+    if (!c->have_conv) return fail(c, BDOF_ERR_STATE, "bdof_set_conv has not been called");
+    const size_t plane = (size_t)c->NX * c->NY;
+    HIPC(c, hipMalloc((void**)&c->cstack, sizeof(cf) * plane * (size_t)(c->S + 1)));
+    HIPC(c, hipMalloc((void**)&c->cdet64, sizeof(double2) * plane));
+    HIPC(c, hipMemcpy(c->cstack, stack, sizeof(cf) * plane * (size_t)(c->S + 1), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->cdet64, det64, sizeof(double2) * plane, hipMemcpyHostToDevice));
+    c->c_p0 = std::complex<double>(p0_re, p0_im);
+    c->c_pS = std::complex<double>(pS_re, pS_im);
+    return 0;
+}
+
 int bdof_forward_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave) {
     int r = conv_check(c, B, angle_of_b);
     if (r) return r;
@@ -1729,21 +1773,28 @@ int bdof_forward_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff
     const size_t n = (size_t)B * c->NX * c->NY;
     const int egrid = (int)std::min<size_t>((n + 255) / 256, (size_t)c->ncu * 16);
     const cf zero = make_float2(0.f, 0.f);
+    const bool cs = c->cstack != nullptr;
+    const size_t plane = (size_t)c->NX * c->NY;
+    const cf* pS = cs ? c->cstack + (size_t)c->S * plane : nullptr;
     if (c->det_mode == BDOF_DET_NONE) {
-        ConvFinalArgs fa{c->bufB, (cf*)out_wave, nullptr, nullptr, nullptr, c->conv_scal, conv_carrier(c, c->S), n, 0.f, 0, make_float2(0.f, 0.f), 0.f, 0.f};
+        ConvFinalArgs fa{c->bufB, (cf*)out_wave, nullptr, nullptr, nullptr, c->conv_scal, cs ? zero : conv_carrier(c, c->S), n, 0.f, 0, zero, 0.f, 0.f, pS, plane};
         hipLaunchKernelGGL((k_conv_final<0>), dim3(egrid), dim3(256), 0, c->stream, fa);
     } else {
-        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, conv_carrier(c, c->S), n, 0.f, 0, make_float2(0.f, 0.f), 0.f, 0.f};
+        // carrier field: only the scattered part s eps_S goes through the float32 detector transforms; the carrier's detector
+        // plane comes in float64, times s (conv_scale64)
+        double2 s64 = kOne;
+        if (cs && (r = conv_scale64(c, &s64))) return r;
+        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, cs ? zero : conv_carrier(c, c->S), n, 0.f, 0, zero, 0.f, 0.f, nullptr, plane};
         hipLaunchKernelGGL((k_conv_final<0>), dim3(egrid), dim3(256), 0, c->stream, fa);
         RealToHybArgs ra{c->bufA, c->bufC, B, c->NX, c->twY};
         DISPATCH_N(c->NY, { hipLaunchKernelGGL((k_row_real_to_hyb<N_>), dim3(rows_grid<N_>(c, B, c->NX)), dim3(BDOF_THREADS), 0, c->stream, ra); });
         if (c->det_mode == BDOF_DET_NEAR) {
             launch_row_prop(c, B, c->bufC, c->bufA, c->hdet, 1.f, 0);
-            launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f, zero);
+            launch_loss_real(c, B, c->bufA, nullptr, false, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f, zero, nullptr, nullptr, cs ? c->cdet64 : nullptr, s64);
         } else {
             const std::complex<double> keep = c->a0;      // the far-field kernel adds the carrier's DC bin: none here
             c->a0 = 0.0;
-            launch_loss_far(c, B, c->bufC, nullptr, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f);
+            launch_loss_far(c, B, c->bufC, nullptr, (cf*)out_wave, nullptr, 1.f, 1.f, 0.f, nullptr, cs ? c->cdet64 : nullptr, s64);
             c->a0 = keep;
         }
     }
@@ -1790,26 +1841,41 @@ int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xo
         absA = (float)std::abs(A);
         dref = (float)(std::abs(A) - std::abs(c->a0));
     }
-    const cf car_end = split ? zero : conv_carrier(c, c->S);       // split: only the scattered part e' = s eps goes on
-    if (c->det_mode == BDOF_DET_NONE) {
-        ConvFinalArgs fa{c->bufB, (cf*)out_wave, c->bufA, meas, c->partial, c->conv_scal, car_end, n, (float)seed_scale, split ? 1 : 0, carA, absA, dref};
+    const bool cs = c->cstack != nullptr;
+    const size_t plane = (size_t)c->NX * c->NY;
+    double2 s64 = kOne;
+    if (cs && (r = conv_scale64(c, &s64))) return r;
+    const cf car_end = (split || cs) ? zero : conv_carrier(c, c->S);       // split / carrier field: only the scattered part s eps goes on
+    if (c->det_mode == BDOF_DET_NONE && cs) {
+        // q = s (p_S + eps_S): the scattered part in float32, the residual against s p_S in float64 (loss_seed_f64), seed in place
+        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, zero, n, 0.f, 0, zero, 0.f, 0.f, nullptr, plane};
+        hipLaunchKernelGGL((k_conv_final<0>), dim3(egrid), dim3(256), 0, c->stream, fa);
+        GLossArgs la{c->bufA, (cf*)out_wave, meas, c->partial, B, c->NX, c->NY, 0, zero, (float)seed_scale, c->cstack + (size_t)c->S * plane, 0, 0.f,
+                     nullptr, nullptr, make_double2(0.0, 0.0), make_double2(0.0, 0.0), c->cdet64, nullptr, 0.0, s64};
+        hipLaunchKernelGGL(k_g_loss, dim3(egrid), dim3(256), 0, c->stream, la);
+        hipLaunchKernelGGL(k_conv_scale_seed, dim3(egrid), dim3(256), 0, c->stream, c->bufA, c->conv_scal, n);
+        npart = egrid;
+        gp = c->bufA;
+    } else if (c->det_mode == BDOF_DET_NONE) {
+        ConvFinalArgs fa{c->bufB, (cf*)out_wave, c->bufA, meas, c->partial, c->conv_scal, car_end, n, (float)seed_scale, split ? 1 : 0, carA, absA, dref, nullptr, plane};
         hipLaunchKernelGGL((k_conv_final<1>), dim3(egrid), dim3(256), 0, c->stream, fa);
         npart = egrid;
         gp = c->bufA;
     } else {
-        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, car_end, n, 0.f, 0, zero, 0.f, 0.f};
+        ConvFinalArgs fa{c->bufB, c->bufA, nullptr, nullptr, nullptr, c->conv_scal, car_end, n, 0.f, 0, zero, 0.f, 0.f, nullptr, plane};
         hipLaunchKernelGGL((k_conv_final<0>), dim3(egrid), dim3(256), 0, c->stream, fa);
         RealToHybArgs ra{c->bufA, c->bufC, B, c->NX, c->twY};
         DISPATCH_N(c->NY, { hipLaunchKernelGGL((k_row_real_to_hyb<N_>), dim3(rows_grid<N_>(c, B, c->NX)), dim3(BDOF_THREADS), 0, c->stream, ra); });
         if (c->det_mode == BDOF_DET_NEAR) {
             launch_row_prop(c, B, c->bufC, c->bufA, c->hdet, 1.f, 0);                                     // d_hat (L1)
             npart = launch_loss_real(c, B, c->bufA, c->bufC, true, (cf*)out_wave, meas, 1.f, 1.f, (float)seed_scale, carA, nullptr,
-                                     split ? &dref : nullptr);
+                                     split ? &dref : nullptr, cs ? c->cdet64 : nullptr, s64);
             launch_row_prop(c, B, c->bufC, c->bufA, c->hdet, 1.f, 1);                                     // g_hat(q) (L1)
         } else {
             const std::complex<double> keep = c->a0;
             c->a0 = 0.0;
-            npart = launch_loss_far(c, B, c->bufC, c->bufA, (cf*)out_wave, meas, 1.f, 1.f, (float)seed_scale);   // g_hat(q) (L1)
+            npart = launch_loss_far(c, B, c->bufC, c->bufA, (cf*)out_wave, meas, 1.f, 1.f, (float)seed_scale, nullptr,
+                                    cs ? c->cdet64 : nullptr, s64);                                           // g_hat(q) (L1)
             c->a0 = keep;
         }
         launch_loss_real(c, B, c->bufA, nullptr, false, c->bufC, nullptr, 1.f, 1.f, 0.f, zero);            // G(q), real space
@@ -1823,7 +1889,8 @@ int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xo
     cf* gcur = gp;
     for (int z = c->S - 1; z >= 0; --z) {
         cf* gout = gcur == c->bufB ? c->bufA : c->bufB;
-        ConvArgs a{gcur, gout, c->tape + (size_t)z * fld, c->grot, obj, B, c->NX, c->NY, z, zero, conv_carrier(c, z), c->k_conv, c->taps_dev, c->taps.ks};
+        ConvArgs a{gcur, gout, c->tape + (size_t)z * fld, c->grot, obj, B, c->NX, c->NY, z, zero, conv_carrier(c, z), c->k_conv, c->taps_dev, c->taps.ks,
+                   cs ? c->cstack + (size_t)z * plane : nullptr};
         if ((r = launch_conv<true>(c, a))) return r;
         gcur = gout;
     }
@@ -1958,11 +2025,12 @@ int bdof_adam_step_slab(bdof_ctx* c, const void* x_old, void* x_new, const void*
     AdamArgs a{(const float2*)x_old, (float2*)x_new, (const float2*)g, (float2*)m, (float2*)v, mask, NXv, NZv, NYv,
                g_scale, alpha_d, alpha_b, gamma, lr, (float)b1d, (float)b2d, eps, (float)(1.0 / bc1), (float)(1.0 / bc2),
                (float)(1.0 - b1d), (float)(1.0 - b2d), clip, x0, x0 + nx};
-    const size_t n = (size_t)nx * NZv * NYv;
-    size_t need = (n + 255) / 256;
-    int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
-    grid = (grid + 7) / 8 * 8;                       // k_adam deals the range to the 8 XCDs by blockIdx % 8
-    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, c->stream, a);
+    // one workgroup per block of 256 (z, y) columns, the x range cut into chunks until the launch has ~8 workgroups per CU
+    // (each chunk re-reads two neighbour planes: chunks stay >= 8 planes where the range allows)
+    const size_t nblk = ((size_t)NZv * NYv + 255) / 256;
+    int gx = (int)std::min<size_t>((nblk + 7) / 8 * 8, (size_t)c->ncu * 16);
+    int gy = (int)std::min<size_t>(std::max<size_t>(1, ((size_t)c->ncu * 8 + gx - 1) / gx), std::max(1, nx / 8));
+    hipLaunchKernelGGL(k_adam, dim3(gx, gy), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;
 }

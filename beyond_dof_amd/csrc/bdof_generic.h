@@ -68,6 +68,7 @@ struct GLossArgs {
     const double2* pdet64;   // nullable: `pdet` in float64 (loss_seed_f64)
     double2* seed64;         // nullable [B][NX][NY]: float64 adjoint sweep (bdof_configure flag 64) — detector wave, residual and
     double meas_ref;         // seed all formed in float64 and left here un-rounded; meas_ref: what the host subtracted (meas_dev)
+    double2 pscale;          // complex factor on pdet64 (the real-space propagator's renormalisation s; 0, 0 means 1)
 };
 
 __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
@@ -105,7 +106,9 @@ __global__ __launch_bounds__(256) void k_g_loss(GLossArgs a) {
         if (a.pdet64 && a.meas) {
             const size_t oi = a.far ? ((size_t)b * a.NY + y) * a.NX + x : idx;
             cf dw;
-            a.field[idx] = loss_seed_f64(d, a.pdet64[(size_t)x * a.NY + y], a.meas[oi], a.seed_scale, acc, acc2, dw);
+            double2 p = a.pdet64[(size_t)x * a.NY + y];
+            if (a.pscale.x != 0.0 || a.pscale.y != 0.0) p = make_double2(p.x * a.pscale.x - p.y * a.pscale.y, p.x * a.pscale.y + p.y * a.pscale.x);
+            a.field[idx] = loss_seed_f64(d, p, a.meas[oi], a.seed_scale, acc, acc2, dw);
             if (a.out_wave) a.out_wave[oi] = dw;
             continue;
         }

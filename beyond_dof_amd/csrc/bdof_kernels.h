@@ -398,6 +398,7 @@ struct LossArgs {
     double2 a_end;       // a_end: constant part of phi_{S-1}
     float dref;          // meas_dev: |carrier| - reference subtracted by the host (loss_seed_dev)
     const double2* pfield64;   // nullable: `pfield` in float64 — the residual is then formed in float64 (loss_seed_f64)
+    double2 pscale;            // complex factor on pfield64 (the real-space propagator's renormalisation s, else 1)
 };
 
 // Adjoint carrier.  With a plane-wave probe and a far-field detector nearly all of the detector wave sits in ONE bin (DC,
@@ -497,12 +498,15 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<N>::MIN_WAVES) void k_row_loss
             for (int m = 0; m < 8; ++m) u[m] = cscale(u[m], a.in_scale);
             const bool dev = !FAR && a.meas_dev && a.meas && !a.pfield;
             cf e0 = make_float2(0.f, 0.f);        // FAR: scattered part of the DC bin
-            if (a.pfield64 && a.meas) {
+            if (a.pfield64) {
                 const double2* pf = a.pfield64 + (size_t)(r0 + r) * N;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
+                    const double2 q = pf[tid + m * C::T];
+                    const double2 p = make_double2(q.x * a.pscale.x - q.y * a.pscale.y, q.x * a.pscale.y + q.y * a.pscale.x);
                     cf dw;
-                    u[m] = loss_seed_f64(u[m], pf[tid + m * C::T], mm[m], a.seed_scale, acc, acc2, dw);
+                    if (a.meas) u[m] = loss_seed_f64(u[m], p, mm[m], a.seed_scale, acc, acc2, dw);
+                    else dw = u[m] = make_float2((float)(p.x + (double)u[m].x), (float)(p.y + (double)u[m].y));
                     if (a.out_wave) a.out_wave[off + tid + m * C::T] = dw;
                 }
             } else if (dev) {
@@ -619,7 +623,10 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
     const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
     // the transforms of the ADJOINT field run with exact constants (EX, bdof_fft.h); re-deriving phi from the tape does not
     constexpr bool EX = BDOF_EX_ADJ;
-    constexpr bool EXP = BDOF_EX_FWD_A;       // A_z's own inverse transform, repeated here bit for bit (HIST 1)
+    // phi_z is re-derived from the tape with plain float32 tables: it is ONE transform of the scattered part (no chain for a
+    // table error to add up along, and phi = carrier + scattered part enters the gradient only through conj(phi) G), so the
+    // exact constants of A_z's own inverse transform buy nothing here and cost 2.4 us per launch (1.2 ms per cfg3 step)
+    constexpr bool EXP = false;
     constexpr bool LO = EX || EXP;
     __shared__ cf smem_tw[FftTw<NY>::LDS_CNT * (LO ? 2 : 1)];
     FftTw<NY> tw;
@@ -858,47 +865,57 @@ struct AdamArgs {
 
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) - (v < 0.f); }
 
+// One thread owns a (z, y) column and walks it along x with the three x-neighbours of the TV stencil in registers (the volume is
+// [X][Z][Y]: x is the slowest axis, its neighbours are NZ*NY*8 B away — 2 MB at 512^3 — and the element-per-thread form of
+// rounds 1-2 fetched them from HBM again: 10.2 GB of traffic per 512^3 step against 7.5 GB algorithmic).  Every plane of x_old is
+// now read once per column plus once per z-neighbour row, and those rows belong to the same XCD's workgroups (blockIdx -> column
+// block mapping below), so they hit in its L2.  blockIdx.y splits the x range of the launch into chunks (two extra plane reads
+// per chunk) so that small volumes and thin slabs still fill the chip.  Same arithmetic in the same order as before: bit-identical.
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
-    const size_t slab = (size_t)a.NZv * a.NYv;
-    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin, so workgroup b works in the (b % 8)-th eighth of the
-    // range and walks it linearly with its XCD's other workgroups — the z+-1 / x+-1 neighbours of the TV stencil (4 KB and
-    // NZ*NY*8 B away) are then lines the same XCD's L2 has just seen, instead of another XCD's.
-    const size_t first = (size_t)a.x0 * slab, total = (size_t)(a.x1 - a.x0) * slab;
-    const size_t per_xcd = (total + 7) / 8;
-    const size_t lane0 = (size_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x, stride = (size_t)(gridDim.x >> 3) * blockDim.x;
-    const size_t c0 = (size_t)(blockIdx.x & 7) * per_xcd, c1 = c0 + per_xcd < total ? c0 + per_xcd : total;
-    for (size_t loc = c0 + lane0; loc < c1; loc += stride) {
-        const size_t idx = first + loc;
-        const int y = idx % a.NYv;
-        const size_t r = idx / a.NYv;
-        const int z = r % a.NZv;
-        const int x = r / a.NZv;
-        const float2 xv = a.x_old[idx];
-        float gd = a.g[idx].x * a.g_scale + a.alpha_d * sgn(xv.x);
-        float gb = a.g[idx].y * a.g_scale + a.alpha_b * sgn(xv.y);
-        if (a.gamma != 0.f) {
-            const size_t sy = 1, sz = a.NYv, sx = (size_t)a.NZv * a.NYv;
-            const float ym = a.x_old[idx - y * sy + ((y + a.NYv - 1) % a.NYv) * sy].x;
-            const float yp = a.x_old[idx - y * sy + ((y + 1) % a.NYv) * sy].x;
-            const float zm = a.x_old[idx - z * sz + ((z + a.NZv - 1) % a.NZv) * sz].x;
-            const float zp = a.x_old[idx - z * sz + ((z + 1) % a.NZv) * sz].x;
-            const float xm = a.x_old[idx - x * sx + ((x + a.NXv - 1) % a.NXv) * sx].x;
-            const float xp = a.x_old[idx - x * sx + ((x + 1) % a.NXv) * sx].x;
-            const float c = xv.x;
-            gd += a.gamma * (sgn(c - ym) - sgn(yp - c) + sgn(c - zm) - sgn(zp - c) + sgn(c - xm) - sgn(xp - c));
+    const size_t ncol = (size_t)a.NZv * a.NYv, sx = ncol;
+    const size_t nblk = (ncol + 255) / 256;
+    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin, so workgroup b takes the (b / 8)-th block of the
+    // (b % 8)-th eighth of the columns: the z +- 1 rows a block needs are its XCD-mates' own rows
+    const size_t per_xcd = (nblk + 7) / 8;
+    const int xc0 = a.x0 + (int)(((long long)(a.x1 - a.x0) * blockIdx.y) / gridDim.y);
+    const int xc1 = a.x0 + (int)(((long long)(a.x1 - a.x0) * (blockIdx.y + 1)) / gridDim.y);
+    if (xc0 >= xc1) return;
+    for (size_t t = blockIdx.x; t < per_xcd * 8; t += gridDim.x) {
+        const size_t blk = (t & 7) * per_xcd + (t >> 3);
+        const size_t col = blk * 256 + threadIdx.x;
+        if (blk >= nblk || col >= ncol) continue;
+        const int y = col % a.NYv, z = col / a.NYv;
+        const size_t o_ym = col - y + (y + a.NYv - 1) % a.NYv, o_yp = col - y + (y + 1) % a.NYv;
+        const size_t o_zm = (size_t)((z + a.NZv - 1) % a.NZv) * a.NYv + y, o_zp = (size_t)((z + 1) % a.NZv) * a.NYv + y;
+        float xm = a.x_old[(size_t)((xc0 + a.NXv - 1) % a.NXv) * sx + col].x;
+        float2 xv = a.x_old[(size_t)xc0 * sx + col];
+        for (int x = xc0; x < xc1; ++x) {
+            const size_t plane = (size_t)x * sx, idx = plane + col;
+            const float2 nxt = a.x_old[(size_t)((x + 1) % a.NXv) * sx + col];       // x + 1: the next iteration's own voxel
+            float gd = a.g[idx].x * a.g_scale + a.alpha_d * sgn(xv.x);
+            float gb = a.g[idx].y * a.g_scale + a.alpha_b * sgn(xv.y);
+            if (a.gamma != 0.f) {
+                const float ym = a.x_old[plane + o_ym].x, yp = a.x_old[plane + o_yp].x;
+                const float zm = a.x_old[plane + o_zm].x, zp = a.x_old[plane + o_zp].x;
+                const float xp = nxt.x;
+                const float c = xv.x;
+                gd += a.gamma * (sgn(c - ym) - sgn(yp - c) + sgn(c - zm) - sgn(zp - c) + sgn(c - xm) - sgn(xp - c));
+            }
+            float2 m = a.m[idx], v = a.v[idx];
+            m.x = a.om_b1 * gd + a.b1 * m.x;
+            m.y = a.om_b1 * gb + a.b1 * m.y;
+            v.x = a.om_b2 * gd * gd + a.b2 * v.x;
+            v.y = a.om_b2 * gb * gb + a.b2 * v.y;
+            a.m[idx] = m;
+            a.v[idx] = v;
+            float nd = xv.x - a.lr * (m.x * a.inv_bc1) / (sqrtf(v.x * a.inv_bc2) + a.eps);
+            float nb = xv.y - a.lr * (m.y * a.inv_bc1) / (sqrtf(v.y * a.inv_bc2) + a.eps);
+            if (a.mask) { const float mk = a.mask[idx]; nd *= mk; nb *= mk; }
+            if (a.clip) { nd = fmaxf(nd, 0.f); nb = fmaxf(nb, 0.f); }
+            a.x_new[idx] = make_float2(nd, nb);
+            xm = xv.x;
+            xv = nxt;
         }
-        float2 m = a.m[idx], v = a.v[idx];
-        m.x = a.om_b1 * gd + a.b1 * m.x;
-        m.y = a.om_b1 * gb + a.b1 * m.y;
-        v.x = a.om_b2 * gd * gd + a.b2 * v.x;
-        v.y = a.om_b2 * gb * gb + a.b2 * v.y;
-        a.m[idx] = m;
-        a.v[idx] = v;
-        float nd = xv.x - a.lr * (m.x * a.inv_bc1) / (sqrtf(v.x * a.inv_bc2) + a.eps);
-        float nb = xv.y - a.lr * (m.y * a.inv_bc1) / (sqrtf(v.y * a.inv_bc2) + a.eps);
-        if (a.mask) { const float mk = a.mask[idx]; nd *= mk; nb *= mk; }
-        if (a.clip) { nd = fmaxf(nd, 0.f); nb = fmaxf(nb, 0.f); }
-        a.x_new[idx] = make_float2(nd, nb);
     }
 }
 
@@ -1460,6 +1477,8 @@ struct ConvArgs {
     float k;
     const ConvTaps* taps;   // device copy (bdof_set_conv): read through the scalar cache one pass at a time — by value in the
     int ks;                 // kernel arguments all 134 dwords are fetched at entry and live in spilled SGPRs (v_readlane per use)
+    const cf* pfield;       // nullable [NX][NY]: carrier FIELD plane replacing `carrier` (bdof_set_conv_probe_stack): forward the
+                            // plane of slice zmod = z + 1, backward that of slice z
 };
 
 // 1-D pass over a register window: thread owns R consecutive outputs and the R + 2H inputs they need, so every LDS
@@ -1643,10 +1662,11 @@ __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
                 const unsigned off = __umul24(x, a.NY) + y;
                 const bool in = srow[q] >= 0 && yg == yc;
                 const float2 mm = make_float2(in ? m1[q].x : 0.f, in ? m1[q].y : 0.f);
+                const cf car = a.pfield ? a.pfield[off] : a.carrier;      // L2-resident plane shared by all wavefields
                 if constexpr (!BWD) {
-                    out_b[off] = modulate_eps(acc, a.carrier, mm);          // phi_{z+1} = c_{z+1} psi_{z+1}  (eps part)
+                    out_b[off] = modulate_eps(acc, car, mm);                // phi_{z+1} = c_{z+1} psi_{z+1}  (eps part)
                 } else {
-                    const cf phi = cadd(tp[q], a.carrier);
+                    const cf phi = cadd(tp[q], car);
                     const cf tt = cmulc(acc, phi);                              // G(phi) conj(phi)
                     grot_b[off] = make_float2(a.k * tt.y, -a.k * tt.x);
                     out_b[off] = cmulc(acc, make_float2(1.f + mm.x, mm.y));     // G(psi_z) = conj(c_z) G(phi_z)
@@ -1665,6 +1685,7 @@ struct ConvInitArgs {
     ObjView obj;
     int B, NX, NY;
     cf carrier;          // a_0
+    const cf* pfield;    // nullable [NX][NY]: carrier field p_0 (then `probe` holds zeros)
 };
 __global__ __launch_bounds__(256) void k_conv_init(ConvInitArgs a) {
     const size_t n = (size_t)a.B * a.NX * a.NY;
@@ -1676,7 +1697,7 @@ __global__ __launch_bounds__(256) void k_conv_init(ConvInitArgs a) {
         const long long srow = obj_src_row(a.obj, b, x, 0, a.NX);
         const int yg = y + (a.obj.yoff ? a.obj.yoff[b] : 0);
         if (srow >= 0 && yg >= 0 && yg < a.obj.volNY) m1 = a.obj.vol[(size_t)srow * a.obj.volNY + yg];
-        a.out[idx] = modulate_eps(a.probe[(size_t)x * a.NY + y], a.carrier, m1);
+        a.out[idx] = modulate_eps(a.probe[(size_t)x * a.NY + y], a.pfield ? a.pfield[(size_t)x * a.NY + y] : a.carrier, m1);
     }
 }
 
@@ -1708,13 +1729,17 @@ struct ConvFinalArgs {
     int split;
     cf A;
     float absA, dref;
+    const cf* pfield;    // nullable [plane]: carrier FIELD p_S added to every wavefield (MODE 0 outputs of the full wave)
+    size_t plane;
 };
 template <int MODE>
 __global__ __launch_bounds__(256) void k_conv_final(ConvFinalArgs a) {
     const cf s = a.scal[0];
     double acc = 0.0, acc2 = 0.0;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < a.n; idx += (size_t)gridDim.x * blockDim.x) {
-        const cf q = cmul(cadd(a.psi_eps[idx], a.carrier_end), s);
+        cf full = cadd(a.psi_eps[idx], a.carrier_end);
+        if (a.pfield) full = cadd(full, a.pfield[idx % a.plane]);
+        const cf q = cmul(full, s);
         if constexpr (MODE == 1) {
             if (a.split) {
                 if (a.out) a.out[idx] = cadd(q, a.A);

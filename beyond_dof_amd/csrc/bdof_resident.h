@@ -613,29 +613,40 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
         // accumulators in the flow block of an `if (tid < N)` region, BEFORE exec was restored: waves with no lane in that
         // region never stored them and reloaded whatever an earlier kernel had left in that scratch slot (loss off by 5 % at
         // N = 128, depending on what ran before).  tools/check_spills.py scans the ISA of every kernel for that pattern.
+        // The loop is counted and the kind of detector / carrier is one wave-uniform switch: the earlier form (`for (e = tid;
+        // e < N * N; e += T)` with a `continue` per case) compiled, at N = 72 after the change above, into code whose sums were
+        // wrong for most waves — and right again with a store added to the loop body (a code-generation problem that moved
+        // with register allocation, like the spill; the structured form has nothing for it to act on).
         double acc = 0.0, acc2 = 0.0;
-        for (int e = tid; e < N * N; e += T) {
-            const int x = res_div<N>(e), y = e - x * N;
-            cf d = f[x * P + y];
-            if (a.meas_dev && a.meas && !far && !a.pdet) {
-                const size_t o = b * fsz + e;
-                if (a.out_wave) a.out_wave[o] = cadd(d, a.carrier_det);
-                f[x * P + y] = loss_seed_dev(d, a.carrier_det, sqrtf(a.carrier_det.x * a.carrier_det.x + a.carrier_det.y * a.carrier_det.y),
-                                             a.meas[o], a.seed_scale, acc, acc2, a.dref);
-                continue;
+        {
+            const int mode = !a.meas ? 0 : ((a.meas_dev && !far && !a.pdet) ? 1 : (a.pdet64 ? 2 : 3));
+            const float abs_car = sqrtf(a.carrier_det.x * a.carrier_det.x + a.carrier_det.y * a.carrier_det.y);
+            int t0 = tid;
+            asm volatile("" : "+v"(t0));
+#pragma nounroll
+            for (int i = 0; i < EPT; ++i) {
+                const int e = t0 + i * T;
+                if (EPT * T == N * N || e < N * N) {
+                    const int x = res_div<N>(e), y = e - x * N;
+                    const size_t o = b * fsz + (far ? y * N + x : e);
+                    cf d = f[x * P + y], seed;
+                    if (mode == 1) {               // plane-wave carrier, real-space detector, residual splitting (loss_seed_dev)
+                        seed = loss_seed_dev(d, a.carrier_det, abs_car, a.meas[o], a.seed_scale, acc, acc2, a.dref);
+                        d = cadd(d, a.carrier_det);
+                    } else if (mode == 2) {        // carrier field in float64: |d| - m in float64 (loss_seed_f64)
+                        cf dw;
+                        seed = loss_seed_f64(d, a.pdet64[e], a.meas[o], a.seed_scale, acc, acc2, dw);
+                        d = dw;
+                    } else {
+                        if (a.pdet) d = cadd(d, a.pdet[e]);
+                        else if (!far || e == 0) d = cadd(d, a.carrier_det);
+                        seed = d;
+                        if (mode == 3) seed = loss_seed(d, a.meas[o], a.seed_scale, acc, acc2);
+                    }
+                    if (a.out_wave) a.out_wave[o] = d;
+                    if (mode != 0) f[x * P + y] = seed;
+                }
             }
-            if (a.pdet64 && a.meas) {
-                const size_t o = b * fsz + (far ? y * N + x : e);
-                cf dw;
-                f[x * P + y] = loss_seed_f64(d, a.pdet64[e], a.meas[o], a.seed_scale, acc, acc2, dw);
-                if (a.out_wave) a.out_wave[o] = dw;
-                continue;
-            }
-            if (a.pdet) d = cadd(d, a.pdet[e]);
-            else if (!far || e == 0) d = cadd(d, a.carrier_det);
-            const size_t o = b * fsz + (far ? y * N + x : e);
-            if (a.out_wave) a.out_wave[o] = d;
-            if (a.meas) f[x * P + y] = loss_seed(d, a.meas[o], a.seed_scale, acc, acc2);
         }
         if (a.meas) {
             acc = wave_reduce_sum(acc);

@@ -151,6 +151,9 @@ class MultisliceEngine(object):
         mean = complex(probe.astype(np.complex128).mean())
         a0 = mean if np.abs(probe - mean).max() <= 0.25 * abs(mean) else 0j
         self.probe_stack = False
+        if getattr(self, '_conv_set', False) and hasattr(self, '_physics_args'):
+            if self._set_conv_probe_stack(probe, a0):
+                return
         use_stack = (a0 == 0 and hasattr(self, '_physics_args') and not os.environ.get('BDOF_NO_PROBE_STACK')
                      and not getattr(self, '_conv_set', False)              # the real-space propagator has its own carrier
                      and self.n_slice * self.nx * self.ny <= (1 << 32)      # 32 GiB of stack at most
@@ -172,6 +175,40 @@ class MultisliceEngine(object):
         eps = np.ascontiguousarray((probe.astype(np.complex128) - a0).T.astype(np.complex64))
         self.ctx.check(self.lib.bdof_set_probe(self.h, eps.ctypes.data, a0.real, a0.imag))
         self._set_meas_mode(a0)
+
+    def _set_conv_probe_stack(self, probe, a0):
+        """Real-space propagator with a probe that has no dominant constant part (a0 == 0, e.g. a ptychography probe): the
+        carrier FIELD of bdof_set_conv_probe_stack — the probe carried through empty space by the padded convolution itself,
+        in float64 on the host — so that only the scattered wave runs through the float32 convolutions and the residual
+        |d| - m is taken in float64.  Returns True if the stack was set (False: scalar carrier, stack removed)."""
+        lib, h = self.lib, self.h
+        small = (self.n_slice + 1) * self.nx * self.ny <= (1 << 28)
+        if a0 != 0 or not small or os.environ.get('BDOF_NO_PROBE_STACK'):
+            self.ctx.check(lib.bdof_set_conv_probe_stack(h, None, None, 0., 0., 0., 0.))
+            return False
+        energy_ev, psize_cm, free_prop_cm, variant, pi = self._physics_args
+        ky, kx, e = self._conv_kernel
+        planes = util.conv_probe_stack(probe.astype(np.complex128), ky, kx, e, self.n_slice)          # (S + 1, Y, X)
+        p_end = planes[-1]
+        if self.det_mode == _lib.DET_FAR:
+            det = np.fft.fft2(p_end)                                                                   # [ky][kx], un-shifted
+        elif self.det_mode == _lib.DET_NEAR:
+            voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
+            hd = np.fft.ifftshift(util.get_kernel(free_prop_cm * 1e7, 1240. / energy_ev, voxel_nm, (self.ny, self.nx), pi=pi))
+            det = np.fft.ifft2(np.fft.fft2(p_end) * hd).T                                              # [x][y]
+        else:
+            det = p_end.T
+        stack = np.ascontiguousarray(planes.transpose(0, 2, 1).astype(np.complex64))                   # [S + 1][x][y]
+        det = np.ascontiguousarray(det.astype(np.complex128))
+        zero = np.zeros((self.nx, self.ny), dtype=np.complex64)
+        if lib.bdof_probe_stack_supported(h) == 1:
+            self.ctx.check(lib.bdof_set_probe_stack(h, None, None))
+        self.ctx.check(lib.bdof_set_probe(h, zero.ctypes.data, 0.0, 0.0))
+        p0, ps = complex(planes[0][0, 0]), complex(p_end[0, 0])
+        self.ctx.check(lib.bdof_set_conv_probe_stack(h, stack.ctypes.data, det.ctypes.data, p0.real, p0.imag, ps.real, ps.imag))
+        self.probe_stack, self.probe_gain = False, 1.0
+        self._set_meas_mode(0j)
+        return True
 
     # ---- gradient w.r.t. the probe (probe_type='optimizable', tensorflow_recon/fullfield.py:311-327) -------------------
     def enable_probe_grad(self, on=True):
@@ -217,11 +254,14 @@ class MultisliceEngine(object):
         ky, kx, e = util.conv_kernel_separable(delta_nm, lmbda_nm, voxel_nm, (self.ny, self.nx), kernel_size)
         ksum = e * ky.sum() * kx.sum()
         self._conv_set = True
+        self._conv_kernel = (ky, kx, e)
         k = 2. * np.pi * delta_nm / lmbda_nm
         kyf = np.ascontiguousarray(ky.astype(np.complex64))
         kxf = np.ascontiguousarray(kx.astype(np.complex64))
         self.ctx.check(self.lib.bdof_set_conv(self.h, kyf.ctypes.data, kxf.ctypes.data, int(kernel_size), e.real, e.imag,
                                               ksum.real, ksum.imag, k))
+        if getattr(self, '_probe_args', None) is not None:
+            self.set_probe(*self._probe_args)      # the carrier (scalar or field) of the probe follows the propagator
 
     # ---- object --------------------------------------------------------------------------------
     def set_object_batch(self, grid_delta_batch, grid_beta_batch):

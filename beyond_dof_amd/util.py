@@ -109,6 +109,32 @@ def conv_kernel_separable(delta_nm, lmbda_nm, voxel_nm, grid_shape, kernel_size,
     return ky, kx, e
 
 
+def conv_probe_stack(probe, ky, kx, e, n_slice):
+    """The probe carried through EMPTY space by the real-space propagator's own step (cnn_propagator/propagation.py:79-104
+    without an object), in float64: p_0 = probe, p_{z+1} = K * pad(p_z, edge_z) ('valid' true convolution, K = e ky (x) kx),
+    edge_{z+1} = sum(K) edge_z, edge_0 = 1.  Returns the S + 1 planes (S + 1, Y, X) complex128 — the carrier field of
+    bdof_set_conv_probe_stack.  Two 1-D passes of shifted adds: cheap enough for a 512^2 x 512 stack."""
+    h = (len(ky) - 1) // 2
+    ksum = e * ky.sum() * kx.sum()
+    p = np.array(probe, dtype=np.complex128)
+    ny, nx = p.shape
+    planes = np.empty((n_slice + 1, ny, nx), dtype=np.complex128)
+    planes[0] = p
+    edge = 1.0 + 0j
+    for z in range(n_slice):
+        padded = np.pad(p, h, mode='constant', constant_values=edge)
+        t = np.zeros((ny, nx + 2 * h), dtype=np.complex128)
+        for a in range(2 * h + 1):                    # out[y] = sum_a ky[a] in[y + 2h - a]: a true convolution
+            t += ky[a] * padded[2 * h - a:2 * h - a + ny, :]
+        q = np.zeros((ny, nx), dtype=np.complex128)
+        for b in range(2 * h + 1):
+            q += kx[b] * t[:, 2 * h - b:2 * h - b + nx]
+        p = e * q
+        edge = edge * ksum
+        planes[z + 1] = p
+    return planes
+
+
 def rotation_lookup(array_size, n_theta):
     """Nearest-neighbour rotation source coordinates for every angle, as save_rotation_lookup builds
     them (cnn_propagator/util.py:294-332) but kept in memory: list of (X*Z, 2) int arrays.  Angles are

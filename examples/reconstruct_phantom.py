@@ -32,16 +32,15 @@ def phantom(n, rng):
     return d
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-    n_theta = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-    n_epochs = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-    lr = float(sys.argv[4]) if len(sys.argv) > 4 else 2e-8
-    fp = sys.argv[5] if len(sys.argv) > 5 else '1e-3'
-    fp = 'inf' if fp == 'inf' else float(fp)
+def run(n=128, n_theta=60, n_epochs=100, lr=2e-8, fp=1e-3, quiet=False):
+    """Simulate, write exchange/data, reconstruct, compare with the phantom: returns the figures main() prints
+    (tests/test_gpu_convergence.py asserts them)."""
+    import contextlib
+    import io
     mb = 10
     rng = np.random.default_rng(0)
     d = phantom(n, rng)
+    cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as td:
         os.chdir(td)
         s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=fp)
@@ -51,18 +50,33 @@ def main():
         os.makedirs('case')
         h5io.write_dataset('case/data.h5', 'exchange/data', prj.astype(np.complex64))
         t0 = time.time()
-        rd, rb = reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, n_epochs=n_epochs, learning_rate=lr,
-                                       minibatch_size=mb, energy_ev=5000, psize_cm=1e-7, free_prop_cm=fp, save_path='case',
-                                       output_folder='out', shrink_cycle=None, seed=3, alpha_d=1e-9, alpha_b=1e-10, gamma=0,
-                                       initial_guess=[np.zeros_like(d), np.zeros_like(d)])
+        with (contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext()):
+            rd, rb = reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, n_epochs=n_epochs, learning_rate=lr,
+                                           minibatch_size=mb, energy_ev=5000, psize_cm=1e-7, free_prop_cm=fp, save_path='case',
+                                           output_folder='out', shrink_cycle=None, seed=3, alpha_d=1e-9, alpha_b=1e-10, gamma=0,
+                                           initial_guess=[np.zeros_like(d), np.zeros_like(d)])
         dt = time.time() - t0
-    c = n // 2
+        os.chdir(cwd)
     inner = (slice(n // 4, -n // 4),) * 3
-    print('reconstruct_fullfield {}^3, {} angles, {} epochs: {:.1f} s'.format(n, n_theta, n_epochs, dt))
+    return {'n': n, 'n_theta': n_theta, 'n_epochs': n_epochs, 'seconds': dt,
+            'delta_corr': float(np.corrcoef(rd.ravel(), d.ravel())[0, 1]),
+            'delta_corr_inner': float(np.corrcoef(rd[inner].ravel(), d[inner].ravel())[0, 1]),
+            'delta_rel_l2': float(np.linalg.norm(rd - d) / np.linalg.norm(d)), 'delta_peak': float(rd.max()), 'phantom_peak': float(d.max()),
+            'beta_corr': float(np.corrcoef(rb.ravel(), 0.1 * d.ravel())[0, 1])}
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    n_theta = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    n_epochs = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+    lr = float(sys.argv[4]) if len(sys.argv) > 4 else 2e-8
+    fp = sys.argv[5] if len(sys.argv) > 5 else '1e-3'
+    fp = 'inf' if fp == 'inf' else float(fp)
+    r = run(n, n_theta, n_epochs, lr, fp)
+    print('reconstruct_fullfield {}^3, {} angles, {} epochs: {:.1f} s'.format(n, n_theta, n_epochs, r['seconds']))
     print('delta: correlation with the phantom {:.4f} (central half {:.4f}); relative L2 error {:.3f}; peak {:.3e} vs {:.3e}'.format(
-        np.corrcoef(rd.ravel(), d.ravel())[0, 1], np.corrcoef(rd[inner].ravel(), d[inner].ravel())[0, 1],
-        np.linalg.norm(rd - d) / np.linalg.norm(d), rd.max(), d.max()))
-    print('beta : correlation {:.4f}'.format(np.corrcoef(rb.ravel(), 0.1 * d.ravel())[0, 1]))
+        r['delta_corr'], r['delta_corr_inner'], r['delta_rel_l2'], r['delta_peak'], r['phantom_peak']))
+    print('beta : correlation {:.4f}'.format(r['beta_corr']))
 
 
 if __name__ == '__main__':

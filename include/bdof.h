@@ -187,6 +187,16 @@ int bdof_set_meas_mode(bdof_ctx* ctx, int mode);
  * bdof_forward / bdof_loss_grad (same arguments, gradient left in bdof_grot). */
 int bdof_set_conv(bdof_ctx* ctx, const float* ky, const float* kx, int ks, double e_re, double e_im, double ksum_re,
                   double ksum_im, double k);
+/* Carrier FIELD of the real-space propagator, for a probe with no dominant constant part (a localised ptychography probe —
+ * what cnn_propagator/ptychography.py:74-76 runs): stack = HOST [S + 1][NX][NY] complex64, the probe carried through EMPTY
+ * space by the same padded convolution, p_0 = probe, p_{z+1} = K * pad(p_z, edge_z), edge_{z+1} = sum(K) edge_z, edge_0 = 1
+ * (propagation.py:79-104 without an object), computed by the host in float64; det64 = HOST [NX][NY] complex128, the detector
+ * plane of p_S before the renormalisation (no detector: p_S; near field: one transfer-function step of it; far field: its
+ * un-shifted, un-normalised fft2 indexed [ky][kx]); p0 / pS: the corner pixels p_0[0,0], p_S[0,0] in float64 (the
+ * renormalisation s = probe[0,0] / psi_S[0,0,0], propagation.py:109-110, is formed against them).  The wave is then carried as
+ * psi_z = p_z + eps_z, eps zero-padded, and |d| - m is taken in float64 against s * det64.  Call bdof_set_probe with a zero
+ * array and a0 = 0 first, and again after every bdof_set_conv.  NULL, NULL removes the stack. */
+int bdof_set_conv_probe_stack(bdof_ctx* ctx, const float* stack, const double* det64, double p0_re, double p0_im, double pS_re, double pS_im);
 int bdof_forward_conv(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave);
 int bdof_loss_grad_conv(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, void* out_wave);
 void* bdof_grot(bdof_ctx* ctx);      /* device [B][S][NX][NY] pairs */

@@ -197,18 +197,23 @@ def test_cfg4_tiles_512_on_the_4096_field_vs_float64():
 
 
 def test_cfg4_tile_size_two_ranges_and_gradient_vs_oracle():
-    """The 512^2 / 64 plan on a field the float64 oracle can differentiate: 1024^2 (9 tiles), 80 slices of a (FY, FX, S) object
-    under the zone plate's aperture = two stitch ranges (64 + 16).  Forward against the whole-field oracle, loss and gradient
-    (bdof_adjoint_range at tile 512, stitch adjoints, overlap-add of the tiles' gradient rows) against the oracle's
-    hand-derived adjoint of the whole-field model, variant tf_all."""
+    """The 512^2 / 64 plan on a field the float64 references can differentiate: 1024^2 (9 tiles), 20 slices of a (FY, FX, S) object
+    under the zone plate's aperture in two stitch ranges (16 + 4).  Forward against the whole-field oracle; loss and gradient
+    (bdof_adjoint_range at tile 512, stitch adjoints, overlap-add of the tiles' gradient rows) against torch autograd of the
+    same tiled algorithm in float64 — the device's hand-derived tiled adjoint at cfg4's tile size — and against the oracle's
+    gradient of the WHOLE-FIELD model.  The latter differs by the tiling itself, not by round-off: the adjoint of the stitch
+    hands every tile a hard-edged piece of the (noise-driven, white) adjoint field, whose edge fringes wrap around the tile's
+    period — in float64 on the CPU 3.3e-3 / 1.7e-3 / 1.2e-3 of the gradient at halos of 16 / 32 / 48 pixels (128^2 tiles) while
+    the forward wave and the loss agree to 3e-6 / 2e-7 (tools/runs/r3 notes in DESIGN §5): the exact gradient of a loss that is
+    2e-7 from the whole field's is still 1e-3 from its gradient."""
     from beyond_dof_amd.tiling import TiledPropagator
-    n, S = 1024, 80
+    n, S, seg = 1024, 20, 16
     slab, probe = _cfg4_inputs(n, r_zp=128.0, half=160.0)
     rng = np.random.default_rng(4)
     delta = slab[:, :, None] * rng.uniform(0.5, 1.0, size=(1, 1, S))      # the plate, its strength varying from slice to slice
     beta = 0.1 * delta
-    tp = TiledPropagator((n, n), S, 5000., 1e-7, tile=512, halo=64, slices_per_exchange=64, variant='tf_all', with_grad=True)
-    assert tp.n_tiles == 9 and tp.segments() == [(0, 64), (64, 16)]
+    tp = TiledPropagator((n, n), S, 5000., 1e-7, tile=512, halo=64, slices_per_exchange=seg, variant='tf_all', with_grad=True)
+    assert tp.n_tiles == 9 and tp.segments() == [(0, 16), (16, 4)]
     tp.set_object(delta, beta)
     out = tp.forward(probe, np.zeros_like(probe))
     zero = np.zeros_like(probe)
@@ -217,7 +222,11 @@ def test_cfg4_tile_size_two_ranges_and_gradient_vs_oracle():
     assert rel(out, ref[0]) <= 1e-5, rel(out, ref[0])
     meas = (np.abs(ref[0]) * (1 + 0.02 * rng.normal(size=probe.shape))).astype(np.float32).astype(np.float64)
     loss, gd, gb = tp.loss_and_grad(probe, zero, meas)
+    rl, rgd, rgb, rfield = _torch_tiled_loss_grad(delta, beta, probe, meas, 512, 64, seg, tp.taper)
+    e = (rel(out, rfield), abs(loss - rl) / abs(rl), rel(gd, rgd), rel(gb, rgb))
+    print('tile 512 vs autograd of the tiled algorithm: wave', e[0], 'loss', e[1], 'g_delta', e[2], 'g_beta', e[3])
+    assert e[0] <= 2e-6 and e[1] <= 1e-5 and e[2] <= 2e-4 and e[3] <= 2e-4, e
     wl, wgd, wgb = orc.multislice_loss_and_grad(delta[None], beta[None], probe, zero, 5000., 1e-7, meas[None], None, 'tf_all')
-    e = (abs(loss - wl) / abs(wl), rel(gd, wgd[0]), rel(gb, wgb[0]))
-    print('tile 512 gradient vs the whole-field oracle: loss', e[0], 'g_delta', e[1], 'g_beta', e[2])
-    assert e[0] <= 1e-5 and e[1] <= 2e-4 and e[2] <= 2e-4, e
+    w = (abs(loss - wl) / abs(wl), rel(gd, wgd[0]), rel(gb, wgb[0]))
+    print('tile 512 vs the whole-field oracle: loss', w[0], 'g_delta', w[1], 'g_beta', w[2])
+    assert w[0] <= 1e-5 and w[1] <= 3e-3 and w[2] <= 3e-3, w
