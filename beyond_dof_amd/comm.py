@@ -501,6 +501,8 @@ def get_comm(backend=None):
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         backend = backend or comm_backend()
         return RcclComm() if backend == 'rccl' else TorchComm(backend)
+    if os.environ.get('BDOF_FORCE_COMM') and (backend or comm_backend()) == 'rccl':
+        return RcclComm(rank=0, size=1, local_rank=int(os.environ.get('LOCAL_RANK', '0')))      # one rank through RCCL (tests, profiles)
     return PseudoComm()
 
 

@@ -538,7 +538,7 @@ static int modulation_done(bdof_ctx* c, size_t n, int grid, bool mean) {
     std::complex<double> cb(0.0, 0.0);
     if (mean) {
         // cbar is needed by the HOST (it forms the carrier scalars in float64): one small read-back per object update
-        hipLaunchKernelGGL(k_sum_mean, dim3(1), dim3(64), 0, c->stream, c->cbar_dev, grid, 1.0 / (double)n, c->cbar_dev + grid);
+        hipLaunchKernelGGL(k_sum_mean, dim3(1), dim3(256), 0, c->stream, c->cbar_dev, grid, 1.0 / (double)n, c->cbar_dev + grid);
         double2 m;
         HIPC(c, hipMemcpyAsync(&m, c->cbar_dev + grid, sizeof(double2), hipMemcpyDeviceToHost, c->stream));
         HIPC(c, hipStreamSynchronize(c->stream));
@@ -1671,17 +1671,20 @@ static int conv_lds_bytes(const bdof_ctx* c) {
     return (TXH * (TYH | 1) + TXH * (BDOF_CONV_TY + 1)) * (int)sizeof(cf);
 }
 
-template <bool BWD, int H> static int launch_conv_h(bdof_ctx* c, ConvArgs& a, ProfScope& ps) {
+template <bool BWD, int H, bool PF> static int launch_conv_hp(bdof_ctx* c, ConvArgs& a, ProfScope& ps) {
     const int lds = conv_lds_bytes(c);
     static bool attr_set[BDOF_MAX_DEVICES] = {};
     if (!attr_set[c->device % BDOF_MAX_DEVICES]) {
-        HIPC(c, hipFuncSetAttribute((const void*)k_conv<BWD, H>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        HIPC(c, hipFuncSetAttribute((const void*)k_conv<BWD, H, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
         attr_set[c->device % BDOF_MAX_DEVICES] = true;
     }
     const int tiles = a.B * (a.NX / BDOF_CONV_TX) * (a.NY / BDOF_CONV_TY);
     const int grid = balanced_grid(c, tiles, 2);
-    BDOF_LAUNCH(ps, (k_conv<BWD, H>), dim3(grid), dim3(BDOF_CONV_THREADS), lds, c->stream, a);
+    BDOF_LAUNCH(ps, (k_conv<BWD, H, PF>), dim3(grid), dim3(BDOF_CONV_THREADS), lds, c->stream, a);
     return 0;
+}
+template <bool BWD, int H> static int launch_conv_h(bdof_ctx* c, ConvArgs& a, ProfScope& ps) {
+    return a.pfield ? launch_conv_hp<BWD, H, true>(c, a, ps) : launch_conv_hp<BWD, H, false>(c, a, ps);
 }
 
 template <bool BWD> static int launch_conv(bdof_ctx* c, ConvArgs& a) {
@@ -2025,12 +2028,11 @@ int bdof_adam_step_slab(bdof_ctx* c, const void* x_old, void* x_new, const void*
     AdamArgs a{(const float2*)x_old, (float2*)x_new, (const float2*)g, (float2*)m, (float2*)v, mask, NXv, NZv, NYv,
                g_scale, alpha_d, alpha_b, gamma, lr, (float)b1d, (float)b2d, eps, (float)(1.0 / bc1), (float)(1.0 / bc2),
                (float)(1.0 - b1d), (float)(1.0 - b2d), clip, x0, x0 + nx};
-    // one workgroup per block of 256 (z, y) columns, the x range cut into chunks until the launch has ~8 workgroups per CU
-    // (each chunk re-reads two neighbour planes: chunks stay >= 8 planes where the range allows)
-    const size_t nblk = ((size_t)NZv * NYv + 255) / 256;
-    int gx = (int)std::min<size_t>((nblk + 7) / 8 * 8, (size_t)c->ncu * 16);
-    int gy = (int)std::min<size_t>(std::max<size_t>(1, ((size_t)c->ncu * 8 + gx - 1) / gx), std::max(1, nx / 8));
-    hipLaunchKernelGGL(k_adam, dim3(gx, gy), dim3(256), 0, c->stream, a);
+    const size_t n = (size_t)nx * NZv * NYv;
+    size_t need = (n + 255) / 256;
+    int grid = need < (size_t)c->ncu * 16 ? (int)need : c->ncu * 16;
+    grid = (grid + 7) / 8 * 8;                       // k_adam deals the range to the 8 XCDs by blockIdx % 8
+    hipLaunchKernelGGL(k_adam, dim3(grid), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;
 }

@@ -168,12 +168,20 @@ __global__ __launch_bounds__(256) void k_modulation_table(const float2* __restri
         if (threadIdx.x == 0) partial[blockIdx.x] = make_double2(w[0][0] + w[0][1] + w[0][2] + w[0][3], w[1][0] + w[1][1] + w[1][2] + w[1][3]);
     }
 }
-__global__ void k_sum_mean(const double2* partial, int n, double inv_count, double2* out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double sx = 0.0, sy = 0.0;
-        for (int j = 0; j < n; ++j) { sx += partial[j].x; sy += partial[j].y; }
-        out[0] = make_double2(sx * inv_count, sy * inv_count);
+// 256 threads, fixed order (thread t sums partial[t], partial[t + 256], ...; then a fixed tree): deterministic.  (One thread
+// summing the 4096 partials of a 512^3 table took 0.40 ms per Adam step — as long as the table pass itself.)
+__global__ __launch_bounds__(256) void k_sum_mean(const double2* partial, int n, double inv_count, double2* out) {
+    __shared__ double sx[256], sy[256];
+    double ax = 0.0, ay = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) { ax += partial[j].x; ay += partial[j].y; }
+    sx[threadIdx.x] = ax;
+    sy[threadIdx.x] = ay;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { sx[threadIdx.x] += sx[threadIdx.x + w]; sy[threadIdx.x] += sy[threadIdx.x + w]; }
+        __syncthreads();
     }
+    if (threadIdx.x == 0) out[0] = make_double2(sx[0] * inv_count, sy[0] * inv_count);
 }
 
 // Loads are unconditional (clamped address) and zeroed afterwards: a branch around each load makes hipcc wait
@@ -865,57 +873,51 @@ struct AdamArgs {
 
 __device__ __forceinline__ float sgn(float v) { return (v > 0.f) - (v < 0.f); }
 
-// One thread owns a (z, y) column and walks it along x with the three x-neighbours of the TV stencil in registers (the volume is
-// [X][Z][Y]: x is the slowest axis, its neighbours are NZ*NY*8 B away — 2 MB at 512^3 — and the element-per-thread form of
-// rounds 1-2 fetched them from HBM again: 10.2 GB of traffic per 512^3 step against 7.5 GB algorithmic).  Every plane of x_old is
-// now read once per column plus once per z-neighbour row, and those rows belong to the same XCD's workgroups (blockIdx -> column
-// block mapping below), so they hit in its L2.  blockIdx.y splits the x range of the launch into chunks (two extra plane reads
-// per chunk) so that small volumes and thin slabs still fill the chip.  Same arithmetic in the same order as before: bit-identical.
+// (Round 3 measured the alternative the round-2 review suggested — one thread per (z, y) column walking x with the x-neighbours
+// of the TV stencil in registers: L2 <-> fabric traffic of a 512^3 step 10.2 -> 8.7 GB as intended, kernel time 1.58 -> 1.97 ms:
+// every workgroup then reads 2-KB pieces 2 MB apart, and what the stencil's re-fetches cost in bytes the linear walk below wins
+// back in DRAM locality.  Kept: this element-per-thread form.)
 __global__ __launch_bounds__(256) void k_adam(AdamArgs a) {
-    const size_t ncol = (size_t)a.NZv * a.NYv, sx = ncol;
-    const size_t nblk = (ncol + 255) / 256;
-    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin, so workgroup b takes the (b / 8)-th block of the
-    // (b % 8)-th eighth of the columns: the z +- 1 rows a block needs are its XCD-mates' own rows
-    const size_t per_xcd = (nblk + 7) / 8;
-    const int xc0 = a.x0 + (int)(((long long)(a.x1 - a.x0) * blockIdx.y) / gridDim.y);
-    const int xc1 = a.x0 + (int)(((long long)(a.x1 - a.x0) * (blockIdx.y + 1)) / gridDim.y);
-    if (xc0 >= xc1) return;
-    for (size_t t = blockIdx.x; t < per_xcd * 8; t += gridDim.x) {
-        const size_t blk = (t & 7) * per_xcd + (t >> 3);
-        const size_t col = blk * 256 + threadIdx.x;
-        if (blk >= nblk || col >= ncol) continue;
-        const int y = col % a.NYv, z = col / a.NYv;
-        const size_t o_ym = col - y + (y + a.NYv - 1) % a.NYv, o_yp = col - y + (y + 1) % a.NYv;
-        const size_t o_zm = (size_t)((z + a.NZv - 1) % a.NZv) * a.NYv + y, o_zp = (size_t)((z + 1) % a.NZv) * a.NYv + y;
-        float xm = a.x_old[(size_t)((xc0 + a.NXv - 1) % a.NXv) * sx + col].x;
-        float2 xv = a.x_old[(size_t)xc0 * sx + col];
-        for (int x = xc0; x < xc1; ++x) {
-            const size_t plane = (size_t)x * sx, idx = plane + col;
-            const float2 nxt = a.x_old[(size_t)((x + 1) % a.NXv) * sx + col];       // x + 1: the next iteration's own voxel
-            float gd = a.g[idx].x * a.g_scale + a.alpha_d * sgn(xv.x);
-            float gb = a.g[idx].y * a.g_scale + a.alpha_b * sgn(xv.y);
-            if (a.gamma != 0.f) {
-                const float ym = a.x_old[plane + o_ym].x, yp = a.x_old[plane + o_yp].x;
-                const float zm = a.x_old[plane + o_zm].x, zp = a.x_old[plane + o_zp].x;
-                const float xp = nxt.x;
-                const float c = xv.x;
-                gd += a.gamma * (sgn(c - ym) - sgn(yp - c) + sgn(c - zm) - sgn(zp - c) + sgn(c - xm) - sgn(xp - c));
-            }
-            float2 m = a.m[idx], v = a.v[idx];
-            m.x = a.om_b1 * gd + a.b1 * m.x;
-            m.y = a.om_b1 * gb + a.b1 * m.y;
-            v.x = a.om_b2 * gd * gd + a.b2 * v.x;
-            v.y = a.om_b2 * gb * gb + a.b2 * v.y;
-            a.m[idx] = m;
-            a.v[idx] = v;
-            float nd = xv.x - a.lr * (m.x * a.inv_bc1) / (sqrtf(v.x * a.inv_bc2) + a.eps);
-            float nb = xv.y - a.lr * (m.y * a.inv_bc1) / (sqrtf(v.y * a.inv_bc2) + a.eps);
-            if (a.mask) { const float mk = a.mask[idx]; nd *= mk; nb *= mk; }
-            if (a.clip) { nd = fmaxf(nd, 0.f); nb = fmaxf(nb, 0.f); }
-            a.x_new[idx] = make_float2(nd, nb);
-            xm = xv.x;
-            xv = nxt;
+    const size_t slab = (size_t)a.NZv * a.NYv;
+    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin, so workgroup b works in the (b % 8)-th eighth of the
+    // range and walks it linearly with its XCD's other workgroups — the z+-1 / x+-1 neighbours of the TV stencil (4 KB and
+    // NZ*NY*8 B away) are then lines the same XCD's L2 has just seen, instead of another XCD's.
+    const size_t first = (size_t)a.x0 * slab, total = (size_t)(a.x1 - a.x0) * slab;
+    const size_t per_xcd = (total + 7) / 8;
+    const size_t lane0 = (size_t)(blockIdx.x >> 3) * blockDim.x + threadIdx.x, stride = (size_t)(gridDim.x >> 3) * blockDim.x;
+    const size_t c0 = (size_t)(blockIdx.x & 7) * per_xcd, c1 = c0 + per_xcd < total ? c0 + per_xcd : total;
+    for (size_t loc = c0 + lane0; loc < c1; loc += stride) {
+        const size_t idx = first + loc;
+        const int y = idx % a.NYv;
+        const size_t r = idx / a.NYv;
+        const int z = r % a.NZv;
+        const int x = r / a.NZv;
+        const float2 xv = a.x_old[idx];
+        float gd = a.g[idx].x * a.g_scale + a.alpha_d * sgn(xv.x);
+        float gb = a.g[idx].y * a.g_scale + a.alpha_b * sgn(xv.y);
+        if (a.gamma != 0.f) {
+            const size_t sy = 1, sz = a.NYv, sx = (size_t)a.NZv * a.NYv;
+            const float ym = a.x_old[idx - y * sy + ((y + a.NYv - 1) % a.NYv) * sy].x;
+            const float yp = a.x_old[idx - y * sy + ((y + 1) % a.NYv) * sy].x;
+            const float zm = a.x_old[idx - z * sz + ((z + a.NZv - 1) % a.NZv) * sz].x;
+            const float zp = a.x_old[idx - z * sz + ((z + 1) % a.NZv) * sz].x;
+            const float xm = a.x_old[idx - x * sx + ((x + a.NXv - 1) % a.NXv) * sx].x;
+            const float xp = a.x_old[idx - x * sx + ((x + 1) % a.NXv) * sx].x;
+            const float c = xv.x;
+            gd += a.gamma * (sgn(c - ym) - sgn(yp - c) + sgn(c - zm) - sgn(zp - c) + sgn(c - xm) - sgn(xp - c));
         }
+        float2 m = a.m[idx], v = a.v[idx];
+        m.x = a.om_b1 * gd + a.b1 * m.x;
+        m.y = a.om_b1 * gb + a.b1 * m.y;
+        v.x = a.om_b2 * gd * gd + a.b2 * v.x;
+        v.y = a.om_b2 * gb * gb + a.b2 * v.y;
+        a.m[idx] = m;
+        a.v[idx] = v;
+        float nd = xv.x - a.lr * (m.x * a.inv_bc1) / (sqrtf(v.x * a.inv_bc2) + a.eps);
+        float nb = xv.y - a.lr * (m.y * a.inv_bc1) / (sqrtf(v.y * a.inv_bc2) + a.eps);
+        if (a.mask) { const float mk = a.mask[idx]; nd *= mk; nb *= mk; }
+        if (a.clip) { nd = fmaxf(nd, 0.f); nb = fmaxf(nb, 0.f); }
+        a.x_new[idx] = make_float2(nd, nb);
     }
 }
 
@@ -1513,7 +1515,9 @@ __device__ __forceinline__ void conv_sync() { asm volatile("s_waitcnt lgkmcnt(0)
 
 // H = (ks - 1) / 2 as a template parameter (2, 4, 8, 16 instantiated; H = 0 selects the generic runtime-ks loops)
 #define BDOF_CONV_THREADS 512
-template <bool BWD, int H>
+// PF: the carrier is a FIELD plane (a.pfield) instead of the scalar a.carrier — an instance of its own, so that the scalar
+// instances keep the register allocation they were tuned with (as a run-time select the extra pointer cost 10 us per launch)
+template <bool BWD, int H, bool PF = false>
 __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
     // R outputs per thread in the y pass (384 windows per tile), R2 in the x pass (512 windows: every thread busy)
     constexpr int TX = BDOF_CONV_TX, TY = BDOF_CONV_TY, R = 8, R2 = 4;
@@ -1662,7 +1666,8 @@ __global__ __launch_bounds__(BDOF_CONV_THREADS, 4) void k_conv(ConvArgs a) {
                 const unsigned off = __umul24(x, a.NY) + y;
                 const bool in = srow[q] >= 0 && yg == yc;
                 const float2 mm = make_float2(in ? m1[q].x : 0.f, in ? m1[q].y : 0.f);
-                const cf car = a.pfield ? a.pfield[off] : a.carrier;      // L2-resident plane shared by all wavefields
+                cf car = a.carrier;
+                if constexpr (PF) car = a.pfield[off];                    // L2-resident plane shared by all wavefields
                 if constexpr (!BWD) {
                     out_b[off] = modulate_eps(acc, car, mm);                // phi_{z+1} = c_{z+1} psi_{z+1}  (eps part)
                 } else {

@@ -96,6 +96,8 @@ if n_or > 0:
         w = w * cmod
         if z < S2 - 1:
             w = sfft.ifft2(sfft.fft2(w, workers=-1) * h, workers=-1)
+        if z % 64 == 63:
+            print('  float64 host propagation: slice %d of %d, %.0f s' % (z + 1, S2, time.perf_counter() - t0), flush=True)
     print('float64 whole field, %d slices on the host: %.0f s' % (S2, time.perf_counter() - t0))
     eng = MultisliceEngine(n, n, S2, 1, with_grad=False)
     eng.set_physics(5000., 1e-7, None)
