@@ -46,3 +46,14 @@ def data_from_phantom(orc, shape, n_theta, noise=0.0):
     if noise:
         out = out * (1 + noise * np.random.default_rng(18).normal(size=out.shape))
     return out.astype(np.complex64)
+
+
+def g20_directions(shape, n_dir=6):
+    """The directions of golden vector G20 (shared by generator and tests): unit-less (Y, X, Z) fields, four of random signs
+    (seeded) and two smooth blobs; applied as delta += t * 1e-9 * v, beta += t * 1e-10 * v."""
+    rng = np.random.default_rng(20)
+    y, x, z = np.mgrid[:shape[0], :shape[1], :shape[2]].astype(np.float64)
+    out = [np.sign(rng.normal(size=shape)) for _ in range(n_dir - 2)]
+    for cy, cx, cz, r in ((0.45, 0.55, 0.5, 0.12), (0.6, 0.4, 0.45, 0.2)):
+        out.append(np.exp(-((y - cy * shape[0]) ** 2 + (x - cx * shape[1]) ** 2 + (z - cz * shape[2]) ** 2) / (2 * (r * shape[0]) ** 2)))
+    return out

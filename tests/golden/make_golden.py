@@ -16,6 +16,8 @@ Run only in the build container (needs /root/reference, which never travels):
     python tests/golden/make_golden.py --g17      # G17 (reconstruct_ptychography's loop around np_funcs' FFT forward model)
     python tests/golden/make_golden.py --g18      # G18 (G15 at BASELINE config 2's size, 256^3; ~2 min)
     python tests/golden/make_golden.py --g19      # G19 (G18 with 2 % amplitude noise on the data, as measured data have)
+    python tests/golden/make_golden.py --g21 fft; python tests/golden/make_golden.py --g21 conv      # G21 (G20 for ptychography)
+    python tests/golden/make_golden.py --g20      # G20 (directional derivatives of the reference's calculate_loss at 64^3, both forward models)
 
 The reference modules are imported unmodified; only third-party imports that
 the hot path never touches (dxchange, h5py, tensorflow, matplotlib backends) are
@@ -690,8 +692,14 @@ def main_g13():
     print('wrote g13')
 
 
-def main_g14(fft=False):
-    """G14: reconstruct_ptychography with a 64 x 64 gaussian probe on a (64, 64, 64) object, 4 positions x 2 angles, minibatches
+class _StopAfterFirstGradient(Exception):
+    pass
+
+
+def main_g14(fft=False, directional=None):
+    """directional: a dict -> G21 mode (see main_g21): the gradient stand-in evaluates central differences of the reference's
+    calculate_loss along g13_inputs.g20_directions at the first minibatch, fills the dict and stops the loop; nothing is written.
+    G14: reconstruct_ptychography with a 64 x 64 gaussian probe on a (64, 64, 64) object, 4 positions x 2 angles, minibatches
     of 2, two epochs; gradient by the oracle's analytic adjoint (as G13).  Volumes stored on every second voxel, float32.
     fft=True is G17: the name multislice_propagate_cnn that ptychography.py calls is bound to np_funcs' transfer-function
     forward model (as G15 does for full field), with the drivers' kind of probe (sigma 10: it has decayed at the window's
@@ -714,7 +722,36 @@ def main_g14(fft=False):
             return gd, gb
         return g
 
-    autograd.grad = oracle_grad
+    def fd_directional(fn, argnums):
+        assert list(argnums) == [0, 1]
+        sys.path.insert(0, HERE)
+        import g13_inputs as gi
+
+        def g(obj_delta, obj_beta, this_i_theta, this_pos_batch, this_prj_batch):
+            d0, b0 = np.array(obj_delta, dtype=np.float64), np.array(obj_beta, dtype=np.float64)
+            out = []
+            with contextlib.redirect_stdout(io.StringIO()):
+                base = float(fn(d0, b0, this_i_theta, this_pos_batch, this_prj_batch))
+                for v in gi.g20_directions(d0.shape):
+                    for which, h in ((0, 1e-10), (1, 3e-11)):
+                        # steps: |psi| of the far-field loss has a kink at every dark bin, so the central difference is off by a term
+                        # LINEAR in h (3e-5 of the derivative at 1e-9, 1.5e-6 at 1e-10), and round-off takes over below (1.5e-5 at
+                        # 1e-11): 1e-10 is the best this loss gives — the test's bound is 5e-6
+                        vals = []
+                        for sgn in (+1.0, -1.0):
+                            d, b = d0.copy(), b0.copy()
+                            if which == 0:
+                                d += sgn * h * v
+                            else:
+                                b += sgn * h * v
+                            vals.append(float(fn(d, b, this_i_theta, this_pos_batch, this_prj_batch)))
+                        out.append((vals[0] - vals[1]) / (2 * h))
+            directional.update(loss=base, dd=np.array(out).reshape(-1, 2), i_theta=int(this_i_theta), pos_batch=np.array(this_pos_batch),
+                               delta_in=d0, beta_in=b0)
+            raise _StopAfterFirstGradient()
+        return g
+
+    autograd.grad = oracle_grad if directional is None else fd_directional
 
     class _Comm(object):
         def Get_size(self):
@@ -805,6 +842,20 @@ def main_g14(fft=False):
             prj = (prj * (1 + 0.02 * rng.normal(size=prj.shape))).astype('complex64')
             store['prj'] = prj
             g14['prj'] = prj
+            if directional is not None:
+                # G21: the data are those of the committed G14 / G17 fixture (the noise above is seeded, the check is cheap)
+                stored = np.load(os.path.join(HERE, 'g17_reconstruct_ptychography_fft_64.npz' if fft else 'g14_reconstruct_ptychography_64.npz'))['prj']
+                assert np.array_equal(stored, prj)
+                try:
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        ref_pt.reconstruct_ptychography('data.h5', [tuple(p) for p in pos], psz, obj_size, theta_st=0, theta_end=2 * np.pi, n_epochs=1,
+                                                        learning_rate=2e-7, minibatch_size=mb, energy_ev=5000, psize_cm=1e-7, save_path='.',
+                                                        output_folder='out', initial_guess=[init_d.copy(), init_b.copy()], probe_type='gaussian',
+                                                        dynamic_dropping=False, **kw)
+                except _StopAfterFirstGradient:
+                    pass
+                os.chdir(cwd)
+                return
             with contextlib.redirect_stdout(io.StringIO()):
                 ref_pt.reconstruct_ptychography('data.h5', [tuple(p) for p in pos], psz, obj_size, theta_st=0, theta_end=2 * np.pi, n_epochs=2,
                                                 learning_rate=2e-7, minibatch_size=mb, energy_ev=5000, psize_cm=1e-7, save_path='.',
@@ -928,6 +979,136 @@ def main_g15(n=64, noise=0.0):
     name = 'g15_reconstruct_fullfield_fft_64.npz' if n == 64 else ('g19_reconstruct_fullfield_fft_256_noisy.npz' if noise else 'g18_reconstruct_fullfield_fft_256.npz')
     np.savez_compressed(os.path.join(HERE, name), **g15)
     print('wrote', name)
+
+
+def main_g20():
+    """G20: the GRADIENT at a size the GPU kernels take, from the reference alone.  reconstruct_fullfield is started at (64, 64, 64)
+    exactly as for G13 (real-space propagator, what fullfield.py calls) and G15 (np_funcs' FFT forward bound to the name it calls);
+    the stand-in for autograd.grad receives the reference's own calculate_loss closure at the first minibatch, evaluates central
+    differences of it along six directions (float64; 24 evaluations of the reference's loss per forward model) and stops the
+    loop.  No oracle code is involved in the stored numbers: they pin the oracle's analytic gradient (CPU test) and the device
+    gradient (GPU test) at this size, which G13-G19 — reference loop + oracle gradient — do not."""
+    import contextlib
+    import io
+    import tempfile
+    autograd = _setup_conv_reference()
+    ref_np = sys.modules.get('np_funcs')
+    sys.path.insert(0, HERE)
+    import g13_inputs
+    ny = nx = 64
+    n_theta, mb = 4, 2
+    dirs = g13_inputs.g20_directions((ny, nx, nx))
+    got = {}
+
+    class _Stop(Exception):
+        pass
+
+    def fd_directional(fn, argnums):
+        assert list(argnums) == [0, 1]
+
+        def g(obj_delta, obj_beta, this_ind_batch, this_prj_batch):
+            d0, b0 = np.array(obj_delta, dtype=np.float64), np.array(obj_beta, dtype=np.float64)
+            out = []
+            with contextlib.redirect_stdout(io.StringIO()):
+                base = float(fn(d0, b0, this_ind_batch, this_prj_batch))
+                for v in dirs:
+                    for which, h in ((0, 1e-9), (1, 1e-10)):
+                        vals = []
+                        for sgn in (+1.0, -1.0):
+                            d, b = d0.copy(), b0.copy()
+                            if which == 0:
+                                d += sgn * h * v
+                            else:
+                                b += sgn * h * v
+                            vals.append(float(fn(d, b, this_ind_batch, this_prj_batch)))
+                        out.append((vals[0] - vals[1]) / (2 * h))
+            got['loss'] = base
+            got['dd'] = np.array(out).reshape(len(dirs), 2)          # [direction][delta, beta]: dL/dt along t * v
+            got['ind'] = np.array(this_ind_batch)
+            got['delta_in'], got['beta_in'] = d0, b0
+            raise _Stop()
+        return g
+
+    autograd.grad = fd_directional
+    import propagation as ref_prop
+    ref_prop.trange = range
+    import fullfield as ref_ff
+    ref_ff.trange = range
+    real_conv = ref_ff.multislice_propagate_cnn
+
+    def fft_forward(grid_delta, grid_beta, probe_real, probe_imag, energy_ev, psize_cm, kernel_size=17, free_prop_cm=None, debug=False):
+        return ref_np.multislice_propagate_batch_numpy(grid_delta, grid_beta, probe_real, probe_imag, energy_ev, psize_cm[0],
+                                                       free_prop_cm=free_prop_cm, obj_batch_shape=grid_delta.shape)[0]
+
+    mask = g13_inputs.mask((ny, nx, nx))
+    init_d, init_b = g13_inputs.initial_guess((ny, nx, nx))
+    store = {}
+
+    class _Dataset(object):
+        def __init__(self, arr):
+            self.arr = arr
+
+        def __getitem__(self, key):
+            return self.arr[key]
+
+    class _File(object):
+        def __init__(self, *a, **k):
+            pass
+
+        def __getitem__(self, key):
+            return _Dataset(store['prj'])
+
+    ref_ff.h5py.File = _File
+    dx = sys.modules['dxchange']
+    dx.read_tiff_stack = lambda fname, ind, digit=5: np.array(mask)
+    dx.read_tiff = lambda fname: np.array(mask)
+    dx.write_tiff = lambda *a, **k: None
+    dx.write_tiff_stack = lambda *a, **k: None
+    g20 = {}
+    cwd = os.getcwd()
+    for model, fixture in (('fft', 'g15_reconstruct_fullfield_fft_64.npz'), ('conv', 'g13_reconstruct_fullfield_64.npz')):
+        ref_ff.multislice_propagate_cnn = fft_forward if model == 'fft' else real_conv
+        store['prj'] = np.load(os.path.join(HERE, fixture))['prj']       # the data of G15 / G13 (outputs of the reference's forward models)
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                ref_ff.save_rotation_lookup([ny, nx, nx], n_theta)
+                np.random.seed(5)
+                try:
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        ref_ff.reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, n_epochs=1, learning_rate=1e-7, minibatch_size=mb,
+                                                     energy_ev=5000, psize_cm=1e-7, free_prop_cm=1e-4, save_path='.', output_folder='out',
+                                                     initial_guess=[init_d.copy(), init_b.copy()], shrink_cycle=None, kernel_size=17,
+                                                     alpha_d=0., alpha_b=0., gamma=0.)
+                except _Stop:
+                    pass
+            finally:
+                os.chdir(cwd)
+        assert np.array_equal(got['delta_in'], init_d * mask) and np.array_equal(got['beta_in'], init_b * mask)
+        g20[model + '_loss'] = np.array(got['loss'])
+        g20[model + '_dd'] = got['dd']
+        g20[model + '_ind'] = got['ind']
+        print(model, 'loss', got['loss'], 'batch', got['ind'], 'dL/dt:', got['dd'].ravel())
+    np.savez_compressed(os.path.join(HERE, 'g20_directional_derivatives_64.npz'), **g20)
+    print('wrote g20')
+
+
+def main_g21():
+    """G21: G20 for ptychography — central differences of the reference's own calculate_loss (cnn_propagator/ptychography.py:30-81:
+    rotation, zero padding, window cut, forward model, far-field loss) along the six directions, at the first minibatch of the
+    G17 run (np_funcs' FFT forward bound in, sigma-10 probe) and of the G14 run (the real-space propagator it literally calls,
+    sigma-40 probe).  Each in a process of its own state: run as two invocations (--g21 fft | --g21 conv), merged on the second."""
+    which = sys.argv[sys.argv.index('--g21') + 1]
+    out = {}
+    main_g14(fft=which == 'fft', directional=out)
+    path = os.path.join(HERE, 'g21_ptycho_directional_derivatives_64.npz')
+    g21 = dict(np.load(path)) if os.path.exists(path) else {}
+    g21[which + '_loss'] = np.array(out['loss'])
+    g21[which + '_dd'] = out['dd']
+    g21[which + '_i_theta'] = np.array(out['i_theta'])
+    g21[which + '_pos_batch'] = out['pos_batch']
+    np.savez_compressed(path, **{k: g21[k] for k in sorted(g21)})
+    print(which, 'loss', out['loss'], 'theta', out['i_theta'], 'positions', out['pos_batch'].tolist(), 'dL/dt', out['dd'].ravel())
 
 
 def main_g16():
@@ -1059,5 +1240,9 @@ if __name__ == '__main__':
         main_g15(n=256, noise=0.02)
     elif '--g16' in sys.argv:
         main_g16()
+    elif '--g20' in sys.argv:
+        main_g20()
+    elif '--g21' in sys.argv:
+        main_g21()
     else:
         main()

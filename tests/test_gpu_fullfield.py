@@ -312,3 +312,35 @@ def test_reconstruct_fullfield_vs_the_reference_loop_at_cfg2_size(tmp_path, monk
     # (2 % noise) delta 7.3e-6, beta 2.1e-5 — both inside the north star's 1e-5 (round 2's default, forward transforms with
     # plain float32 tables: 1.17e-5 / 6.7e-6; -DBDOF_FAST_ADJOINT: 2.1e-5 / 1.68e-5)
     assert stats[0] <= 0.05 and stats[1] <= 1e-5 and stats[3] <= 1e-4, stats
+
+
+@pytest.mark.parametrize('model', ['fft', 'conv'])
+def test_device_gradient_vs_directional_derivatives_of_the_reference_loss(model):
+    """Golden vector G20: central differences of the REFERENCE's own calculate_loss (cnn_propagator/fullfield.py:93-121 executed at
+    (64, 64, 64), first minibatch of the G15 / G13 runs; tests/golden/make_golden.py --g20) along six directions — numbers no
+    oracle code produced.  The device's volume gradient (rotation gather, multislice forward, loss, adjoint sweep, rotation
+    adjoint), projected on the same directions, for the transfer-function propagator and for the real-space one."""
+    import sys
+    from beyond_dof_amd.solver import FullfieldSolver
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, gdir)
+    import g13_inputs
+    g = np.load(os.path.join(gdir, 'g20_directional_derivatives_64.npz'))
+    shape = (64, 64, 64)
+    mask = g13_inputs.mask(shape)
+    init_d, init_b = g13_inputs.initial_guess(shape)
+    d, b = init_d * mask, init_b * mask
+    prj = np.load(os.path.join(gdir, 'g15_reconstruct_fullfield_fft_64.npz' if model == 'fft' else 'g13_reconstruct_fullfield_64.npz'))['prj']
+    ind = g[model + '_ind']
+    s = FullfieldSolver(64, 64, 64, 4, len(ind), 5000., 1e-7, free_prop_cm=1e-4, propagator=model, kernel_size=17)
+    s.set_measurements(np.abs(prj))
+    s.set_volume(d, b)
+    loss = s.loss_and_grad(ind)
+    gd, gb = s.gradient_to_host()
+    assert abs(loss - float(g[model + '_loss'])) <= 1e-5 * abs(loss)
+    dirs = g13_inputs.g20_directions(shape)
+    got = np.array([[np.sum(gd.astype(np.float64) * v), np.sum(gb.astype(np.float64) * v)] for v in dirs])
+    ref = g[model + '_dd']
+    err = np.abs(got - ref) / np.abs(ref)
+    print('G20', model, 'loss', abs(loss - float(g[model + '_loss'])) / abs(loss), 'directional derivatives rel err', err.ravel())
+    assert np.max(err) <= 5e-5, (got, ref)

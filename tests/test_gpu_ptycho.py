@@ -247,3 +247,36 @@ def test_cfg5_solver_step_at_full_shape():
     assert not np.any(moved & ~lit)                                                      # nothing outside the windows moved
     assert np.mean(moved[lit]) > 0.99 and np.all(d1 >= 0) and np.all(b1 >= 0)
     assert np.abs(d1 - d0).max() <= 1.0001e-7                                             # Adam's first step: at most lr
+
+
+@pytest.mark.parametrize('model,adjoint64', [('fft', False), ('fft', True), ('conv', False)])
+def test_device_gradient_vs_directional_derivatives_of_the_reference_loss(model, adjoint64):
+    """Golden vector G21: central differences of the REFERENCE's own calculate_loss (cnn_propagator/ptychography.py:30-81 executed
+    at (64, 64, 64), first minibatch of the G17 / G14 runs; tests/golden/make_golden.py --g21) along six directions — numbers no
+    oracle code produced.  The device's volume gradient (rotation gather, zero-padded window cut, multislice forward, far-field
+    loss, adjoint sweep, window overlap-add, rotation adjoint) projected on the same directions."""
+    import sys
+    from beyond_dof_amd.solver import PtychoSolver
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, gdir)
+    import g13_inputs
+    g = np.load(os.path.join(gdir, 'g21_ptycho_directional_derivatives_64.npz'))
+    f = np.load(os.path.join(gdir, 'g17_reconstruct_ptychography_fft_64.npz' if model == 'fft' else 'g14_reconstruct_ptychography_64.npz'))
+    obj_size, psz, sigma = tuple(int(v) for v in f['obj_size']), tuple(int(v) for v in f['probe_size']), float(f['probe_sigma'])
+    d, b = g13_inputs.initial_guess(obj_size)
+    pr, pi_ = orc.gaussian_probe(psz, sigma, sigma, 0.5)
+    i_theta, batch = int(g[model + '_i_theta']), g[model + '_pos_batch']
+    ind = np.array([int(np.where((f['probe_pos'] == p).all(axis=1))[0][0]) for p in batch])
+    s = PtychoSolver(obj_size, psz, f['probe_pos'], f['prj'].shape[0], len(ind), 5000., 1e-7, pr, pi_, propagator=model, kernel_size=17,
+                     adjoint64=adjoint64 or None)
+    s.set_volume(d, b)
+    loss = s.loss_and_grad(i_theta, ind, np.abs(f['prj'][i_theta, ind]))
+    gd, gb = s.gradient_to_host()
+    dirs = g13_inputs.g20_directions(obj_size)
+    got = np.array([[np.sum(gd.astype(np.float64) * v), np.sum(gb.astype(np.float64) * v)] for v in dirs])
+    ref = g[model + '_dd']
+    err = np.abs(got - ref) / np.abs(ref)
+    print('G21', model, 'adjoint64' if adjoint64 else '', 'loss', abs(loss - float(g[model + '_loss'])) / abs(loss), 'directional derivatives rel err',
+          err.ravel())
+    assert abs(loss - float(g[model + '_loss'])) <= 1e-5 * abs(loss)
+    assert np.max(err) <= 5e-5, (got, ref)

@@ -223,3 +223,62 @@ def test_g10_gradient_of_the_reference_loss(golden_dir):
     rd, rb = orc.regularizer_grad(d, b, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)
     rel = lambda a, c: np.linalg.norm(a - c) / np.linalg.norm(c)
     assert rel(gd + rd, g['grad0_gd']) <= 1e-6 and rel(gb + rb, g['grad0_gb']) <= 1e-6, (rel(gd + rd, g['grad0_gd']), rel(gb + rb, g['grad0_gb']))
+
+
+def _g20_setup(golden_dir):
+    import sys
+    sys.path.insert(0, golden_dir)
+    import g13_inputs
+    g = np.load(os.path.join(golden_dir, 'g20_directional_derivatives_64.npz'))
+    shape = (64, 64, 64)
+    mask = g13_inputs.mask(shape)
+    init_d, init_b = g13_inputs.initial_guess(shape)
+    return g, init_d * mask, init_b * mask, g13_inputs.g20_directions(shape), orc.rotation_lookup(list(shape), 4)
+
+
+def test_g20_gradient_of_the_reference_loss_at_64_cubed(golden_dir):
+    """The oracle's analytic gradient against central differences of the REFERENCE's own calculate_loss along six directions at
+    (64, 64, 64) — a size the HIP kernels take — for both forward models the reference has (np_funcs' FFT propagator and the
+    real-space propagator its entry point calls): golden vector G20, numbers that no oracle code produced."""
+    g, d, b, dirs, coords = _g20_setup(golden_dir)
+    one, zero = np.ones((64, 64)), np.zeros((64, 64))
+    for model, fixture in (('fft', 'g15_reconstruct_fullfield_fft_64.npz'), ('conv', 'g13_reconstruct_fullfield_64.npz')):
+        prj = np.load(os.path.join(golden_dir, fixture))['prj']
+        ind = g[model + '_ind']
+        if model == 'fft':
+            loss, gd, gb = orc.fullfield_loss_and_grad(d, b, coords, ind, prj[ind], one, zero, 5000., 1e-7, free_prop_cm=1e-4, with_reg=False)
+        else:
+            rot = np.stack([orc.apply_rotation(np.stack([d, b], axis=3), coords[j]) for j in ind])
+            loss, gd_rot, gb_rot = orc.cnn_loss_and_grad(rot[..., 0], rot[..., 1], one, zero, 5000., [1e-7] * 3, np.abs(prj[ind]), kernel_size=17,
+                                                         free_prop_cm=1e-4)
+            gd = sum(orc.apply_rotation_adjoint(gd_rot[k], coords[j]) for k, j in enumerate(ind))
+            gb = sum(orc.apply_rotation_adjoint(gb_rot[k], coords[j]) for k, j in enumerate(ind))
+        assert abs(loss - float(g[model + '_loss'])) <= 1e-10 * abs(loss)
+        got = np.array([[np.sum(gd * v), np.sum(gb * v)] for v in dirs])
+        ref = g[model + '_dd']
+        assert np.max(np.abs(got - ref) / np.abs(ref)) <= 1e-6, (model, got, ref)
+
+
+@pytest.mark.parametrize('model', ['fft', 'conv'])
+def test_g21_gradient_of_the_reference_ptychography_loss_at_64_cubed(golden_dir, model):
+    """G20 for ptychography: central differences of the REFERENCE's calculate_loss (cnn_propagator/ptychography.py:30-81 —
+    rotation, padding, window cut, forward, far-field loss) along six directions at the first minibatch of the G17 (FFT forward
+    bound in) and G14 (real-space propagator) runs, against the oracle's analytic gradient: numbers no oracle code produced."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import g13_inputs
+    g = np.load(os.path.join(golden_dir, 'g21_ptycho_directional_derivatives_64.npz'))
+    f = np.load(os.path.join(golden_dir, 'g17_reconstruct_ptychography_fft_64.npz' if model == 'fft' else 'g14_reconstruct_ptychography_64.npz'))
+    obj_size, psz, sigma = tuple(int(v) for v in f['obj_size']), tuple(int(v) for v in f['probe_size']), float(f['probe_sigma'])
+    d, b = g13_inputs.initial_guess(obj_size)
+    coords = orc.rotation_lookup(list(obj_size), f['prj'].shape[0])
+    pr, pi_ = orc.gaussian_probe(psz, sigma, sigma, 0.5)
+    i_theta, batch = int(g[model + '_i_theta']), g[model + '_pos_batch']
+    ind = [int(np.where((f['probe_pos'] == p).all(axis=1))[0][0]) for p in batch]
+    loss, gd, gb = orc.ptycho_loss_and_grad(d.astype(np.float64), b.astype(np.float64), coords[i_theta], f['probe_pos'], batch, f['prj'][i_theta, ind],
+                                            pr, pi_, psz, 5000., 1e-7, propagator=model, kernel_size=17)
+    assert abs(loss - float(g[model + '_loss'])) <= 1e-10 * abs(loss)
+    got = np.array([[np.sum(gd * v), np.sum(gb * v)] for v in g13_inputs.g20_directions(obj_size)])
+    ref = g[model + '_dd']
+    # 5e-6: the differences' own floor here (kinks of |psi| at dark far-field bins against round-off; make_golden.py fd_directional)
+    assert np.max(np.abs(got - ref) / np.abs(ref)) <= 5e-6, (model, np.abs(got - ref) / np.abs(ref))
