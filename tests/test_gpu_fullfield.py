@@ -341,6 +341,9 @@ def test_device_gradient_vs_directional_derivatives_of_the_reference_loss(model)
     dirs = g13_inputs.g20_directions(shape)
     got = np.array([[np.sum(gd.astype(np.float64) * v), np.sum(gb.astype(np.float64) * v)] for v in dirs])
     ref = g[model + '_dd']
-    err = np.abs(got - ref) / np.abs(ref)
+    # each number against the larger of itself and a tenth of the largest projection of its parameter: a projection is a sum of
+    # 262144 signed terms, and the ones that cancel to a few per cent of the others carry the same ABSOLUTE float32 error
+    err = np.abs(got - ref) / np.maximum(np.abs(ref), 0.1 * np.abs(ref).max(axis=0))
     print('G20', model, 'loss', abs(loss - float(g[model + '_loss'])) / abs(loss), 'directional derivatives rel err', err.ravel())
-    assert np.max(err) <= 5e-5, (got, ref)
+    # measured: transfer-function model 5.2e-6 at worst, real-space model 3.1e-5 (its kernel taps are float32)
+    assert np.max(err) <= (1.5e-5 if model == 'fft' else 1e-4), (got, ref)
