@@ -508,12 +508,24 @@ class PtychoSolver(_VolumeSolver):
         pin = 'resident' if (self.py == self.px and self.py in RESIDENT_SIZES and not self.conv
                              and not os.environ.get('BDOF_NO_RESIDENT_PIN')) else 'auto'
         self.eng = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream, engine=pin,
-                                    adjoint64=adjoint64)
+                                    adjoint64=adjoint64 is True)
         self.ctx = self.eng.ctx
         self.eng.set_physics(energy_ev, psize_cm, 'inf', variant=variant)   # free_prop_cm='inf', ptychography.py:76
         if self.conv:
             self.eng.set_conv(energy_ev, psize_cm, kernel_size)
         self.eng.set_probe(probe_real, probe_imag)
+        # adjoint64='first': a second engine with the float64 adjoint sweep for the FIRST minibatch of every epoch — Adam's first
+        # step after a restart is lr g / (|g| + 1e-8), the only one in which a 1e-8 error of the gradient moves a voxel by a
+        # fraction of a whole step; every later step runs on the fast engine
+        self.eng64 = None
+        if adjoint64 == 'first':
+            self.eng64 = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream, adjoint64=True)
+            self.eng64.set_physics(energy_ev, psize_cm, 'inf', variant=variant)
+            self.eng64.set_probe(probe_real, probe_imag)
+            if (getattr(self.eng64, 'meas_ref', 0.0) != getattr(self.eng, 'meas_ref', 0.0)) or self.eng64.det_mode != self.eng.det_mode:
+                raise RuntimeError('the two engines of one solver must lay the measurements out alike')
+        elif adjoint64 not in (None, False, True):
+            raise ValueError("adjoint64 must be None, False, True or 'first'")
         if coord_ls is None:
             coord_ls = util.rotation_lookup([self.dim_y, self.dim_x, self.dim_z], n_theta)
         tab, off, order = util.device_rotation_tables(coord_ls, self.dim_x, self.dim_z)
@@ -525,7 +537,15 @@ class PtychoSolver(_VolumeSolver):
         self.idx_buf = DeviceBuffer(self.ctx, 4 * self.mb * 4, np.int32, (4, self.mb))
         self._bind_volume()
         self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
+        if self.eng64 is not None:
+            self.eng64.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
         self._last = None
+        self._last_ctx = self.ctx
+
+    def _bind_volume(self):
+        _VolumeSolver._bind_volume(self)
+        if self.eng64 is not None:
+            self.eng64.set_volume(self.x[self.cur], self.dim_x * self.dim_z, self.dim_y, self.tab, self.dim_x, self.n_theta)
 
     def set_measurements(self, prj_abs_all):
         """All diffraction amplitudes |prj| (n_theta, n_pos, py, px) resident on the device (a cfg5-sized dataset is 0.75 GB):
@@ -555,17 +575,28 @@ class PtychoSolver(_VolumeSolver):
             self.meas_stage.upload(self.eng.meas_layout(prj_abs_batch))
         return p, p + 4 * self.mb, p + 8 * self.mb
 
-    def _win_loss_grad(self, i_theta, pos_idx, prj_abs_batch):
-        lib, h = self.ctx.lib, self.ctx.handle
+    def _win_loss_grad(self, i_theta, pos_idx, prj_abs_batch, use64=False):
         a, xo, yo = self._stage(i_theta, pos_idx, prj_abs_batch)
-        fn = lib.bdof_loss_grad_conv if self.conv else lib.bdof_loss_grad
-        self.ctx.check(fn(h, self.mb, a, xo, yo, self.meas_stage.ptr, None))
+        ctx = self.eng64.ctx if use64 else self.ctx
+        if ctx is not self.ctx:
+            self.ctx.sync()                          # the staging buffers and the volume were written on self.ctx's stream
+        fn = ctx.lib.bdof_loss_grad_conv if self.conv else ctx.lib.bdof_loss_grad
+        ctx.check(fn(ctx.handle, self.mb, a, xo, yo, self.meas_stage.ptr, None))
         self._last = (int(i_theta), xo, yo)
+        self._last_ctx = ctx
 
     def _produce_all(self):
-        lib, h = self.ctx.lib, self.ctx.handle
+        ctx = self._last_ctx
         i_theta, xo, yo = self._last
-        self.ctx.check(lib.bdof_window_rotation_adjoint(h, self.mb, i_theta, xo, yo, self.g.ptr, 0, 1.0))
+        ctx.check(ctx.lib.bdof_window_rotation_adjoint(ctx.handle, self.mb, i_theta, xo, yo, self.g.ptr, 0, 1.0))
+        if ctx is not self.ctx:
+            ctx.sync()                               # the tail of the step (exchange, Adam) runs on self.ctx's stream
+
+    def _get_loss(self):
+        loss = ctypes.c_double(0)
+        ctx = self._last_ctx
+        ctx.check(ctx.lib.bdof_get_loss(ctx.handle, ctypes.byref(loss)))
+        return loss.value
 
     def loss_and_grad(self, i_theta, pos_idx, prj_abs_batch=None, want_loss=True):
         """prj_abs_batch: |this_prj_batch| (mb, py, px) for probe positions pos_idx at angle i_theta (None: from the resident
@@ -580,7 +611,7 @@ class PtychoSolver(_VolumeSolver):
     def step(self, i_batch, i_theta, pos_idx, prj_abs_batch=None, learning_rate=1.0, want_loss=False, n_slabs=None, sharded=None, clip=True):
         """One Adam iteration of ptychography.py:301-310: loss_grad, Allreduce, /size, Adam, clip (no regulariser, no mask).
         The window/rotation adjoint produces the whole volume gradient in one pass; exchange and Adam are still slab-wise."""
-        self._win_loss_grad(i_theta, pos_idx, prj_abs_batch)
+        self._win_loss_grad(i_theta, pos_idx, prj_abs_batch, use64=self.eng64 is not None and i_batch == 0 and self.probe is None)
         self._probe_collect()
         self._produce_all()
         self._tail(lambda x0, nx: None, i_batch, learning_rate, clip=clip, use_mask=False, n_slabs=n_slabs, sharded=sharded)

@@ -139,7 +139,7 @@ def test_resident_measurements_equal_per_step_upload(psz):
     assert np.array_equal(vols[0][0], vols[1][0]) and np.array_equal(vols[0][1], vols[1][1])
 
 
-@pytest.mark.parametrize('adjoint_precision', ['float32', 'float64'])
+@pytest.mark.parametrize('adjoint_precision', ['float32', 'float64', 'first-step'])
 def test_reconstruct_ptychography_vs_the_reference_loop_fft(tmp_path, monkeypatch, adjoint_precision):
     """The DEFAULT ptychography entry point (transfer-function propagator, LDS-resident engine for the 64 x 64 probe, far field)
     against golden vector G17: the reference's own reconstruct_ptychography loop executed with the name it calls for the forward
@@ -181,6 +181,9 @@ def test_reconstruct_ptychography_vs_the_reference_loop_fft(tmp_path, monkeypatc
     if adjoint_precision == 'float64':
         # measured: delta 1.6e-6, beta 2.6e-7, no voxel more than 0.001 of a step away
         assert stats[0] <= 0.01 and stats[1] <= 5e-6 and stats[3] <= 2e-6 and stats[4] == 0.0, stats
+    elif adjoint_precision == 'first-step':
+        # float64 for the first minibatch of each epoch only (2 of the 8 steps here, 1 in hundreds at cfg5's size)
+        assert stats[0] <= 0.02 and stats[1] <= 1e-5 and stats[3] <= 5e-6 and stats[4] == 0.0, stats
     else:
         # measured: delta 1.7e-5 (1.85e-5 with exact adjoint twiddles: it is a lottery over ~100 voxels), beta 1.7e-6 relative
         # after eight Adam steps, no voxel more than 0.014 of a step away (round 2, residual in float32: 4.9e-5 / 0.045)

@@ -43,3 +43,24 @@ px = ps * ps
 # gradient write 8) — that is the figure its roofline fraction is priced at, not the streaming engines' 104 B
 print('probe %d^2, %d positions, %d slices: %.2f ms per Adam step, %.0f slice-steps/s, %.1f GB/s at the resident kernel\'s 40 B/px (%.3f of 8 TB/s)' %
       (ps, mb, n, dt * 1e3, mb * n / dt, 40.0 * px * mb * n / dt / 1e9, 40.0 * px * mb * n / dt / 8e12))
+
+# what adjoint_precision='first-step' (reconstruct_ptychography's default) adds: the first minibatch of every epoch on a second
+# engine with the float64 adjoint sweep (rocFFT double precision, unfused)
+if os.environ.get('BDOF_BENCH_FIRST_STEP'):
+    del s
+    s = PtychoSolver([n, n, n], [ps, ps], pos, n_theta, mb, 5000., 1e-7, pr, pi, coord_ls=coords, adjoint64='first')
+    s.set_volume(d, 0.1 * d)
+    s.set_measurements(meas)
+    used = s.ctx.mem_used() / 2.0 ** 30
+    for rep in range(2):
+        s.reset_moments()
+        s.ctx.sync()
+        t0 = time.perf_counter()
+        s.step(0, 0, np.arange(mb), None, 1e-7)
+        s.ctx.sync()
+        t1 = time.perf_counter()
+        s.step(1, 1, np.arange(mb), None, 1e-7)
+        s.ctx.sync()
+        t2 = time.perf_counter()
+    print('first step of an epoch with the float64 adjoint sweep: %.1f ms (the following float32 step %.2f ms); %.1f GiB of HBM in use with both engines'
+          % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, used))
