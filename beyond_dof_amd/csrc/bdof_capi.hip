@@ -43,6 +43,10 @@ struct bdof_ctx {
     bool with_grad = false;
     bool recompute = false;                      // tape-free adjoint (bdof_configure flag 16): the tape holds 3 fields, not S
     cf *twY = nullptr, *twX = nullptr;
+    // dithered twiddle tables (bdof_fft.h; BDOF_TW_DITHER=D, default 64): D copies of each table, entry j of copy d rounded up or
+    // down so that the mean over the D copies is the float64 value to ulp / D; the launches of slice z take copy z mod D
+    int tw_dither = 0;
+    unsigned tw_tick = 0;          // the slice of the last A / A' launch: the transfer-function launch that follows takes the same copy
     cf *hs = nullptr, *hdet = nullptr, *hcomb = nullptr, *probe = nullptr;
     cf *bufA = nullptr, *bufB = nullptr, *tape = nullptr;
     float2* grot = nullptr;
@@ -343,6 +347,29 @@ static ObjView sub_obj(const bdof_ctx* c) {
     }
     return o;
 }
+// copy d of a dithered constant: the float32 below or above v, the upper one in a fraction p = (v - below) / ulp of the copies,
+// spread evenly (copy d takes it iff floor((d + 1) p + phase) > floor(d p + phase)): the mean over any run of copies is v to
+// ulp / (length of the run)
+static float dither_pick(double v, int d, double phase) {
+    const float r = (float)v;
+    float f0 = r, f1 = r;
+    if ((double)r > v) f0 = std::nextafterf(r, -4.f); else if ((double)r < v) f1 = std::nextafterf(r, 4.f); else return r;
+    const double p = (v - (double)f0) / ((double)f1 - (double)f0);
+    return std::floor((d + 1) * p + phase) > std::floor(d * p + phase) ? f1 : f0;
+}
+
+// sqrt(1/2) of a slice launch for the transforms compiled with ROUND 1 / ROUND 2 (bdof_fft.h): the nearest float32 and its upper
+// neighbour (one transform in four rounds up: the defects cancel to a quarter) — or, with dithered tables, one value for both,
+// the upper neighbour in 20.3 % of the slices so that the mean over the slices is sqrt(1/2)
+static void sq_of(const bdof_ctx* c, unsigned key, float (&sq)[2]) {
+    if (c->tw_dither > 0) sq[0] = sq[1] = dither_pick(0.70710678118654752440, (int)(key % (unsigned)c->tw_dither), 0.5);
+    else { sq[0] = 0.70710678118654752f; sq[1] = 0.70710682868957520f; }
+}
+// the table copy of a slice launch
+static const cf* tw_of(bdof_ctx* c, const cf* base, int N, unsigned key) {
+    return c->tw_dither > 0 ? base + (size_t)(key % (unsigned)c->tw_dither) * 2 * N : base;
+}
+
 template <class T> static T* sub_field(const bdof_ctx* c, T* p) { return p ? p + (size_t)c->sub_b0 * c->NX * c->NY : p; }
 
 // A_z: L1 (or the probe) -> L2 (tstore) or L1 (plain)
@@ -353,7 +380,9 @@ static const cf* slice_carrier_field(const bdof_ctx* c, int z) { return c->pstac
 static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool tstore, cf* phi_out = nullptr, const cf* start = nullptr) {
     ProfScope ps(c, BDOF_K_ROW_FWD, true);
     RowFwdArgs a{sub_field(c, in), start ? sub_field(c, start) : c->probe, sub_field(c, out), sub_field(c, phi_out), sub_obj(c), B, c->NX, z,
-                 c->k, carrier_at(c, z), c->twY, slice_carrier_field(c, z), cshift_at(c, z), 0, 1.f, start ? 1 : 0};
+                 c->k, carrier_at(c, z), tw_of(c, c->twY, c->NY, (unsigned)z), slice_carrier_field(c, z), cshift_at(c, z), 0, 1.f, start ? 1 : 0};
+    sq_of(c, (unsigned)z, a.sq);
+    c->tw_tick = (unsigned)z;
     const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
@@ -379,8 +408,10 @@ static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, boo
 // A_z^-1 (tape-free adjoint): scattered part of phi_z (L1 hybrid, or real space) -> R eps(psi_z) in L2
 static void launch_row_unmod(bdof_ctx* c, int B, int z, const cf* in, cf* out, bool real_in, float in_scale) {
     ProfScope ps(c, BDOF_K_ROW_FWD, true);
-    RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), nullptr, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
+    RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), nullptr, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), tw_of(c, c->twY, c->NY, (unsigned)z),
                  slice_carrier_field(c, z), cshift_at(c, z), real_in ? 1 : 0, in_scale, 0};
+    sq_of(c, (unsigned)z, a.sq);
+    c->tw_tick = (unsigned)z;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
         const dim3 blk(BDOF_THREADS);
@@ -392,7 +423,8 @@ static void launch_row_unmod(bdof_ctx* c, int B, int z, const cf* in, cf* out, b
 // B: L2 -> L1
 static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf* h, float scale, int conj_h) {
     ProfScope ps(c, BDOF_K_COL_PROP, true);
-    RowPropArgs a{sub_field(c, in), sub_field(c, out), h, B, c->NY, scale, conj_h, c->twX};
+    RowPropArgs a{sub_field(c, in), sub_field(c, out), h, B, c->NY, scale, conj_h, tw_of(c, c->twX, c->NX, c->tw_tick)};
+    sq_of(c, c->tw_tick, a.sq);
     DISPATCH_N(c->NX, {
         // the adjoint step runs the instance with exact transform constants (bdof_fft.h: that is where the gradient's error is made)
         if (conj_h ? BDOF_EX_ADJ : BDOF_EX_FWD_B) BDOF_LAUNCH(ps, (k_row_prop<N_, true>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
@@ -412,10 +444,12 @@ static void launch_row_bwd(bdof_ctx* c, int B, int z, const cf* gin, const cf* t
     ProfScope ps(c, BDOF_K_ROW_BWD, true);
     float2* grot = gt && gt->grot ? gt->grot + (size_t)c->sub_b0 * gt->S_ * c->NX * c->NY : c->grot + (size_t)c->sub_b0 * c->S * c->NX * c->NY;
     RowBwdArgs a{sub_field(c, gin), hist == 2 ? c->probe : sub_field(c, tape), sub_field(c, gout),
-                 grot, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), c->twY,
+                 grot, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), tw_of(c, c->twY, c->NY, (unsigned)z),
                  slice_carrier_field(c, z), adj_carrier_at(c, c->S - 1 - z), cshift_at(c, z), carrier_phi_at(c, z), tape_scale,
                  gt && gt->gpsi ? sub_field(c, gt->gpsi) : (z == 0 && c->gpsi0 ? c->gpsi0 + (size_t)c->sub_b0 * c->NX * c->NY : nullptr),
                  gt && gt->grot ? gt->S_ : c->S, gt && gt->grot ? gt->z_ : z};
+    sq_of(c, (unsigned)z, a.sq);
+    c->tw_tick = (unsigned)z;
     const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
         const dim3 grid(rows_grid<N_>(c, B, c->NX));
@@ -951,19 +985,25 @@ static cf unit_twiddle(double c, double s) {
     return make_float2(bc, bs);
 }
 
-static int upload_twiddle(bdof_ctx* c, int N, cf** dst) {
-    std::vector<cf> t((size_t)N * 2);                     // hi, then lo (bdof_fft.h)
-    for (int j = 0; j < N; ++j) {
-        double ang = -2.0 * M_PI * (double)j / (double)N;
-        t[j] = unit_twiddle(std::cos(ang), std::sin(ang));
-        t[(size_t)N + j] = make_float2((float)(std::cos(ang) - (double)t[j].x), (float)(std::sin(ang) - (double)t[j].y));
-    }
+static int upload_twiddle(bdof_ctx* c, int N, cf** dst, bool dither = true) {
+    const int D = dither && c->tw_dither > 0 ? c->tw_dither : 1;
+    std::vector<cf> t((size_t)N * 2 * D);                 // per copy: hi, then lo (bdof_fft.h)
+    for (int d = 0; d < D; ++d)
+        for (int j = 0; j < N; ++j) {
+            double ang = -2.0 * M_PI * (double)j / (double)N;
+            cf* td = t.data() + (size_t)d * 2 * N;
+            if (D > 1) {
+                // golden-ratio phases: a different offset of the up / down pattern for every entry and component
+                const double ph1 = std::fmod(0.6180339887498949 * (2 * j + 1), 1.0), ph2 = std::fmod(0.6180339887498949 * (2 * j + 2) + 0.37, 1.0);
+                td[j] = make_float2(dither_pick(std::cos(ang), d, ph1), dither_pick(std::sin(ang), d, ph2));
+            } else td[j] = unit_twiddle(std::cos(ang), std::sin(ang));
+            td[(size_t)N + j] = make_float2((float)(std::cos(ang) - (double)td[j].x), (float)(std::sin(ang) - (double)td[j].y));
+        }
     HIPC(c, hipMalloc((void**)dst, sizeof(cf) * t.size()));
     HIPC(c, hipMemcpyAsync(*dst, t.data(), sizeof(cf) * t.size(), hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
-
 int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) {
     if (!c) return BDOF_ERR_ARG;
     if (NY < 1 || NX < 1 || S < 1 || Bmax < 1) return fail(c, BDOF_ERR_ARG, "NY, NX, S and Bmax must be >= 1");
@@ -974,6 +1014,8 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     free_workspace(c);
     c->NY = NY; c->NX = NX; c->S = S; c->Bmax = Bmax; c->with_grad = (with_grad & 1) != 0;
     c->generic = generic;
+    // dithered transform constants (bdof_fft.h): 64 copies of each table by default, BDOF_TW_DITHER=0 for one plain table
+    { const char* e = std::getenv("BDOF_TW_DITHER"); c->tw_dither = e ? std::max(0, std::min(256, atoi(e))) : 64; }
     c->recompute = (with_grad & 16) != 0 && !generic;      // the streaming engine's option; the others keep their tapes
     c->adj64 = (with_grad & 64) != 0 && (with_grad & 1) != 0;
     c->resident = (with_grad & (6 | 64)) == 0 && NX == NY && resident_supported(NX) && !std::getenv("BDOF_NO_RESIDENT");
@@ -982,7 +1024,7 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     c->have_physics = c->have_probe = c->tape_valid = false;
     int r;
     if (c->resident) {
-        if ((r = upload_twiddle(c, NX, &c->twR))) return r;
+        if ((r = upload_twiddle(c, NX, &c->twR, false))) return r;       // one launch runs all slices: one table
         HIPC(c, hipMalloc((void**)&c->hsT, sizeof(cf) * NX * NY));
         HIPC(c, hipMalloc((void**)&c->hdetT, sizeof(cf) * NX * NY));
         HIPC(c, hipMalloc((void**)&c->res_carrier, sizeof(cf) * 2 * (size_t)S));

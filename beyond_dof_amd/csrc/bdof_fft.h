@@ -19,42 +19,31 @@ __device__ __forceinline__ cf cmul(cf a, cf b) { return make_float2(a.x * b.x - 
 __device__ __forceinline__ cf cmulc(cf a, cf b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 __device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s, a.y * s); }
 
-// Twiddle tables come as hi + lo pairs (table[N + j] = the float32 rounding error of table[j], from the host's float64
-// values).  A transform instantiated with EX = true multiplies by hi + lo and takes sqrt(1/2) as a hi + lo pair too: the fixed
-// tables then stop acting as the same small perturbation of every transform of a stack (gradient error at 512 slices
-// 1.61e-5 -> 6.1e-6; reconstructed delta against the reference's loop at 256^3 on noise-free data 2.1e-5 -> 1.17e-5 with the
-// adjoint transforms exact -> 6.0e-6 with every transform exact).  Since round 3 EVERY transform is exact by default (parity
-// with the reference comes before the 2.8 % of step time it costs); -DBDOF_FAST_FORWARD takes the forward sweep's back to
-// plain float32 tables (round 2's default), -DBDOF_FAST_ADJOINT with it the adjoint sweep's too.
-#ifdef BDOF_FAST_FORWARD
-constexpr bool BDOF_EX_ALL = false;
-#else
+// Transform constants.  float32-rounded twiddle tables and float32(sqrt(1/2)) are the SAME small perturbation of every transform
+// of a multislice stack: their errors add up coherently along hundreds of slices (gradient error at 512 slices 1.61e-5,
+// reconstructed delta against the reference's loop at 256^3 2.1e-5).  Two remedies are built in:
+//
+//  * dithered constants (the streaming engine's per-slice kernels, default): the host uploads D = 64 copies of each table in which
+//    entry j is rounded DOWN or UP so that the mean over the copies is the float64 value to ulp / D, slice z runs with copy
+//    z mod D, and sqrt(1/2) arrives per launch the same way (mul_sqrt_half's `sq`).  Plain float32 arithmetic, no extra
+//    instruction — and the table errors of neighbouring slices cancel instead of adding up: gradient error at 512 slices 6.0e-6,
+//    reconstructed delta 6.6e-6 (G18) / 3.4e-6 (G15) / 7.4e-6 (G19).  BDOF_TW_DITHER=0 in the environment switches it off.
+//  * hi + lo pairs (EX = true: table[N + j] = the float32 rounding error of table[j], sqrt(1/2) likewise): every product with a
+//    constant is exact to 1e-15 for 2 more FMAs — 6.1e-6 / 5.8e-6 / 3.7e-6 / 7.0e-6 on the same four numbers for +3.2 ms (4.8 %)
+//    of the cfg3 step.  The kernels that run once per step (detector plane, loss) use it; -DBDOF_EXACT_TRANSFORMS builds the
+//    per-slice kernels with it too (round 3's first default, kept for comparison).
 #ifndef BDOF_EXACT_CONSTANTS
-#define BDOF_EXACT_CONSTANTS 1
+#define BDOF_EXACT_CONSTANTS 1          // sqrt(1/2) as a hi + lo pair wherever no dithered value is handed in (mul_sqrt_half)
 #endif
+#ifdef BDOF_EXACT_TRANSFORMS
 constexpr bool BDOF_EX_ALL = true;
-#endif
-#ifdef BDOF_FAST_ADJOINT
-constexpr bool BDOF_EX_ADJ = BDOF_EX_ALL;
 #else
-constexpr bool BDOF_EX_ADJ = true;
+constexpr bool BDOF_EX_ALL = false;
 #endif
-// per kernel of the FORWARD sweep (experiments: -DBDOF_FAST_FORWARD -DBDOF_EXACT_FWD_A / _B / _DET switch single ones back on)
-#ifdef BDOF_EXACT_FWD_A
-constexpr bool BDOF_EX_FWD_A = true;
-#else
-constexpr bool BDOF_EX_FWD_A = BDOF_EX_ALL;
-#endif
-#ifdef BDOF_EXACT_FWD_B
-constexpr bool BDOF_EX_FWD_B = true;
-#else
+constexpr bool BDOF_EX_ADJ = BDOF_EX_ALL;       // adjoint sweep (A', B')
+constexpr bool BDOF_EX_FWD_A = BDOF_EX_ALL;     // forward sweep
 constexpr bool BDOF_EX_FWD_B = BDOF_EX_ALL;
-#endif
-#ifdef BDOF_EXACT_DET
-constexpr bool BDOF_EX_DET = true;
-#else
-constexpr bool BDOF_EX_DET = BDOF_EX_ALL;
-#endif
+constexpr bool BDOF_EX_DET = true;              // once per step: detector plane, loss, seed
 // u * (w + wl), the twiddle conjugated for the inverse transform
 template <int SIGN, bool EX> __device__ __forceinline__ cf tw_mul(cf u, cf w, cf wl) {
     if (SIGN > 0) { w.y = -w.y; wl.y = -wl.y; }
@@ -87,34 +76,36 @@ template <int SIGN> __device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2,
 
 // Irrational butterfly constants.  float32(sqrt(1/2)) is 1.7e-8 short (float32(sqrt(3)/2) 1.8e-8): every product with it
 // shrinks the amplitude by that much, the defects add up along a chain of transforms and a multislice stack drifts in
-// energy (-1.25e-7 per slice at 72^2).  ROUND selects the remedy:
-//   0  hi + lo pair, one more FMA per product — the constant is exact to 1e-15 (+1.5 % on the streaming step: not used);
-//   1  the nearest float32 (rounds DOWN for both constants); 2  its upper neighbour.  A kernel whose propagation step runs
-//      four line transforms uses 2 in one of them and 1 in the other three: (3 x -1.71 + 6.72)e-8 — the defects cancel to
-//      a quarter at no cost in instructions.  The streaming engine rounds up in the inverse transform of the
-//      transfer-function kernel, the LDS-resident kernel in its inverse passes along x.
-// Building with -DBDOF_EXACT_CONSTANTS (BDOF_BUILD_FLAGS of __graft_entry__.build) takes the hi + lo pair everywhere: the
-// accuracy option for deep volumes (gradient error at 512 slices 1.61e-5 -> 1.15e-5 for +1.5 % step time).
-template <int ROUND_> __device__ __forceinline__ float mul_sqrt_half(float t) {
+// energy (-1.25e-7 per slice at 72^2).  The remedies:
+//   sq != nullptr (the per-slice kernels of the streaming engine): the constant of THIS launch comes from the host, sq[0] for the
+//      transforms instantiated with ROUND 1 and sq[1] for those with ROUND 2 — the host walks the two neighbouring float32 values
+//      over the slices so that their mean is sqrt(1/2) (dithered constants, above), at no cost in instructions;
+//   ROUND 0, or BDOF_EXACT_CONSTANTS (the default) without sq: hi + lo pair, one more FMA per product, exact to 1e-15;
+//   without BDOF_EXACT_CONSTANTS (-UBDOF_EXACT_CONSTANTS is not offered; round 2's scheme, kept for the record): ROUND 1 = the
+//      nearest float32 (rounds DOWN), ROUND 2 = its upper neighbour; a kernel whose propagation step runs four line transforms uses
+//      2 in one of them and 1 in the other three: (3 x -1.71 + 6.72)e-8 — the defects cancel to a quarter.
+template <int ROUND_> __device__ __forceinline__ float mul_sqrt_half(float t, const float* sq = nullptr) {
+    if constexpr (ROUND_ == 0) return fmaf(t, 0.70710678118654752f, t * 1.2101617e-8f);
+    else if (sq) return t * sq[ROUND_ - 1];
+    else {
 #ifdef BDOF_EXACT_CONSTANTS
-    constexpr int ROUND = 0;
+        return fmaf(t, 0.70710678118654752f, t * 1.2101617e-8f);
 #else
-    constexpr int ROUND = ROUND_;
+        if constexpr (ROUND_ == 1) return t * 0.70710678118654752f;
+        else return t * 0.70710682868957520f;
 #endif
-    if constexpr (ROUND == 0) return fmaf(t, 0.70710678118654752f, t * 1.2101617e-8f);
-    else if constexpr (ROUND == 1) return t * 0.70710678118654752f;
-    else return t * 0.70710682868957520f;
+    }
 }
 
 template <int SIGN, int ROUND = 1>
-__device__ __forceinline__ void dft8(cf& a0, cf& a1, cf& a2, cf& a3, cf& a4, cf& a5, cf& a6, cf& a7) {
+__device__ __forceinline__ void dft8(cf& a0, cf& a1, cf& a2, cf& a3, cf& a4, cf& a5, cf& a6, cf& a7, const float* sq = nullptr) {
     dft4<SIGN>(a0, a2, a4, a6);   // E0..E3 -> a0,a2,a4,a6
     dft4<SIGN>(a1, a3, a5, a7);   // O0..O3 -> a1,a3,a5,a7
     const float s = (float)SIGN;
     cf o0 = a1;
-    cf o1 = make_float2(mul_sqrt_half<ROUND>(a3.x - s * a3.y), mul_sqrt_half<ROUND>(a3.y + s * a3.x));       // * (1 + s i)/sqrt2
-    cf o2 = mul_si<SIGN>(a5);                                                                                // * s i
-    cf o3 = make_float2(mul_sqrt_half<ROUND>(-a7.x - s * a7.y), mul_sqrt_half<ROUND>(-a7.y + s * a7.x));     // * (-1 + s i)/sqrt2
+    cf o1 = make_float2(mul_sqrt_half<ROUND>(a3.x - s * a3.y, sq), mul_sqrt_half<ROUND>(a3.y + s * a3.x, sq));       // * (1 + s i)/sqrt2
+    cf o2 = mul_si<SIGN>(a5);                                                                                        // * s i
+    cf o3 = make_float2(mul_sqrt_half<ROUND>(-a7.x - s * a7.y, sq), mul_sqrt_half<ROUND>(-a7.y + s * a7.x, sq));     // * (-1 + s i)/sqrt2
     cf e0 = a0, e1 = a2, e2 = a4, e3 = a6;
     a0 = cadd(e0, o0); a4 = csub(e0, o0);
     a1 = cadd(e1, o1); a5 = csub(e1, o1);
@@ -150,6 +141,7 @@ template <int N> struct FftTw {
     const cf* mid;      // LDS table of the middle stages
     const cf* tail;     // LDS table [m-1][j] of the last stage (load<true>: its lo parts follow at + 7 T, the middle
                         // stages' at mid + LDS_CNT)
+    const float* sq = nullptr;      // dithered sqrt(1/2) of this launch (mul_sqrt_half); nullptr: the compiled-in constants
 
     // table[j] = exp(-2 pi i j / N), j in [0, N).  Must be called by every thread of the workgroup.
     // lds_mid: LDS_CNT slots; lds_tail: 7*N/8 slots laid out [m-1][j] = table[m*j] (also the tail stage's twiddles):
@@ -178,8 +170,8 @@ template <int N> struct FftTw {
     }
 };
 
-template <int R, int SIGN, int ROUND = 1> __device__ __forceinline__ void dftR(cf (&u)[8], int j) {
-    if constexpr (R == 8) dft8<SIGN, ROUND>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+template <int R, int SIGN, int ROUND = 1> __device__ __forceinline__ void dftR(cf (&u)[8], int j, const float* sq = nullptr) {
+    if constexpr (R == 8) dft8<SIGN, ROUND>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7], sq);
     else if constexpr (R == 4) {
         if (j == 0) dft4<SIGN>(u[0], u[1], u[2], u[3]); else dft4<SIGN>(u[4], u[5], u[6], u[7]);
     } else {
@@ -219,7 +211,7 @@ __device__ __forceinline__ void stage_compute(cf (&u)[8], const FftTw<N>& tw, in
 #pragma unroll
             for (int m = 1; m < R; ++m) u[j * R + m] = tw_mul<SIGN, EX>(u[j * R + m], row[m - 1], row[(EX ? TW::LDS_CNT : 0) + m - 1]);
         }
-        dftR<R, SIGN, EX ? 0 : ROUND>(u, j);
+        dftR<R, SIGN, EX ? 0 : ROUND>(u, j, tw.sq);
     }
 }
 
@@ -290,7 +282,7 @@ __device__ __forceinline__ void line_fft_partial(cf (&u)[8], const FftTw<N>& tw,
 // The last stage (radix 8, p = N/8) for butterfly j of a line whose image is `lds`; `tail` is the LDS copy
 // [m-1][j] of the twiddles exp(-2 pi i m j / N) (fill_tail_table).  On exit u[q] is the output at position j + q*N/8.
 template <int N, int SIGN, int ROUND = 1, bool EX = BDOF_EX_ALL, class L>
-__device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* tail) {
+__device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* tail, const float* sq = nullptr) {
     constexpr int T = N / 8;
     cf w[7], wl[7];
 #pragma unroll
@@ -301,5 +293,5 @@ __device__ __forceinline__ void last_stage(cf (&u)[8], int j, L& lds, const cf* 
     stage_read<N, 8>(u, j, lds);
 #pragma unroll
     for (int m = 1; m < 8; ++m) u[m] = tw_mul<SIGN, EX>(u[m], w[m - 1], wl[m - 1]);
-    dft8<SIGN, EX ? 0 : ROUND>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
+    dft8<SIGN, EX ? 0 : ROUND>(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7], sq);
 }

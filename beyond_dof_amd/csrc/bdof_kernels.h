@@ -57,7 +57,7 @@ template <int T> struct RowLds {
 // Called by all threads between two workgroup barriers.
 // ---------------------------------------------------------------------------------------------
 template <int N, int SIGN, int ROUND = 1, bool EX = BDOF_EX_ALL>
-__device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, size_t ld, float scale, const cf* tail) {
+__device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, size_t ld, float scale, const cf* tail, const float* sq = nullptr) {
     typedef RowCfg<N> C;
 #pragma nounroll
     for (int pass = 0; pass < C::PASSES; ++pass) {
@@ -65,7 +65,7 @@ __device__ __forceinline__ void transposed_tail(cf* smem, cf* __restrict__ dst, 
         const int r = q % C::TILE, j = q / C::TILE;
         RowLds<C::T> lds{smem + r * C::RS};
         cf u[8];
-        last_stage<N, SIGN, ROUND, EX>(u, j, lds, tail);
+        last_stage<N, SIGN, ROUND, EX>(u, j, lds, tail, sq);
 #pragma unroll
         for (int m = 0; m < 8; ++m) dst[(size_t)(j + m * C::T) * ld + r] = cscale(u[m], scale);
     }
@@ -216,6 +216,7 @@ struct RowFwdArgs {
     int real_in;       // INV kernels: `in` is real-space (no inverse transform first)
     float in_scale;    // INV kernels: factor on the (transformed) input
     int probe_batched; // FIRST kernels: `probe` is [B][NX][NY], one starting field per wavefield (bdof_forward_range)
+    float sq[2];       // sqrt(1/2) of this launch for the transforms with ROUND 1 / ROUND 2 (dithered over the slices, bdof_fft.h)
 };
 
 // Inverse of the modulation, for the tape-free adjoint (bdof_configure flag 16): from the scattered part of phi_z = c psi_z
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
     FftTw<NY> tw;
     __shared__ cf smem_tail[7 * C::T * (EX ? 2 : 1)];
     tw.template load<EX>(a.twiddle, tid, smem_tw, smem_tail);
+    tw.sq = a.sq;
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
         }
         if constexpr (TSTORE) {
             __syncthreads();
-            transposed_tail<NY, -1, 1, EX>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
+            transposed_tail<NY, -1, 1, EX>(smem, a.out + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail, a.sq);
             __syncthreads();
         }
     }
@@ -311,6 +313,7 @@ struct RowPropArgs {
     float scale;     // extra factor applied with h
     int conj_h;      // adjoint step uses conj(h)
     const cf* twiddle;
+    float sq[2];     // sqrt(1/2) of this launch (RowFwdArgs)
 };
 
 // EX: exact transform constants (hi + lo twiddles, bdof_fft.h) — the instance the adjoint sweep launches
@@ -323,6 +326,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_pro
     FftTw<NX> tw;
     __shared__ cf smem_tail[7 * C::T * (EX ? 2 : 1)];
     tw.template load<EX>(a.twiddle, tid, smem_tw, smem_tail);
+    tw.sq = a.sq;
     const int ntiles = a.B * a.NY / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_pro
             line_fft_partial<NX, +1, 2, EX>(u, tw, tid, lds);  // constants rounded up here, down elsewhere (bdof_fft.h)
         }
         __syncthreads();
-        transposed_tail<NX, +1, 2, EX>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, smem_tail);
+        transposed_tail<NX, +1, 2, EX>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, smem_tail, a.sq);
         __syncthreads();
     }
 }
@@ -616,6 +620,7 @@ struct RowBwdArgs {
                        // (probe_real / probe_imag of tensorflow_recon/fullfield.py:311-327 as optimisation variables)
     int grot_S, grot_z;  // gradient rows go to grot[b][grot_z][x][y] of a [B][grot_S][NX][NY] buffer (= obj.S, z unless the
                          // sweep covers a slice range with a buffer of its own, bdof_adjoint_range)
+    float sq[2];         // sqrt(1/2) of this launch (RowFwdArgs)
 };
 
 // HIST = 0: phi_z (scattered part) is read from the tape A_z wrote.  HIST = 1: the tape holds the per-slice history
@@ -640,6 +645,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
     FftTw<NY> tw;
     __shared__ cf smem_tail[7 * C::T * (LO ? 2 : 1)];
     tw.template load<LO>(a.twiddle, tid, smem_tw, smem_tail);
+    tw.sq = a.sq;
     const int ntiles = a.B * a.NX / C::TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * C::TILE;
@@ -696,7 +702,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
         }
         if (a.gout) {
             __syncthreads();
-            transposed_tail<NY, -1, 1, EX>(smem, a.gout + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail);
+            transposed_tail<NY, -1, 1, EX>(smem, a.gout + (size_t)b * NY * a.NX + x0, a.NX, 1.f, smem_tail, a.sq);
             __syncthreads();
         }
     }

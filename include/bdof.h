@@ -58,6 +58,8 @@ int bdof_timer_elapsed(bdof_ctx* ctx, int slot_a, int slot_b, double* ms);
  * transforms (rocFFT double precision), transfer function and the products conj(phi) G in float64, forward sweep and tape in
  * float32 — what autograd's float64 tape gives the reference (cnn_propagator/fullfield.py:329, ptychography.py:248);
  * follow bdof_set_physics with bdof_set_physics_f64.
+ * Environment read here: BDOF_TW_DITHER=D — number of dithered copies of the transform constants the per-slice kernels walk
+ * (default 64; 0: one plain float32 table, round 2's behaviour; DESIGN §4 "Dithered transform constants").
  * Replaces the per-call allocations of multislice_propagate_batch_numpy
  * (cnn_propagator/np_funcs.py:20,43) and of autograd's tape (cnn_propagator/fullfield.py:329). */
 int bdof_configure(bdof_ctx* ctx, int NY, int NX, int S, int Bmax, int with_grad);
