@@ -26,6 +26,7 @@ _SIGNATURES = {
     'bdof_sync': (ctypes.c_int, [_vp]),
     'bdof_stream': (_vp, [_vp]),
     'bdof_device_count': (ctypes.c_int, []),
+    'bdof_twiddle_tables': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'bdof_device_pci_bus_id': (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     'bdof_timer_mark': (ctypes.c_int, [_vp, ctypes.c_int]),
     'bdof_timer_elapsed': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),

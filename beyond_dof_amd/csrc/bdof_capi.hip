@@ -985,13 +985,14 @@ static cf unit_twiddle(double c, double s) {
     return make_float2(bc, bs);
 }
 
-static int upload_twiddle(bdof_ctx* c, int N, cf** dst, bool dither = true) {
-    const int D = dither && c->tw_dither > 0 ? c->tw_dither : 1;
-    std::vector<cf> t((size_t)N * 2 * D);                 // per copy: hi, then lo (bdof_fft.h)
-    for (int d = 0; d < D; ++d)
+// D copies (D <= 1: one copy, nearest rounding with the modulus kept closest to one) of the twiddle table of length N; per copy
+// N hi values, then N lo values (the float32 rounding error of the hi ones), (re, im) pairs
+static void fill_twiddle_tables(int N, int D, cf* t) {
+    const int copies = D > 1 ? D : 1;
+    for (int d = 0; d < copies; ++d)
         for (int j = 0; j < N; ++j) {
-            double ang = -2.0 * M_PI * (double)j / (double)N;
-            cf* td = t.data() + (size_t)d * 2 * N;
+            const double ang = -2.0 * M_PI * (double)j / (double)N;
+            cf* td = t + (size_t)d * 2 * N;
             if (D > 1) {
                 // golden-ratio phases: a different offset of the up / down pattern for every entry and component
                 const double ph1 = std::fmod(0.6180339887498949 * (2 * j + 1), 1.0), ph2 = std::fmod(0.6180339887498949 * (2 * j + 2) + 0.37, 1.0);
@@ -999,11 +1000,24 @@ static int upload_twiddle(bdof_ctx* c, int N, cf** dst, bool dither = true) {
             } else td[j] = unit_twiddle(std::cos(ang), std::sin(ang));
             td[(size_t)N + j] = make_float2((float)(std::cos(ang) - (double)td[j].x), (float)(std::sin(ang) - (double)td[j].y));
         }
+}
+
+int bdof_twiddle_tables(int N, int D, float* out) {
+    if (N < 1 || D < 0 || D > 256 || !out) return BDOF_ERR_ARG;
+    fill_twiddle_tables(N, D, (cf*)out);
+    return 0;
+}
+
+static int upload_twiddle(bdof_ctx* c, int N, cf** dst, bool dither = true) {
+    const int D = dither && c->tw_dither > 1 ? c->tw_dither : 1;
+    std::vector<cf> t((size_t)N * 2 * D);
+    fill_twiddle_tables(N, D, t.data());
     HIPC(c, hipMalloc((void**)dst, sizeof(cf) * t.size()));
     HIPC(c, hipMemcpyAsync(*dst, t.data(), sizeof(cf) * t.size(), hipMemcpyHostToDevice, c->stream));
     HIPC(c, hipStreamSynchronize(c->stream));
     return 0;
 }
+
 int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) {
     if (!c) return BDOF_ERR_ARG;
     if (NY < 1 || NX < 1 || S < 1 || Bmax < 1) return fail(c, BDOF_ERR_ARG, "NY, NX, S and Bmax must be >= 1");
@@ -1015,7 +1029,7 @@ int bdof_configure(bdof_ctx* c, int NY, int NX, int S, int Bmax, int with_grad) 
     c->NY = NY; c->NX = NX; c->S = S; c->Bmax = Bmax; c->with_grad = (with_grad & 1) != 0;
     c->generic = generic;
     // dithered transform constants (bdof_fft.h): 64 copies of each table by default, BDOF_TW_DITHER=0 for one plain table
-    { const char* e = std::getenv("BDOF_TW_DITHER"); c->tw_dither = e ? std::max(0, std::min(256, atoi(e))) : 64; }
+    { const char* e = std::getenv("BDOF_TW_DITHER"); c->tw_dither = e ? std::max(0, std::min(256, atoi(e))) : 64; if (c->tw_dither == 1) c->tw_dither = 0; }
     c->recompute = (with_grad & 16) != 0 && !generic;      // the streaming engine's option; the others keep their tapes
     c->adj64 = (with_grad & 64) != 0 && (with_grad & 1) != 0;
     c->resident = (with_grad & (6 | 64)) == 0 && NX == NY && resident_supported(NX) && !std::getenv("BDOF_NO_RESIDENT");

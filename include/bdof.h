@@ -38,6 +38,13 @@ const char* bdof_last_error(const bdof_ctx* ctx);
 int bdof_sync(bdof_ctx* ctx);
 void* bdof_stream(bdof_ctx* ctx);   /* the ctx's hipStream_t, for ordering foreign work (collectives) against it */
 int bdof_device_count(void);
+
+/* Host only (no device is touched): the twiddle tables bdof_configure uploads for transforms of length N, as D copies of
+ * [N hi (re, im)][N lo (re, im)] float32 — exp(-2 pi i j / N) with lo = the rounding error of hi.  D >= 2: the dithered copies
+ * (entry j of copy d is the float32 below or above the float64 value, the upper one in the fraction of the copies that makes the
+ * mean over the copies equal the float64 value to ulp / D; DESIGN §4 "Dithered transform constants"); D = 0 or 1: one copy,
+ * rounded to nearest with the modulus kept closest to one.  out: 4 N max(D, 1) floats.  Exposed for the tests. */
+int bdof_twiddle_tables(int N, int D, float* out);
 int bdof_device_pci_bus_id(int device, char* out, int len);      /* "0000:c1:00.0": which physical GPU a rank really got */
 /* Stream-ordered time stamps on the ctx stream (16 slots): mark now, read the interval after the work has run — how the
  * bench reports the tail of a step (rotation adjoint, gradient exchange, Adam) without a host synchronisation inside it. */

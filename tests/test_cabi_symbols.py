@@ -90,3 +90,35 @@ def test_no_spill_under_restricted_exec():
     import check_spills
     hits = check_spills.scan(check_spills.device_isa())
     assert not hits, hits[:5]
+
+
+@pytest.mark.parametrize('n', [64, 512, 1024])
+def test_dithered_twiddle_tables(built_lib, n):
+    """The transform constants of the per-slice kernels (DESIGN §4 "Dithered transform constants"; host code, no device): in each
+    of the D copies every component is one of the two float32 neighbours of the float64 value, hi + lo of every copy is that value,
+    and the mean over ANY run of L consecutive copies (the slices a wave passes through) is the value to ulp / L — where one
+    round-to-nearest table is off by up to ulp / 2 in every slice."""
+    import ctypes
+    import numpy as np
+    D = 64
+    buf = np.zeros((D, 2, n, 2), dtype=np.float32)
+    assert built_lib.bdof_twiddle_tables(n, D, buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    j = np.arange(n)
+    exact = np.stack([np.cos(-2 * np.pi * j / n), np.sin(-2 * np.pi * j / n)], axis=-1)          # float64
+    hi = buf[:, 0].astype(np.float64)
+    lo = buf[:, 1].astype(np.float64)
+    below = np.nextafter(exact.astype(np.float32), np.float32(-4)).astype(np.float64)
+    below = np.where(exact.astype(np.float32).astype(np.float64) <= exact, exact.astype(np.float32).astype(np.float64), below)
+    above = np.nextafter(below.astype(np.float32), np.float32(4)).astype(np.float64)
+    ulp = above - below
+    assert np.all((hi == below) | (hi == above) | (exact == below))
+    assert np.abs(hi + lo - exact).max() <= 2e-15                                                  # the pair is exact
+    for L in (8, 16, 64):
+        for start in (0, 5, 40):
+            idx = (start + np.arange(L)) % D
+            err = np.abs(hi[idx].mean(axis=0) - exact) / ulp
+            assert err.max() <= 1.0 / L + 1e-12, (L, start, err.max())
+    # one nearest-rounded table for comparison: its error does not shrink with the number of slices
+    one = np.zeros((1, 2, n, 2), dtype=np.float32)
+    assert built_lib.bdof_twiddle_tables(n, 0, one.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert (np.abs(one[0, 0].astype(np.float64) - exact) / ulp).max() > 0.4

@@ -362,11 +362,12 @@ def test_full_size_properties_512(engine_mod):
     assert abs((l0 - l1) - step * gnorm2) <= 0.05 * step * gnorm2
 
 
-def test_cfg3_full_depth_vs_oracle(engine_mod):
+def test_cfg3_full_depth_vs_oracle(engine_mod, monkeypatch):
     """BASELINE's headline wavefield at its full size: one 512 x 512 wavefield through all 512 slices (plane probe,
     charcoal-like object of bench.py, near-field detector) against the float64 oracle — the oracle needs ~20 s for it.
-    Carrier splitting keeps the float32 forward within 1.2e-7 of the reference in intensity (north star: 1e-5), the
-    gradient within 2e-5 (tools/gpu_check_cfg3_depth.py)."""
+    Carrier splitting keeps the float32 forward within 1.2e-7 of the reference in intensity (north star: 1e-5); the dithered
+    transform constants keep the gradient within 6.0e-6 where one fixed float32 table per transform leaves
+    1.61e-5 (tools/gpu_check_cfg3_depth.py) — both are measured here, on the same oracle."""
     from scipy.ndimage import uniform_filter
     n = S = 512
     rng = np.random.default_rng(3)
@@ -386,7 +387,20 @@ def test_cfg3_full_depth_vs_oracle(engine_mod):
     loss = eng.loss_grad(1, meas)
     gd, gb = eng.grad_batch_to_host(1)
     assert abs(loss - rl) <= 1e-6 * abs(rl)
-    assert rel(gd, rgd) <= 1e-4 and rel(gb, rgb) <= 1e-4
+    e_dither = max(rel(gd, rgd), rel(gb, rgb))
+    assert e_dither <= 1e-5, e_dither
+    del eng
+    # the same sweep with ONE nearest-rounded table (round 2's kernels): the coherent part of the error is back
+    monkeypatch.setenv('BDOF_TW_DITHER', '0')
+    eng = engine_mod.MultisliceEngine(n, n, S, 1, with_grad=True)
+    eng.set_physics(5000., 1e-7, 1e-4)
+    eng.set_probe(pr, pi)
+    eng.set_object_batch(delta, beta)
+    eng.loss_grad(1, meas)
+    gd0, gb0 = eng.grad_batch_to_host(1)
+    e_plain = max(rel(gd0, rgd), rel(gb0, rgb))
+    print('gradient error at 512 slices: dithered constants %.2e, one table %.2e' % (e_dither, e_plain))
+    assert 2e-5 >= e_plain >= 2.0 * e_dither, (e_plain, e_dither)
 
 
 def test_cfg2_full_size_fullfield_step_vs_oracle(engine_mod):
