@@ -108,14 +108,21 @@ if n_or > 0:
     res['float64_check'] = {'slices': S2, 'whole_field_rocfft_vs_float64': rel(whole2, w), 'tiled': []}
     print('  whole field (rocFFT, float32) vs float64: %.2e' % res['float64_check']['whole_field_rocfft_vs_float64'])
     del eng, vol
-    for tile, halo in ((512, 32), (512, 64), (1024, 64)):
+    # the last entry repeats 512 / 64 with ONE nearest-rounded twiddle table per transform (BDOF_TW_DITHER=0) instead of the
+    # dithered copies: what the coherent table error is worth at this depth
+    for tile, halo, dither in ((512, 32, None), (512, 64, None), (512, 96, None), (512, 128, None), (1024, 64, None), (1024, 128, None), (512, 64, '0')):
+        if dither is not None:
+            os.environ['BDOF_TW_DITHER'] = dither
         tp = TiledPropagator((n, n), S2, 5000., 1e-7, tile=tile, halo=halo)
         tp.set_object_slab(slab, 0.1 * slab)
         o = tp.forward(pr, np.zeros_like(pr))
         e = rel(o, w)
-        res['float64_check']['tiled'].append({'tile': tile, 'halo': halo, 'vs_float64': e, 'vs_whole_field_float32': rel(o, whole2)})
-        print('  tiles %d^2 halo %d vs float64: %.2e   (vs the float32 whole field: %.2e)' % (tile, halo, e, rel(o, whole2)))
+        res['float64_check']['tiled'].append({'tile': tile, 'halo': halo, 'one_table': dither is not None, 'vs_float64': e,
+                                              'vs_whole_field_float32': rel(o, whole2)})
+        print('  tiles %d^2 halo %d%s vs float64: %.2e   (vs the float32 whole field: %.2e)' % (tile, halo, ' (one twiddle table)' if dither is not None else '',
+                                                                                             e, rel(o, whole2)), flush=True)
         del tp
+        os.environ.pop('BDOF_TW_DITHER', None)
     if out_json:
         json.dump(res, open(out_json, 'w'), indent=1)
 
