@@ -52,6 +52,7 @@ _SIGNATURES = {
     'bdof_tape_to_real': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     'bdof_loss_grad': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     'bdof_set_conv': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int] + [ctypes.c_double] * 5),
+    'bdof_set_conv_taps_f64': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, ctypes.c_double]),
     'bdof_set_conv_probe_stack': (ctypes.c_int, [_vp, _vp, _vp] + [ctypes.c_double] * 4),
     'bdof_forward_conv': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
     'bdof_loss_grad_conv': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),

@@ -66,6 +66,7 @@ struct bdof_ctx {
     bool have_conv = false;
     ConvTaps taps{};
     ConvTaps* taps_dev = nullptr;
+    int taps_copies = 1;          // dithered copies of the taps in taps_dev (bdof_set_conv_taps_f64), slice z takes copy z mod taps_copies
     std::complex<double> ksum{1.0, 0.0};
     float k_conv = 0.f;
     cf *bufC = nullptr, *conv_scal = nullptr;
@@ -929,6 +930,7 @@ static void free_workspace(bdof_ctx* c) {
     c->bufC = c->conv_scal = nullptr;
     c->cstack = nullptr; c->cdet64 = nullptr;
     c->taps_dev = nullptr;
+    c->taps_copies = 1;
     c->have_conv = false;
     c->twY = c->twX = c->hs = c->hdet = c->hcomb = c->probe = c->bufA = c->bufB = c->tape = nullptr;
     c->grot = nullptr;
@@ -1702,11 +1704,40 @@ int bdof_set_conv(bdof_ctx* c, const float* ky, const float* kx, int ks, double 
     const size_t fld = (size_t)c->Bmax * c->NX * c->NY;
     if (!c->bufC) HIPC(c, hipMalloc((void**)&c->bufC, sizeof(cf) * fld));
     if (!c->conv_scal) HIPC(c, hipMalloc((void**)&c->conv_scal, sizeof(cf) * 4));
-    if (!c->taps_dev) HIPC(c, hipMalloc((void**)&c->taps_dev, sizeof(ConvTaps)));
     HIPC(c, hipStreamSynchronize(c->stream));                  // a sweep still in flight reads the previous taps
+    if (c->taps_dev && c->taps_copies != 1) { hipFree(c->taps_dev); c->taps_dev = nullptr; }
+    if (!c->taps_dev) HIPC(c, hipMalloc((void**)&c->taps_dev, sizeof(ConvTaps)));
+    c->taps_copies = 1;
     HIPC(c, hipMemcpy(c->taps_dev, &c->taps, sizeof(ConvTaps), hipMemcpyHostToDevice));
     c->have_conv = true;
     c->mod_dirty = true;
+    return 0;
+}
+
+int bdof_set_conv_taps_f64(bdof_ctx* c, const double* ky, const double* kx, double e_re, double e_im) {
+    if (!c || !ky || !kx) return BDOF_ERR_ARG;
+    if (!c->have_conv) return fail(c, BDOF_ERR_STATE, "bdof_set_conv has not been called");
+    const int D = c->tw_dither;
+    if (D < 2) return 0;                                       // BDOF_TW_DITHER=0: the nearest-rounded taps of bdof_set_conv stay
+    HIPC(c, hipSetDevice(c->device));
+    std::vector<ConvTaps> t((size_t)D, c->taps);
+    const int ks = c->taps.ks;
+    for (int d = 0; d < D; ++d) {
+        for (int i = 0; i < ks; ++i) {
+            // a phase of its own for each of the 4 ks + 2 numbers (golden-ratio sequence), as for the twiddle tables
+            const double ph = 0.6180339887498949 * (4 * i + 1);
+            t[d].ky[i] = make_float2(dither_pick(ky[2 * i], d, std::fmod(ph, 1.0)), dither_pick(ky[2 * i + 1], d, std::fmod(ph + 0.6180339887498949, 1.0)));
+            t[d].kx[i] = make_float2(dither_pick(kx[2 * i], d, std::fmod(ph + 2 * 0.6180339887498949, 1.0)),
+                                     dither_pick(kx[2 * i + 1], d, std::fmod(ph + 3 * 0.6180339887498949, 1.0)));
+        }
+        t[d].e = make_float2(dither_pick(e_re, d, 0.25), dither_pick(e_im, d, 0.75));
+    }
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->taps_dev) hipFree(c->taps_dev);
+    c->taps_dev = nullptr;
+    HIPC(c, hipMalloc((void**)&c->taps_dev, sizeof(ConvTaps) * D));
+    HIPC(c, hipMemcpy(c->taps_dev, t.data(), sizeof(ConvTaps) * D, hipMemcpyHostToDevice));
+    c->taps_copies = D;
     return 0;
 }
 
@@ -1770,7 +1801,7 @@ static int conv_forward_sweep(bdof_ctx* c, int B, bool tape) {
         const bool last = z == c->S - 1;
         cf* out = last ? c->bufB : (tape ? c->tape + (size_t)(z + 1) * fld : (cur == c->bufA ? c->bufC : c->bufA));
         ConvArgs a{cur, out, nullptr, nullptr, obj, B, c->NX, c->NY, last ? -1 : z + 1, cs ? zero : conv_pad(c, z), conv_carrier(c, z + 1),
-                   c->k_conv, c->taps_dev, c->taps.ks, cs && !last ? c->cstack + (size_t)(z + 1) * plane : nullptr};
+                   c->k_conv, c->taps_dev + z % c->taps_copies, c->taps.ks, cs && !last ? c->cstack + (size_t)(z + 1) * plane : nullptr};
         if ((r = launch_conv<false>(c, a))) return r;
         cur = out;
     }
@@ -1948,7 +1979,7 @@ int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xo
     cf* gcur = gp;
     for (int z = c->S - 1; z >= 0; --z) {
         cf* gout = gcur == c->bufB ? c->bufA : c->bufB;
-        ConvArgs a{gcur, gout, c->tape + (size_t)z * fld, c->grot, obj, B, c->NX, c->NY, z, zero, conv_carrier(c, z), c->k_conv, c->taps_dev, c->taps.ks,
+        ConvArgs a{gcur, gout, c->tape + (size_t)z * fld, c->grot, obj, B, c->NX, c->NY, z, zero, conv_carrier(c, z), c->k_conv, c->taps_dev + z % c->taps_copies, c->taps.ks,
                    cs ? c->cstack + (size_t)z * plane : nullptr};
         if ((r = launch_conv<true>(c, a))) return r;
         gcur = gout;

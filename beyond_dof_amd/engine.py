@@ -260,6 +260,10 @@ class MultisliceEngine(object):
         kxf = np.ascontiguousarray(kx.astype(np.complex64))
         self.ctx.check(self.lib.bdof_set_conv(self.h, kyf.ctypes.data, kxf.ctypes.data, int(kernel_size), e.real, e.imag,
                                               ksum.real, ksum.imag, k))
+        # the taps in float64 as well: dithered copies, one per slice (include/bdof.h)
+        ky64 = np.ascontiguousarray(ky.astype(np.complex128))
+        kx64 = np.ascontiguousarray(kx.astype(np.complex128))
+        self.ctx.check(self.lib.bdof_set_conv_taps_f64(self.h, ky64.ctypes.data, kx64.ctypes.data, float(e.real), float(e.imag)))
         if getattr(self, '_probe_args', None) is not None:
             self.set_probe(*self._probe_args)      # the carrier (scalar or field) of the probe follows the propagator
 

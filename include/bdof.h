@@ -196,6 +196,11 @@ int bdof_set_meas_mode(bdof_ctx* ctx, int mode);
  * bdof_forward / bdof_loss_grad (same arguments, gradient left in bdof_grot). */
 int bdof_set_conv(bdof_ctx* ctx, const float* ky, const float* kx, int ks, double e_re, double e_im, double ksum_re,
                   double ksum_im, double k);
+/* Optional, after bdof_set_conv: the same taps in float64 (HOST complex128 arrays of ks taps, and e).  The library then keeps
+ * BDOF_TW_DITHER (default 64) copies of the float32 taps whose roundings average to these values and runs slice z with copy
+ * z mod D, as it does with the transform constants of the transfer-function path (bdof_configure) — the taps are the same small
+ * perturbation of every slice otherwise.  A no-op with BDOF_TW_DITHER=0. */
+int bdof_set_conv_taps_f64(bdof_ctx* ctx, const double* ky, const double* kx, double e_re, double e_im);
 /* Carrier FIELD of the real-space propagator, for a probe with no dominant constant part (a localised ptychography probe —
  * what cnn_propagator/ptychography.py:74-76 runs): stack = HOST [S + 1][NX][NY] complex64, the probe carried through EMPTY
  * space by the same padded convolution, p_0 = probe, p_{z+1} = K * pad(p_z, edge_z), edge_{z+1} = sum(K) edge_z, edge_0 = 1
