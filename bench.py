@@ -407,6 +407,8 @@ def main():
                                               'slab-pipelined; max over ranks, two steps after the timed region',
                           'propagator': args.propagator, 'rotation': args.rotation,
                           'adjoint': 'recompute (tape-free)' if args.recompute else 'tape',
+                          'transform_constants': 'one float32 table' if os.environ.get('BDOF_TW_DITHER') in ('0', '1') else
+                          'dithered over the slices, {} copies (DESIGN 4)'.format(os.environ.get('BDOF_TW_DITHER', '64')),
                           'hbm_used_GiB': solver.ctx.mem_used() / 2.0 ** 30},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:
