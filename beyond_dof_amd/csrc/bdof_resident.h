@@ -12,12 +12,12 @@
 #pragma once
 #include "bdof_generic.h"
 
-// Exact twiddles (hi + lo pairs) in the ADJOINT passes of this kernel, what the streaming kernels run by default: measured in
+// Exact twiddles (hi + lo pairs) in the ADJOINT passes of this kernel (what -DBDOF_EXACT_TRANSFORMS gives the streaming kernels): measured in
 // round 3 on far-field ptychography (golden vector G17's configuration, 64^2 x 64 slices): gradient error 1.86e-6 -> 1.70e-6 for
 // +2.3 % (72^2) / +3.3 % (64^2) kernel time — the float32 rounding of the transforms themselves is the floor here, not the
 // tables (tools/precision_model.py).  Off by default; -DBDOF_RES_EXACT_ADJOINT switches it on.
 #ifdef BDOF_RES_EXACT_ADJOINT
-constexpr bool BDOF_EX_RES = BDOF_EX_ADJ;
+constexpr bool BDOF_EX_RES = true;
 #else
 constexpr bool BDOF_EX_RES = false;
 #endif
