@@ -18,6 +18,7 @@ from .comm import get_comm
 from .fullfield import create_probe_initial_guess, upsample_2x
 from .misc import create_summary
 from .solver import PtychoSolver
+from ._lib import BdofError
 from .util import print_flush, split_tasks
 
 PI = util.PI
@@ -156,10 +157,19 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
         else:
             raise ValueError("Invalid wavefront type. Choose from 'plane', 'fixed', 'optimizable'.")
 
-        solver = PtychoSolver(this_obj_size, this_probe_size, this_probe_pos, n_theta, minibatch_size, energy_ev,
-                              psize_cm * ds_level, probe_real, probe_imag, variant=variant, comm=comm, device=comm.local_rank,
-                              coord_ls=coord_ls, propagator=propagator, kernel_size=kwargs.get('kernel_size', 17),
-                              adjoint64={'float32': None, 'float64': True, 'first-step': 'first'}[adjoint_precision])
+        mk = lambda prec: PtychoSolver(this_obj_size, this_probe_size, this_probe_pos, n_theta, minibatch_size, energy_ev,
+                                       psize_cm * ds_level, probe_real, probe_imag, variant=variant, comm=comm, device=comm.local_rank,
+                                       coord_ls=coord_ls, propagator=propagator, kernel_size=kwargs.get('kernel_size', 17),
+                                       adjoint64={'float32': None, 'float64': True, 'first-step': 'first'}[prec])
+        try:
+            solver = mk(adjoint_precision)
+        except BdofError as err:
+            # the DEFAULT's second engine (float64 adjoint sweep for the first minibatch of an epoch) is an accuracy refinement:
+            # where it does not fit beside the first one the run goes on in float32 and says so; an explicit request fails
+            if 'adjoint_precision' in kwargs or adjoint_precision != 'first-step':
+                raise
+            print_flush("adjoint_precision='first-step' could not be set up ({}): continuing with 'float32'".format(err), 0, rank)
+            solver = mk('float32')
         solver.set_volume(obj_delta, obj_beta)
         solver.tune_tail()
         # the diffraction amplitudes stay on the device when they fit (ptychography.py:295 reads them from the file per step)
