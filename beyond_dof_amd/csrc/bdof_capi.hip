@@ -1705,7 +1705,7 @@ int bdof_set_conv(bdof_ctx* c, const float* ky, const float* kx, int ks, double 
     if (!c->bufC) HIPC(c, hipMalloc((void**)&c->bufC, sizeof(cf) * fld));
     if (!c->conv_scal) HIPC(c, hipMalloc((void**)&c->conv_scal, sizeof(cf) * 4));
     HIPC(c, hipStreamSynchronize(c->stream));                  // a sweep still in flight reads the previous taps
-    if (c->taps_dev && c->taps_copies != 1) { hipFree(c->taps_dev); c->taps_dev = nullptr; }
+    if (c->taps_dev && c->taps_copies != 1) { (void)hipFree(c->taps_dev); c->taps_dev = nullptr; }
     if (!c->taps_dev) HIPC(c, hipMalloc((void**)&c->taps_dev, sizeof(ConvTaps)));
     c->taps_copies = 1;
     HIPC(c, hipMemcpy(c->taps_dev, &c->taps, sizeof(ConvTaps), hipMemcpyHostToDevice));
@@ -1733,7 +1733,7 @@ int bdof_set_conv_taps_f64(bdof_ctx* c, const double* ky, const double* kx, doub
         t[d].e = make_float2(dither_pick(e_re, d, 0.25), dither_pick(e_im, d, 0.75));
     }
     HIPC(c, hipStreamSynchronize(c->stream));
-    if (c->taps_dev) hipFree(c->taps_dev);
+    if (c->taps_dev) (void)hipFree(c->taps_dev);
     c->taps_dev = nullptr;
     HIPC(c, hipMalloc((void**)&c->taps_dev, sizeof(ConvTaps) * D));
     HIPC(c, hipMemcpy(c->taps_dev, t.data(), sizeof(ConvTaps) * D, hipMemcpyHostToDevice));
