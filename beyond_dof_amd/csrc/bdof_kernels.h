@@ -192,13 +192,7 @@ __device__ __forceinline__ void load_obj_row(const ObjView& o, long long srow, i
     for (int m = 0; m < 8; ++m) {
         const int yg = tid + m * T + y0;
         const int yc = min(max(yg, 0), o.volNY - 1);
-#ifdef BDOF_NT_OBJ
-        typedef float nt_v2f __attribute__((ext_vector_type(2)));
-        const nt_v2f nv = __builtin_nontemporal_load((const nt_v2f*)(row + yc));
-        const float2 v = make_float2(nv.x, nv.y);
-#else
         const float2 v = row[yc];
-#endif
         const bool in = srow >= 0 && yg == yc;
         db[m] = make_float2(in ? v.x : 0.f, in ? v.y : 0.f);
     }
@@ -671,15 +665,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_bwd
             for (int m = 0; m < 8; ++m) g[m] = a.gin[off + tid + m * C::T];
             const cf* psrc = HIST == 2 ? a.tape + (size_t)x * NY : a.tape + off;      // HIST 2: `tape` is the probe [NX][NY]
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-#ifdef BDOF_NT_TAPE
-                typedef float nt_v2f __attribute__((ext_vector_type(2)));
-                const nt_v2f nv = __builtin_nontemporal_load((const nt_v2f*)(psrc + tid + m * C::T));
-                p[m] = make_float2(nv.x, nv.y);
-#else
-                p[m] = psrc[tid + m * C::T];
-#endif
-            }
+            for (int m = 0; m < 8; ++m) p[m] = psrc[tid + m * C::T];
             load_obj_row(a.obj, obj_src_row(a.obj, b, x, a.z, a.NX), y0, tid, C::T, db);
             cf pc[PF ? 8 : 1];
             if constexpr (PF) {
