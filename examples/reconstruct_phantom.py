@@ -6,7 +6,7 @@ carry: at 10 um (free_prop_cm=1e-3) 100 epochs recover delta to a correlation of
 the far field with a plane probe (one bright bin) it does not converge — properties of the measurement, the same for the
 reference.
 
-    python examples/reconstruct_phantom.py [n=128] [n_theta=60] [n_epochs=100] [learning_rate=2e-8] [free_prop_cm=1e-3]
+    python examples/reconstruct_phantom.py [n=128] [n_theta=60] [n_epochs=100] [learning_rate=2e-8] [free_prop_cm=1e-3] [minibatch=10]
 """
 import os
 import sys
@@ -32,12 +32,11 @@ def phantom(n, rng):
     return d
 
 
-def run(n=128, n_theta=60, n_epochs=100, lr=2e-8, fp=1e-3, quiet=False):
+def run(n=128, n_theta=60, n_epochs=100, lr=2e-8, fp=1e-3, quiet=False, mb=10):
     """Simulate, write exchange/data, reconstruct, compare with the phantom: returns the figures main() prints
     (tests/test_gpu_convergence.py asserts them)."""
     import contextlib
     import io
-    mb = 10
     rng = np.random.default_rng(0)
     d = phantom(n, rng)
     cwd = os.getcwd()
@@ -72,8 +71,10 @@ def main():
     lr = float(sys.argv[4]) if len(sys.argv) > 4 else 2e-8
     fp = sys.argv[5] if len(sys.argv) > 5 else '1e-3'
     fp = 'inf' if fp == 'inf' else float(fp)
-    r = run(n, n_theta, n_epochs, lr, fp)
-    print('reconstruct_fullfield {}^3, {} angles, {} epochs: {:.1f} s'.format(n, n_theta, n_epochs, r['seconds']))
+    mb = int(sys.argv[6]) if len(sys.argv) > 6 else 10
+    r = run(n, n_theta, n_epochs, lr, fp, mb=mb)
+    print('reconstruct_fullfield {}^3, {} angles, {} epochs in minibatches of {}: {:.1f} s ({:.1f} ms per Adam step, entry point to files)'.format(
+        n, n_theta, n_epochs, mb, r['seconds'], 1e3 * r['seconds'] / (n_epochs * max(1, n_theta // mb))))
     print('delta: correlation with the phantom {:.4f} (central half {:.4f}); relative L2 error {:.3f}; peak {:.3e} vs {:.3e}'.format(
         r['delta_corr'], r['delta_corr_inner'], r['delta_rel_l2'], r['delta_peak'], r['phantom_peak']))
     print('beta : correlation {:.4f}'.format(r['beta_corr']))
