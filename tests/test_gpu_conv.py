@@ -194,3 +194,43 @@ def test_reconstruct_ptychography_vs_the_reference_loop(engine_mod, tmp_path, mo
     # detector: first-minibatch gradient 1.8e-4 -> 4.9e-6, delta after the eight steps 1.6e-5, beta 3.1e-6, no voxel more than
     # 0.009 of a step away — where the transfer-function path stands with float32 adjoint arithmetic (G17: 1.7e-5).
     assert stats[0] <= 0.05 and stats[1] <= 3e-5 and stats[3] <= 1e-5 and stats[4] == 0.0, stats
+
+
+@pytest.mark.parametrize('ks,probe,shape', [(17, 'plane', (128, 128)), (17, 'random', (64, 256)), (9, 'random', (128, 64)),
+                                            (5, 'random', (64, 64)), (17, 'random', (512, 512))])
+def test_second_tiling_equals_the_first(engine_mod, monkeypatch, ks, probe, shape):
+    """k_conv2 (64 x 32 tiles by LDS-DMA, csrc/bdof_conv2.h) keeps k_conv's order of the tap sums; only the epilogue's
+    multiply-adds may be contracted differently by the compiler: forward wave, loss and gradient agree to float32 rounding,
+    incl. the tiles that touch the field's edge with a non-zero padding constant (cnn_propagator/propagation.py:80-107)."""
+    rng = np.random.default_rng(11)
+    Y, X = shape
+    B, S = (3, 5) if Y < 512 else (2, 3)
+    delta = rng.uniform(0, 2e-5, size=(B, Y, X, S))
+    beta = 0.1 * delta
+    if probe == 'plane':
+        pr, pi = np.ones((Y, X)), np.zeros((Y, X))
+    else:
+        pr, pi = 0.8 + 0.1 * rng.normal(size=(Y, X)), 0.1 * rng.normal(size=(Y, X))
+    out = {}
+    for tiling in ('1', '2'):
+        monkeypatch.setenv('BDOF_CONV_TILING', tiling)
+        eng = engine_mod.MultisliceEngine(Y, X, S, B, with_grad=True)
+        eng.set_physics(5000., 1e-7, 1e-4)
+        eng.set_conv(5000., [1e-7] * 3, ks)
+        eng.set_probe(pr, pi)
+        eng.set_object_batch(delta, beta)
+        wave = eng.forward(B, conv=True)
+        meas = np.abs(wave) * (1 + 0.05 * np.random.default_rng(5).normal(size=wave.shape))
+        if tiling == '1':
+            meas1 = meas
+        loss = eng.loss_grad(B, meas1, conv=True)
+        gd, gb = eng.grad_batch_to_host(B)
+        out[tiling] = (wave, loss, gd, gb)
+        del eng
+    w1, l1, gd1, gb1 = out['1']
+    w2, l2, gd2, gb2 = out['2']
+    assert np.isfinite(w1).all() and np.abs(w1).max() > 0
+    assert np.abs(w1 - w2).max() <= 4e-7 * np.abs(w1).max() and rel(w2, w1) <= 1e-7
+    assert abs(l1 - l2) <= 1e-6 * abs(l1)
+    assert rel(gd2, gd1) <= 2e-6 and rel(gb2, gb1) <= 2e-6
+    assert np.abs(gd1 - gd2).max() <= 1e-5 * np.abs(gd1).max()
