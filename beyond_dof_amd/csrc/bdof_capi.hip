@@ -1759,20 +1759,25 @@ static int conv_lds_bytes(const bdof_ctx* c) {
     return (TXH * (TYH | 1) + TXH * (BDOF_CONV_TY + 1)) * (int)sizeof(cf);
 }
 
-// BDOF_CONV_TILING=1 keeps the first tiling (k_conv, 32 x 64 tiles through staging registers) for every size; read at
-// every launch so that one process can run both (tests/test_gpu_conv.py compares them bit for bit)
-static bool conv_second_tiling() {
+// BDOF_CONV_TILING=1 keeps the first tiling (k_conv, 32 x 64 tiles through staging registers) for every size; read at every
+// launch so that one process can run both (tests/test_gpu_conv.py compares them)
+static int conv_tiling() {
     const char* e = getenv("BDOF_CONV_TILING");
-    return !(e && e[0] == '1');
+    return e && e[0] == '1' ? 1 : 2;
 }
 
 template <bool BWD, int H, bool PF> static int launch_conv_hp(bdof_ctx* c, ConvArgs& a, ProfScope& ps) {
     if constexpr (H == 2 || H == 4 || H == 8) {
         // second tiling (bdof_conv2.h): 64 x 32 tiles by LDS-DMA, static LDS, two workgroups per CU by registers
-        if (conv_second_tiling() && a.NX % Conv2Cfg<H>::TX == 0 && a.NY % Conv2Cfg<H>::TY == 0) {
-            const int tiles = a.B * (a.NX / Conv2Cfg<H>::TX) * (a.NY / Conv2Cfg<H>::TY);
-            const int grid = balanced_grid(c, tiles, 2);
-            BDOF_LAUNCH(ps, (k_conv2<BWD, H, PF>), dim3(grid), dim3(Conv2Cfg<H>::THREADS), 0, c->stream, a);
+        if (conv_tiling() != 1 && a.NX % Conv2Cfg<H>::TX == 0 && a.NY % Conv2Cfg<H>::TY == 0) {
+            // 8 runs of strips (bdof_conv2.h, XCD-aware order), nwg workgroups each: as few rounds as two workgroups per CU
+            // allow, and the workgroup count that fills the last round best
+            const int nstrips = a.B * (a.NX / Conv2Cfg<H>::TX);
+            const int run_tiles = ((nstrips + 7) / 8) * (a.NY / Conv2Cfg<H>::TY);
+            const int slots = std::max(1, c->ncu * 2 / 8);
+            const int rounds = (run_tiles + slots - 1) / slots;
+            const int nwg = (run_tiles + rounds - 1) / rounds;
+            BDOF_LAUNCH(ps, (k_conv2<BWD, H, PF>), dim3(8 * nwg), dim3(Conv2Cfg<H>::THREADS), 0, c->stream, a);
             return 0;
         }
     }

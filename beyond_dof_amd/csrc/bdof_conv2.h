@@ -14,6 +14,29 @@
 // Reference: cnn_propagator/propagation.py:80-107 (the convolution of one slice), :109-110 (renormalisation, k_conv_final).
 #pragma once
 
+// Loads whose results are carried into the NEXT tile are issued by asm: hipcc keeps no s_waitcnt bookkeeping for them (met
+// again across the loop's back edge and the branches of the DMA issue it can only answer with vmcnt(0), which drains the DMA
+// as soon as it is queued, or this tile's stores); the counted wait at the end of a tile retires them, and names their
+// registers so that no use moves above it.  "memory": they keep their place between the DMA and the stores.
+__device__ __forceinline__ int conv2_ld32(const int* p) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// The DMA itself is asm for the same reason: hipcc tracks a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
+// s_waitcnt vmcnt(0) in front of the next read of the destination array — at the top of a tile that also waits for the
+// previous tile's stores.  M0 (the destination base) is saved and restored around the statement (cdna_hip_programming.md).
+// lds_dst: wave-uniform LDS byte address; each lane's 16 bytes land at lds_dst + 16 * lane.
+__device__ __forceinline__ void conv2_dma16(const char* base, unsigned voff, unsigned lds_dst) {        // base uniform
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void conv2_dma16(const char* src, unsigned lds_dst) {                        // per-lane address
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
 template <int H> struct Conv2Cfg {
     static constexpr int TX = 64, TY = 32, R = 4, SM = 33, THREADS = 512;
     static constexpr int TXH = TX + 2 * H, TYH = TY + 2 * H, NP = TYH / 2, RU = NP | 1;
@@ -29,16 +52,27 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
     typedef Conv2Cfg<H> C;
     constexpr int TX = C::TX, TY = C::TY, R = C::R, TXH = C::TXH, RU = C::RU, NP = C::NP, SM = C::SM, MP = C::MP;
     typedef const __attribute__((address_space(4))) ConvTaps* TapsPtr;
-    typedef const __attribute__((address_space(1))) void* GPtr;
-    typedef __attribute__((address_space(3))) void* LPtr;
-    // two LDS objects of their own: hipcc then knows that a read of M cannot alias the DMA's destination, and does not
-    // wait for the DMA before the x pass (with one dynamic array it puts s_waitcnt vmcnt(0) in front of the first read)
     __shared__ float4 A4[C::NLOADS * 64];                    // raw halo tile [TXH][RU] units of two complex values
     __shared__ cf M[TXH * SM];                               // y-pass result [TXH][SM]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = a.NX / TX, tiles_y = a.NY / TY, tpf = tiles_x * tiles_y;
-    const int ntiles = a.B * tpf;
+    const unsigned a4_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)A4;      // LDS byte address of the raw image
+    // XCD-aware tile order.  Workgroups are dealt to the 8 XCDs round-robin (b and b + 8 share one): the strips (one row of
+    // tiles across a field; B * tiles_x of them) are split into 8 contiguous runs, one per value of blockIdx.x % 8, and the
+    // workgroups of a run walk its tiles in order — the tiles in flight on an XCD at any time are neighbours in y and x, so
+    // the halos they share (7/8 of what a tile reads beyond its own pixels) are hits in that XCD's L2 instead of second
+    // fetches through the fabric.  Placement is the dispatcher's: a different one costs speed, never correctness.
+    const int tiles_x = a.NX / TX, tiles_y = a.NY / TY;
+    const int nstrips = a.B * tiles_x;
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, nwg = gridDim.x >> 3;       // the host launches a multiple of 8
+    const int strip0 = xcd * nstrips / 8;
+    const int ntiles = ((xcd + 1) * nstrips / 8 - strip0) * tiles_y;                   // tiles of this XCD's run
+    struct TilePos { int b, x0, y0; };
+    auto tile_pos = [&](int l) -> TilePos {
+        const int s = strip0 + l / tiles_y;
+        const int b = s / tiles_x;
+        return TilePos{b, (s - b * tiles_x) * TX, (l % tiles_y) * TY};
+    };
 
     // ---- LDS-DMA plan of this lane: unit u = 64 k + lane of load k = wave + 8 m holds row i = u / RU, pair c = u % RU
     unsigned rel[MP];            // byte offset of the unit from the tile's halo origin (interior tiles)
@@ -52,8 +86,8 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
     }
     unsigned oob = 0;            // bit m: the unit of load m lies outside the field (padding constant after landing)
     auto issue = [&](int tile) {
-        const int b = tile / tpf, t2 = tile - b * tpf;
-        const int x0 = (t2 / tiles_y) * TX, y0 = (t2 % tiles_y) * TY;
+        const TilePos tp_ = tile_pos(tile);
+        const int b = tp_.b, x0 = tp_.x0, y0 = tp_.y0;
         const char* src = (const char*)(a.in + (size_t)b * a.NX * a.NY);
         const bool interior = x0 >= H && x0 + TX + H <= a.NX && y0 >= H && y0 + TY + H <= a.NY;      // uniform
         oob = 0;
@@ -62,7 +96,7 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
 #pragma unroll
             for (int m = 0; m < MP; ++m)
                 if ((act >> m) & 1u)
-                    __builtin_amdgcn_global_load_lds((GPtr)(base + rel[m]), (LPtr)(A4 + (wave + 8 * m) * 64), 16, 0, 0);
+                    conv2_dma16(base, rel[m], a4_lds + (wave + 8 * m) * 1024);
         } else {
 #pragma unroll
             for (int m = 0; m < MP; ++m) {
@@ -73,7 +107,7 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
                 const unsigned off = (__umul24(min(max(x, 0), a.NX - 1), a.NY) + min(max(y, 0), a.NY - 2)) * 8u;
                 if ((act >> m) & 1u) {
                     oob |= in ? 0u : 1u << m;
-                    __builtin_amdgcn_global_load_lds((GPtr)(src + off), (LPtr)(A4 + (wave + 8 * m) * 64), 16, 0, 0);
+                    conv2_dma16(src + off, a4_lds + (wave + 8 * m) * 1024);
                 }
             }
         }
@@ -87,10 +121,11 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
     unsigned xin = 0;
     int yo = 0;                  // window origin in y of the tile's wavefield (ptychography)
     auto request_rows = [&](int tile) {
-        const int b = tile / tpf, t2 = tile - b * tpf;
-        const int x0 = (t2 / tiles_y) * TX;
+        const TilePos tp_ = tile_pos(tile);
+        const int b = tp_.b, x0 = tp_.x0;
         xin = 0;
-        yo = a.obj.yoff ? a.obj.yoff[b] : 0;
+        yo = 0;
+        if (a.obj.yoff) yo = conv2_ld32(a.obj.yoff + b);
         if (use_tab) {
             const int xg0 = x0 + i0 + (a.obj.xoff ? a.obj.xoff[b] : 0);
             const int* tabrow = a.obj.tab + ((long long)a.obj.angle_of_b[b] * a.obj.S + a.zmod) * a.obj.volNX;
@@ -98,7 +133,7 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
             for (int q = 0; q < R; ++q) {
                 const int xg = xg0 + q;
                 xin |= (unsigned)xg < (unsigned)a.obj.volNX ? 1u << q : 0u;
-                sraw[q] = tabrow[min(max(xg, 0), a.obj.volNX - 1)];
+                sraw[q] = conv2_ld32(tabrow + min(max(xg, 0), a.obj.volNX - 1));
             }
         } else {
 #pragma unroll
@@ -107,15 +142,48 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
         }
     };
 
-    if ((int)blockIdx.x < ntiles) {
-        issue(blockIdx.x);
-        request_rows(blockIdx.x);
+    // operands of a tile's epilogue: modulation factors, tape (backward) and carrier-field plane of this thread's R outputs
+    struct Epi {
+        float2 m1[R];
+        cf tp[R], pf[R];
+        unsigned xin;      // bit q: output row q has a modulation row
+        bool yin;          // this thread's y lies inside the volume
+    };
+    // requests them for `tile` from the table rows in sraw / xin / yo (which have landed)
+    auto request_epi = [&](int tile, Epi& e) {
+        const TilePos tp_ = tile_pos(tile);
+        const int b = tp_.b, x0 = tp_.x0, y0 = tp_.y0;
+        const int y = y0 + j, yg = y + yo;
+        const int yc = min(max(yg, 0), a.obj.volNY - 1);
+        e.xin = xin;
+        e.yin = yg == yc;
+        const cf* tape_b = BWD ? a.tape + (size_t)b * a.NX * a.NY : nullptr;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            if (sraw[q] < 0) e.xin &= ~(1u << q);                          // a table entry that points nowhere
+            const unsigned off = __umul24(x0 + i0 + q, a.NY) + y;
+            e.m1[q] = a.obj.vol[(size_t)max(sraw[q], 0) * a.obj.volNY + yc];
+            if constexpr (BWD) e.tp[q] = tape_b[off];
+            if constexpr (PF) e.pf[q] = a.pfield[off];                   // L2-resident plane shared by all wavefields
+        }
+    };
+    // Order of a tile (vmcnt retires in order): operands of its epilogue | y pass | wait for them | DMA of the next halo
+    // tile | table rows of the next tile | x pass, epilogue, NS stores | vmcnt(NS): everything but the stores has retired.
+    // (Measured and dropped, round 3: the epilogue's operands of the NEXT tile prefetched behind the DMA as well — 16 to 24
+    // more live registers, fwd 46.3 -> 51 us, bwd 55.6 -> 63 us per launch of 25 fields of 512 x 512.)
+    constexpr int NS = BWD ? 2 * R : R;          // global stores of one tile's epilogue (distinct rows: never merged)
+    if (wg < ntiles) {
+        issue(wg);
+        request_rows(wg);
     }
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = tile / tpf, t2 = tile - b * tpf;
-        const int x0 = (t2 / tiles_y) * TX, y0 = (t2 % tiles_y) * TY;
-        // the halo tile has landed (and the table rows with it); outside the field the padding constant
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < R; ++q) asm volatile("" : "+v"(sraw[q]));           // no use of these moves above the wait
+    asm volatile("" : "+v"(yo));
+    for (int tile = wg; tile < ntiles; tile += nwg) {
+        const TilePos tp_ = tile_pos(tile);
+        const int b = tp_.b, x0 = tp_.x0, y0 = tp_.y0;
+        // the halo tile has landed; outside the field the padding constant
         if (oob) {
             const float4 pp = make_float4(a.pad.x, a.pad.y, a.pad.x, a.pad.y);
 #pragma unroll
@@ -123,20 +191,8 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
                 if ((oob >> m) & 1u) A4[(wave + 8 * m) * 64 + lane] = pp;
         }
         conv_sync();
-        // loads the epilogue needs, in flight during the y pass
-        const int y = y0 + j;
-        const int yg = y + yo;
-        const int yc = min(max(yg, 0), a.obj.volNY - 1);
-        float2 m1[R];
-        cf tp[R], pf[R];
-        const cf* tape_b = BWD ? a.tape + (size_t)b * a.NX * a.NY : nullptr;
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-            if (sraw[q] < 0) xin &= ~(1u << q);                          // a table entry that points nowhere
-            m1[q] = a.obj.vol[(size_t)max(sraw[q], 0) * a.obj.volNY + yc];
-            if constexpr (BWD) tp[q] = tape_b[__umul24(x0 + i0 + q, a.NY) + y];
-            if constexpr (PF) pf[q] = a.pfield[__umul24(x0 + i0 + q, a.NY) + y];       // L2-resident plane shared by all wavefields
-        }
+        Epi cur;
+        request_epi(tile, cur);         // in flight during the y pass
         TapsPtr kt = (TapsPtr)a.taps;
         asm volatile("" : "+s"(kt));
         // pass along y: lanes = 8 windows of 4 outputs along a row, then rows.  forward: o[y] = sum_d K[h+d] f[y-d]
@@ -155,17 +211,19 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
 #pragma unroll
             for (int q = 0; q < R; ++q) M[i * SM + R * w + q] = o[q];
         }
-        // the epilogue's operands are in registers before the next DMA is queued behind them (vmcnt retires in order)
+        // the epilogue's operands are in registers before the next DMA is queued behind them
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-            asm volatile("" : "+v"(m1[q].x), "+v"(m1[q].y));
-            if constexpr (BWD) asm volatile("" : "+v"(tp[q].x), "+v"(tp[q].y));
-            if constexpr (PF) asm volatile("" : "+v"(pf[q].x), "+v"(pf[q].y));
+            asm volatile("" : "+v"(cur.m1[q].x), "+v"(cur.m1[q].y));
+            if constexpr (BWD) asm volatile("" : "+v"(cur.tp[q].x), "+v"(cur.tp[q].y));
+            if constexpr (PF) asm volatile("" : "+v"(cur.pf[q].x), "+v"(cur.pf[q].y));
         }
         conv_sync();
-        const unsigned xin_t = xin;
-        const int next = tile + gridDim.x;
-        if (next < ntiles) issue(next);                 // A is free: in flight during the x pass and the epilogue
+        const int next = tile + nwg;
+        if (next < ntiles) {
+            issue(next);                 // A is free: in flight during the x pass and the epilogue
+            request_rows(next);
+        }
         asm volatile("" : "+s"(kt));
         // pass along x (window of R consecutive x for one y), then the pointwise physics
         {
@@ -177,25 +235,30 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
 #pragma unroll
             for (int q = 0; q < R + 2 * H; ++q) win[q] = M[(i0 + q) * SM + j];
             conv_window<BWD, H, R>(win, kt->kx, o);
+            const int y = y0 + j;
 #pragma unroll
             for (int q = 0; q < R; ++q) {
                 const cf acc = BWD ? cmulc(o[q], ke) : cmul(o[q], ke);
                 const int x = x0 + i0 + q;
                 const unsigned off = __umul24(x, a.NY) + y;
-                const bool in = ((xin_t >> q) & 1u) && yg == yc;
-                const float2 mm = make_float2(in ? m1[q].x : 0.f, in ? m1[q].y : 0.f);
+                const bool in = ((cur.xin >> q) & 1u) && cur.yin;
+                const float2 mm = make_float2(in ? cur.m1[q].x : 0.f, in ? cur.m1[q].y : 0.f);
                 cf car = a.carrier;
-                if constexpr (PF) car = pf[q];
+                if constexpr (PF) car = cur.pf[q];
                 if constexpr (!BWD) {
                     out_b[off] = modulate_eps(acc, car, mm);
                 } else {
-                    const cf phi = cadd(tp[q], car);
+                    const cf phi = cadd(cur.tp[q], car);
                     const cf tt = cmulc(acc, phi);
                     grot_b[off] = make_float2(a.k * tt.y, -a.k * tt.x);
                     out_b[off] = cmulc(acc, make_float2(1.f + mm.x, mm.y));
                 }
             }
         }
-        if (next < ntiles) request_rows(next);
+        // everything queued before this tile's NS stores has retired: the next halo tile and its table rows
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+#pragma unroll
+        for (int q = 0; q < R; ++q) asm volatile("" : "+v"(sraw[q]));
+        asm volatile("" : "+v"(yo));
     }
 }

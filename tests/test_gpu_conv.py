@@ -228,9 +228,10 @@ def test_second_tiling_equals_the_first(engine_mod, monkeypatch, ks, probe, shap
         out[tiling] = (wave, loss, gd, gb)
         del eng
     w1, l1, gd1, gb1 = out['1']
-    w2, l2, gd2, gb2 = out['2']
     assert np.isfinite(w1).all() and np.abs(w1).max() > 0
-    assert np.abs(w1 - w2).max() <= 4e-7 * np.abs(w1).max() and rel(w2, w1) <= 1e-7
-    assert abs(l1 - l2) <= 1e-6 * abs(l1)
-    assert rel(gd2, gd1) <= 2e-6 and rel(gb2, gb1) <= 2e-6
-    assert np.abs(gd1 - gd2).max() <= 1e-5 * np.abs(gd1).max()
+    for tiling in ('2',):
+        w2, l2, gd2, gb2 = out[tiling]
+        assert np.abs(w1 - w2).max() <= 4e-7 * np.abs(w1).max() and rel(w2, w1) <= 1e-7
+        assert abs(l1 - l2) <= 1e-6 * abs(l1)
+        assert rel(gd2, gd1) <= 2e-6 and rel(gb2, gb1) <= 2e-6
+        assert np.abs(gd1 - gd2).max() <= 1e-5 * np.abs(gd1).max()
