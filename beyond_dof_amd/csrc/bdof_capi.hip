@@ -1770,14 +1770,16 @@ template <bool BWD, int H, bool PF> static int launch_conv_hp(bdof_ctx* c, ConvA
     if constexpr (H == 2 || H == 4 || H == 8) {
         // second tiling (bdof_conv2.h): 64 x 32 tiles by LDS-DMA, static LDS, two workgroups per CU by registers
         if (conv_tiling() != 1 && a.NX % Conv2Cfg<H>::TX == 0 && a.NY % Conv2Cfg<H>::TY == 0) {
-            // 8 runs of strips (bdof_conv2.h, XCD-aware order), nwg workgroups each: as few rounds as two workgroups per CU
+            // 8 runs of strips (bdof_conv2.h, XCD-aware order), nwg workgroups each: as few rounds as the workgroups per CU
             // allow, and the workgroup count that fills the last round best
-            const int nstrips = a.B * (a.NX / Conv2Cfg<H>::TX);
-            const int run_tiles = ((nstrips + 7) / 8) * (a.NY / Conv2Cfg<H>::TY);
-            const int slots = std::max(1, c->ncu * 2 / 8);
-            const int rounds = (run_tiles + slots - 1) / slots;
-            const int nwg = (run_tiles + rounds - 1) / rounds;
-            BDOF_LAUNCH(ps, (k_conv2<BWD, H, PF>), dim3(8 * nwg), dim3(Conv2Cfg<H>::THREADS), 0, c->stream, a);
+            auto plan = [&](int tx, int per_cu) {
+                const int nstrips = a.B * (a.NX / tx);
+                const int run_tiles = ((nstrips + 7) / 8) * (a.NY / Conv2Cfg<H>::TY);
+                const int slots = std::max(1, c->ncu * per_cu / 8);
+                const int rounds = (run_tiles + slots - 1) / slots;
+                return 8 * ((run_tiles + rounds - 1) / rounds);
+            };
+            BDOF_LAUNCH(ps, (k_conv2<BWD, H, PF>), dim3(plan(Conv2Cfg<H>::TX, 2)), dim3(Conv2Cfg<H>::THREADS), 0, c->stream, a);
             return 0;
         }
     }

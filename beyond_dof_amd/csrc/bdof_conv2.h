@@ -37,19 +37,22 @@ __device__ __forceinline__ void conv2_dma16(const char* src, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
-template <int H> struct Conv2Cfg {
-    static constexpr int TX = 64, TY = 32, R = 4, SM = 33, THREADS = 512;
+// TXV: rows of a tile.  64 (512 threads, two workgroups per CU) is what runs; 32 (256 threads, four workgroups per CU: more
+// halo per output, twice as many independent pipelines per CU) was measured slower, 47.0 / 54.5 against 45.0 / 53.6 us
+template <int H, int TXV = 64> struct Conv2Cfg {
+    static constexpr int TX = TXV, TY = 32, R = 4, SM = 33, THREADS = TX * TY / R, NW = THREADS / 64;
     static constexpr int TXH = TX + 2 * H, TYH = TY + 2 * H, NP = TYH / 2, RU = NP | 1;
-    static constexpr int UNITS = TXH * RU, NLOADS = (UNITS + 63) / 64, MP = (NLOADS + 7) / 8;
+    static constexpr int UNITS = TXH * RU, NLOADS = (UNITS + 63) / 64, MP = (NLOADS + NW - 1) / NW;
     static constexpr int A_BYTES = NLOADS * 1024, M_BYTES = TXH * SM * 8, LDS = A_BYTES + M_BYTES;
     static constexpr int MINW = 4;
     static_assert(H % 2 == 0 && NP % 2 == 0, "halo of even width: 16-byte units must not straddle the field's edge");
     static_assert(TX * TY == THREADS * R, "one x-pass window per thread");
 };
 
-template <bool BWD, int H, bool PF = false>
-__global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_conv2(ConvArgs a) {
-    typedef Conv2Cfg<H> C;
+template <bool BWD, int H, bool PF = false, int TXV = 64>
+__global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MINW)) void k_conv2(ConvArgs a) {
+    typedef Conv2Cfg<H, TXV> C;
+    constexpr int NW = C::NW;
     constexpr int TX = C::TX, TY = C::TY, R = C::R, TXH = C::TXH, RU = C::RU, NP = C::NP, SM = C::SM, MP = C::MP;
     typedef const __attribute__((address_space(4))) ConvTaps* TapsPtr;
     __shared__ float4 A4[C::NLOADS * 64];                    // raw halo tile [TXH][RU] units of two complex values
@@ -74,15 +77,15 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
         return TilePos{b, (s - b * tiles_x) * TX, (l % tiles_y) * TY};
     };
 
-    // ---- LDS-DMA plan of this lane: unit u = 64 k + lane of load k = wave + 8 m holds row i = u / RU, pair c = u % RU
+    // ---- LDS-DMA plan of this lane: unit u = 64 k + lane of load k = wave + NW m holds row i = u / RU, pair c = u % RU
     unsigned rel[MP];            // byte offset of the unit from the tile's halo origin (interior tiles)
     unsigned act = 0;            // bit m: the lane takes part in load m
 #pragma unroll
     for (int m = 0; m < MP; ++m) {
-        const int u = (wave + 8 * m) * 64 + lane;
+        const int u = (wave + NW * m) * 64 + lane;
         const int i = u / RU, c = u - i * RU;
         rel[m] = (unsigned)(min(i, TXH - 1) * a.NY + 2 * min(c, NP - 1)) * 8u;
-        act |= (wave + 8 * m < C::NLOADS && i < TXH && c < NP) ? 1u << m : 0u;
+        act |= (wave + NW * m < C::NLOADS && i < TXH && c < NP) ? 1u << m : 0u;
     }
     unsigned oob = 0;            // bit m: the unit of load m lies outside the field (padding constant after landing)
     auto issue = [&](int tile) {
@@ -96,18 +99,18 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
 #pragma unroll
             for (int m = 0; m < MP; ++m)
                 if ((act >> m) & 1u)
-                    conv2_dma16(base, rel[m], a4_lds + (wave + 8 * m) * 1024);
+                    conv2_dma16(base, rel[m], a4_lds + (wave + NW * m) * 1024);
         } else {
 #pragma unroll
             for (int m = 0; m < MP; ++m) {
-                const int u = (wave + 8 * m) * 64 + lane;
+                const int u = (wave + NW * m) * 64 + lane;
                 const int i = u / RU, c = u - i * RU;
                 const int x = x0 - H + i, y = y0 - H + 2 * c;
                 const bool in = (unsigned)x < (unsigned)a.NX && (unsigned)y < (unsigned)a.NY;
                 const unsigned off = (__umul24(min(max(x, 0), a.NX - 1), a.NY) + min(max(y, 0), a.NY - 2)) * 8u;
                 if ((act >> m) & 1u) {
                     oob |= in ? 0u : 1u << m;
-                    conv2_dma16(src + off, a4_lds + (wave + 8 * m) * 1024);
+                    conv2_dma16(src + off, a4_lds + (wave + NW * m) * 1024);
                 }
             }
         }
@@ -170,7 +173,8 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
     // Order of a tile (vmcnt retires in order): operands of its epilogue | y pass | wait for them | DMA of the next halo
     // tile | table rows of the next tile | x pass, epilogue, NS stores | vmcnt(NS): everything but the stores has retired.
     // (Measured and dropped, round 3: the epilogue's operands of the NEXT tile prefetched behind the DMA as well — 16 to 24
-    // more live registers, fwd 46.3 -> 51 us, bwd 55.6 -> 63 us per launch of 25 fields of 512 x 512.)
+    // more live registers, fwd 46.3 -> 51 us, bwd 55.6 -> 63 us per launch of 25 fields of 512 x 512; the arguments read
+    // through a laundered kernarg pointer instead of SGPRs spilled to VGPR lanes — 69 v_readlane per tile gone, same time.)
     constexpr int NS = BWD ? 2 * R : R;          // global stores of one tile's epilogue (distinct rows: never merged)
     if (wg < ntiles) {
         issue(wg);
@@ -183,16 +187,17 @@ __global__ __launch_bounds__(Conv2Cfg<H>::THREADS, Conv2Cfg<H>::MINW) void k_con
     for (int tile = wg; tile < ntiles; tile += nwg) {
         const TilePos tp_ = tile_pos(tile);
         const int b = tp_.b, x0 = tp_.x0, y0 = tp_.y0;
+        // the epilogue's operands: requested first, in flight across the barrier and the y pass
+        Epi cur;
+        request_epi(tile, cur);
         // the halo tile has landed; outside the field the padding constant
         if (oob) {
             const float4 pp = make_float4(a.pad.x, a.pad.y, a.pad.x, a.pad.y);
 #pragma unroll
             for (int m = 0; m < MP; ++m)
-                if ((oob >> m) & 1u) A4[(wave + 8 * m) * 64 + lane] = pp;
+                if ((oob >> m) & 1u) A4[(wave + NW * m) * 64 + lane] = pp;
         }
         conv_sync();
-        Epi cur;
-        request_epi(tile, cur);         // in flight during the y pass
         TapsPtr kt = (TapsPtr)a.taps;
         asm volatile("" : "+s"(kt));
         // pass along y: lanes = 8 windows of 4 outputs along a row, then rows.  forward: o[y] = sum_d K[h+d] f[y-d]

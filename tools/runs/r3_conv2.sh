@@ -3,7 +3,7 @@
 out=gpurun_out/r3_conv2; mkdir -p $out
 timeout -k 10 500 python -m pytest tests/test_gpu_conv.py -q -x > $out/tests.log 2>&1; rc=$?; echo "conv tests rc $rc"; tail -n 5 $out/tests.log
 [ $rc = 0 ] || exit 1
-for t in 1 2 1 2; do
+for t in 1 2 2; do
   BDOF_CONV_TILING=$t timeout -k 10 200 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --propagator conv > $out/bench_t$t.json 2> $out/bench_t$t.err || exit 1
   python - <<PY
 import json
