@@ -49,6 +49,16 @@ template <int H, int TXV = 64> struct Conv2Cfg {
     static_assert(TX * TY == THREADS * R, "one x-pass window per thread");
 };
 
+// In-kernel phase stamps (tools/kbench_conv2.hip builds with -DBDOF_CONV2_STAMP): wave 0 of every workgroup adds the
+// cycles (s_memtime) it spent in each phase of its tiles to g_conv2_stamp[phase]; compiled out of the library.
+#ifdef BDOF_CONV2_STAMP
+__device__ unsigned long long g_conv2_stamp[8];
+#define CONV2_STAMP(k) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                            st_acc[k] += t_ - st_t; st_t = t_; } while (0)
+#else
+#define CONV2_STAMP(k) do { } while (0)
+#endif
+
 template <bool BWD, int H, bool PF = false, int TXV = 64>
 __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MINW)) void k_conv2(ConvArgs a) {
     typedef Conv2Cfg<H, TXV> C;
@@ -184,6 +194,9 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
 #pragma unroll
     for (int q = 0; q < R; ++q) asm volatile("" : "+v"(sraw[q]));           // no use of these moves above the wait
     asm volatile("" : "+v"(yo));
+#ifdef BDOF_CONV2_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t = __builtin_amdgcn_s_memtime();
+#endif
     for (int tile = wg; tile < ntiles; tile += nwg) {
         const TilePos tp_ = tile_pos(tile);
         const int b = tp_.b, x0 = tp_.x0, y0 = tp_.y0;
@@ -197,7 +210,9 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
             for (int m = 0; m < MP; ++m)
                 if ((oob >> m) & 1u) A4[(wave + NW * m) * 64 + lane] = pp;
         }
+        CONV2_STAMP(0);          // operand requests, padding patch
         conv_sync();
+        CONV2_STAMP(1);          // barrier: the other waves' DMA pieces
         TapsPtr kt = (TapsPtr)a.taps;
         asm volatile("" : "+s"(kt));
         // pass along y: lanes = 8 windows of 4 outputs along a row, then rows.  forward: o[y] = sum_d K[h+d] f[y-d]
@@ -216,6 +231,7 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
 #pragma unroll
             for (int q = 0; q < R; ++q) M[i * SM + R * w + q] = o[q];
         }
+        CONV2_STAMP(2);          // y pass
         // the epilogue's operands are in registers before the next DMA is queued behind them
 #pragma unroll
         for (int q = 0; q < R; ++q) {
@@ -223,12 +239,15 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
             if constexpr (BWD) asm volatile("" : "+v"(cur.tp[q].x), "+v"(cur.tp[q].y));
             if constexpr (PF) asm volatile("" : "+v"(cur.pf[q].x), "+v"(cur.pf[q].y));
         }
+        CONV2_STAMP(3);          // wait for the epilogue's operands
         conv_sync();
+        CONV2_STAMP(4);          // barrier: M complete
         const int next = tile + nwg;
         if (next < ntiles) {
             issue(next);                 // A is free: in flight during the x pass and the epilogue
             request_rows(next);
         }
+        CONV2_STAMP(5);          // DMA issue
         asm volatile("" : "+s"(kt));
         // pass along x (window of R consecutive x for one y), then the pointwise physics
         {
@@ -260,10 +279,16 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
                 }
             }
         }
+        CONV2_STAMP(6);          // x pass, epilogue, stores issued
         // everything queued before this tile's NS stores has retired: the next halo tile and its table rows
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+        CONV2_STAMP(7);          // wait for the next halo tile
 #pragma unroll
         for (int q = 0; q < R; ++q) asm volatile("" : "+v"(sraw[q]));
         asm volatile("" : "+v"(yo));
     }
+#ifdef BDOF_CONV2_STAMP
+    if (tid == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_conv2_stamp[k], st_acc[k]);
+#endif
 }
