@@ -298,7 +298,7 @@ class RcclComm(object):
             self._destroy()
         lib = ctx.lib
         where = [tuple(w) for w in self.group.allgather([socket.gethostname(), int(ctx.device)])]
-        if len(set(where)) != len(where):
+        if len(set(where)) != len(where) and not os.environ.get('BDOF_RCCL_LIB'):       # a stand-in library (tests) may share a GPU
             raise RuntimeError('RCCL needs one device per rank, got {} — rehearse several ranks on one GPU with '
                                'BDOF_COMM_BACKEND=gloo'.format(where))
         uid = ctypes.create_string_buffer(128)

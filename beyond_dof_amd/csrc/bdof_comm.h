@@ -10,6 +10,7 @@
 // communicator's stream.  bdof_comm_wait(ctx, ticket) makes the ctx stream wait for it.  No host synchronisation: the
 // producer of the next slab and the consumer of the previous one keep running while a slab is on the wire.
 #pragma once
+#include <cstdlib>
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -35,11 +36,22 @@ static RcclApi g_rccl;
 
 static bool rccl_load() {
     if (g_rccl.dl) return true;
+    // BDOF_RCCL_LIB names the library to bind instead (tests/rccl_stub: a stand-in that lets several ranks share one GPU, so
+    // that this file's callers run with nranks > 1 on a single-GPU box); RTLD_LOCAL there: its nccl* symbols stay private
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* dl = nullptr;
+    const char* over = getenv("BDOF_RCCL_LIB");
+    if (over && over[0]) {
+        dl = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!dl) {
+            const char* e = dlerror();
+            g_rccl.err = std::string("dlopen(BDOF_RCCL_LIB=") + over + ") failed: " + (e ? e : "?");
+            return false;
+        }
+    }
     for (const char* n : names) {
-        dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (dl) break;
+        dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     }
     if (!dl) {
         const char* e = dlerror();

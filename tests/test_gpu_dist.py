@@ -27,19 +27,30 @@ def _launch_two(worker, *args, **kw):
     port = _free_port()
     procs = []
     backend = kw.get('backend', 'gloo')
+    stub = kw.get('stub')
     for rank in range(2):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
-                   LOCAL_RANK=str(rank), BDOF_COMM_BACKEND=backend)
+                   LOCAL_RANK='0' if stub else str(rank), BDOF_COMM_BACKEND=backend)
         if backend == 'rccl':
             env['BDOF_RDZV'] = os.path.join(str(args[0]), 'rdzv_{}.sock'.format(port))
             env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if stub:
+            env['BDOF_RCCL_LIB'] = stub
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', worker)] + [str(a) for a in args],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     return procs
 
 
-def _run_two_ranks(tmp_path, sharded, backend='gloo'):
-    procs = _launch_two('_dist_gpu_worker.py', tmp_path, int(sharded), backend=backend)
+def _build_rccl_stub(tmp_path):
+    """tests/rccl_stub/rccl_stub.cpp -> a shared library with librccl's eight entry points the product binds."""
+    out = os.path.join(str(tmp_path), 'librccl_stub.so')
+    subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '-O2', '-std=c++17', '-shared', '-fPIC', '-o', out,
+                           os.path.join(ROOT, 'tests', 'rccl_stub', 'rccl_stub.cpp'), '-I/opt/rocm/include'])
+    return out
+
+
+def _run_two_ranks(tmp_path, sharded, backend='gloo', stub=None):
+    procs = _launch_two('_dist_gpu_worker.py', tmp_path, int(sharded), backend=backend, stub=stub)
     outs = []
     for p in procs:
         try:
@@ -107,6 +118,24 @@ def test_two_ranks_on_two_gpus_through_rccl(tmp_path):
     for sharded in (False, True):
         g0, g1 = _run_two_ranks(tmp_path, sharded, backend='gloo')
         r0, r1 = _run_two_ranks(tmp_path, sharded, backend='rccl')
+        for k in ('d', 'b', 'gd', 'gb'):
+            assert np.array_equal(r0[k], r1[k]), (sharded, k)          # both ranks end alike
+            assert np.array_equal(r0[k], g0[k]), (sharded, k)          # and like the gloo run
+        assert np.allclose(r0['losses'], g0['losses'], rtol=0, atol=0)
+
+
+def test_two_ranks_on_one_gpu_through_the_library_collectives(tmp_path):
+    """The same product path as the test above — RcclComm: socket rendezvous, bdof_comm_create, reduce-scatter / all-gather
+    in place at rank * count offsets, tickets on the communicator's stream (cnn_propagator/fullfield.py:343-353) — with
+    nranks = 2 on ONE GPU: librccl is replaced by tests/rccl_stub (NCCL's semantics over shared memory, sums in rank order),
+    because RCCL itself refuses two ranks on one device.  Everything on the library's side of the nccl* calls runs as it
+    will on a multi-GPU node; the results equal the gloo rehearsal bit for bit in both forms of the exchange."""
+    import __graft_entry__ as entry
+    entry.build()
+    stub = _build_rccl_stub(tmp_path)
+    for sharded in (False, True):
+        g0, g1 = _run_two_ranks(tmp_path, sharded, backend='gloo')
+        r0, r1 = _run_two_ranks(tmp_path, sharded, backend='rccl', stub=stub)
         for k in ('d', 'b', 'gd', 'gb'):
             assert np.array_equal(r0[k], r1[k]), (sharded, k)          # both ranks end alike
             assert np.array_equal(r0[k], g0[k]), (sharded, k)          # and like the gloo run
