@@ -322,8 +322,10 @@ def main():
 
     comm = get_comm()                      # N > 1: RcclComm (RCCL behind the C ABI); BDOF_COMM_BACKEND=gloo: rehearsal
     device = local_rank
-    if world > 1 and comm_backend() == 'gloo':
-        device = local_rank % max(1, _lib.load().bdof_device_count())     # several rehearsal ranks may share one GPU
+    if world > 1 and (comm_backend() == 'gloo' or os.environ.get('BDOF_RCCL_LIB')):
+        # several rehearsal ranks may share one GPU: through gloo, or through the library's own collectives bound to a stand-in
+        # for librccl (tests/rccl_stub; RCCL itself refuses two ranks on one device)
+        device = local_rank % max(1, _lib.load().bdof_device_count())
 
     n, mb, n_theta = args.size, args.angles_per_gpu, args.n_theta
     sched = minibatch_schedule(n_theta, world, mb, rng=np.random.default_rng(1234))

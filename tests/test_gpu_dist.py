@@ -142,6 +142,29 @@ def test_two_ranks_on_one_gpu_through_the_library_collectives(tmp_path):
         assert np.allclose(r0['losses'], g0['losses'], rtol=0, atol=0)
 
 
+def test_bench_with_two_ranks_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` as the driver starts it (self-launch, socket rendezvous, RcclComm, tail tuning, barrier, max
+    over ranks, one JSON line from rank 0) on a single GPU, the collectives bound to tests/rccl_stub: a rehearsal of the
+    first N > 1 bench run at a small size."""
+    import json
+    import __graft_entry__ as entry
+    entry.build()
+    env = dict(os.environ, BDOF_RCCL_LIB=_build_rccl_stub(tmp_path), BDOF_STUB_SLOT_MB='128')
+    env.pop('BDOF_COMM_BACKEND', None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--size', '128', '--angles-per-gpu', '4',
+                        '--n-theta', '16', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-profile'],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-4000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['value'] > 0 and d['scaling'] == 'weak'
+    assert 'rccl' in d['config']['exchange'].lower() or 'reduce' in d['config']['exchange'].lower(), d['config']['exchange']
+    assert d['config']['exchange_ms'] > 0
+    err = p.stderr.decode()
+    assert 'rccl communicator of 2 ranks ready' in err          # one line per rank with its device (comm.RcclComm.attach)
+
+
 def test_two_rank_ptychography_matches_the_union_minibatch(tmp_path):
     """Probe positions sharded over two ranks (cnn_propagator/ptychography.py:292-306): window/rotation adjoint, exchange and
     Adam through PtychoSolver.step in both forms of the exchange, against one rank holding all positions."""
