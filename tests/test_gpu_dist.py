@@ -165,6 +165,26 @@ def test_bench_with_two_ranks_on_one_gpu(tmp_path):
     assert 'rccl communicator of 2 ranks ready' in err          # one line per rank with its device (comm.RcclComm.attach)
 
 
+def _run_two_ptycho_ranks(tmp_path, sharded, backend='gloo', stub=None):
+    procs = _launch_two('_dist_ptycho_worker.py', tmp_path, int(sharded), backend=backend, stub=stub)
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), '\n'.join(o[-3000:] for o in outs)
+    return [np.load(str(tmp_path / 'pty{}_{}.npz'.format(r, int(sharded)))) for r in range(2)]
+
+
+def test_two_rank_ptychography_through_the_library_collectives(tmp_path):
+    """Probe positions sharded over two ranks (cnn_propagator/ptychography.py:292-306) through RcclComm and the library's
+    collectives bound to tests/rccl_stub, on one GPU: the volumes of the gloo rehearsal, bit for bit, in both forms."""
+    import __graft_entry__ as entry
+    entry.build()
+    stub = _build_rccl_stub(tmp_path)
+    for sharded in (False, True):
+        g0, _ = _run_two_ptycho_ranks(tmp_path, sharded)
+        r0, r1 = _run_two_ptycho_ranks(tmp_path, sharded, backend='rccl', stub=stub)
+        assert np.array_equal(r0['d'], r1['d']) and np.array_equal(r0['b'], r1['b'])
+        assert np.array_equal(r0['d'], g0['d']) and np.array_equal(r0['b'], g0['b'])
+
+
 def test_two_rank_ptychography_matches_the_union_minibatch(tmp_path):
     """Probe positions sharded over two ranks (cnn_propagator/ptychography.py:292-306): window/rotation adjoint, exchange and
     Adam through PtychoSolver.step in both forms of the exchange, against one rank holding all positions."""
