@@ -88,8 +88,13 @@ def test_no_spill_under_restricted_exec():
     import sys
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import check_spills
-    hits = check_spills.scan(check_spills.device_isa())
+    isa = check_spills.device_isa()
+    hits = check_spills.scan(isa)
     assert not hits, hits[:5]
+    # the same listing: k_conv2's counted wait (csrc/bdof_conv2.h) — `s_waitcnt vmcnt(N)` by asm at the end of a tile means
+    # "everything but this tile's N stores has retired" only if the N youngest vector-memory operations there are stores
+    bad, n = check_spills.scan_counted_waits(isa)
+    assert n >= 12 and not bad, (n, bad[:5])          # 3 tap counts x forward / backward x scalar / field carrier
 
 
 @pytest.mark.parametrize('n', [64, 512, 1024])
@@ -122,3 +127,23 @@ def test_dithered_twiddle_tables(built_lib, n):
     one = np.zeros((1, 2, n, 2), dtype=np.float32)
     assert built_lib.bdof_twiddle_tables(n, 0, one.ctypes.data_as(ctypes.c_void_p)) == 0
     assert (np.abs(one[0, 0].astype(np.float64) - exact) / ulp).max() > 0.4
+
+
+def test_counted_wait_scanner_flags_a_wait_not_backed_by_stores():
+    """tools/check_spills.scan_counted_waits on a made-up listing: two stores before vmcnt(2) pass, a load among them or a block
+    boundary before the second store is reported."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_spills
+    head = '_Z7k_conv2ILb0ELi8ELb0ELi64EEv8ConvArgs:  ; @k\n.LBB0_1:\n'
+    wait = '\t;;#ASMSTART\n\ts_waitcnt vmcnt(2)\n\t;;#ASMEND\n'
+    good = head + '\tglobal_store_dwordx2 v[0:1], v[2:3], off\n\tv_add_u32_e32 v0, v1, v2\n\tglobal_store_dwordx2 v[4:5], v[2:3], off\n' + wait
+    assert check_spills.scan_counted_waits(good) == ([], 1)
+    load = head + '\tglobal_store_dwordx2 v[0:1], v[2:3], off\n\tglobal_load_dword v9, v[2:3], off\n\tglobal_store_dwordx2 v[4:5], v[2:3], off\n' + wait
+    bad, n = check_spills.scan_counted_waits(load)
+    assert n == 1 and len(bad) == 1 and 'global_load_dword' in bad[0][2]
+    split = head + '\tglobal_store_dwordx2 v[0:1], v[2:3], off\n.LBB0_2:\n\tglobal_store_dwordx2 v[4:5], v[2:3], off\n' + wait
+    bad, n = check_spills.scan_counted_waits(split)
+    assert len(bad) == 1 and 'only 1' in bad[0][2]
+    none = head + '\tglobal_store_dwordx2 v[0:1], v[2:3], off\n\ts_endpgm\n'
+    assert check_spills.scan_counted_waits(none)[0] == [('_Z7k_conv2ILb0ELi8ELb0ELi64EEv8ConvArgs', 0, 'no counted wait found')]

@@ -69,13 +69,67 @@ def scan(isa):
     return hits
 
 
+VMEM = ('global_', 'scratch_', 'buffer_', 'flat_')
+
+
+def scan_counted_waits(isa, kernel_substr='k_conv2'):
+    """The counted wait of k_conv2 (csrc/bdof_conv2.h): `s_waitcnt vmcnt(N)` at the end of a tile, issued by asm, stands for "all
+    vector-memory operations but this tile's N stores have retired" — true only if the N youngest operations at that point ARE
+    stores.  Returns [(kernel, line, why)] for every asm `s_waitcnt vmcnt(N > 0)` of such a kernel that is not directly preceded,
+    within its basic block, by at least N vector-memory instructions that are all global stores; and an entry for every such
+    kernel that has no counted wait at all.  hipcc is free to merge, split or move memory operations: this is the check that it
+    has not."""
+    hits = []
+    lines = isa.splitlines()
+    kernel, start = None, 0
+    found = {}
+    for ln, line in enumerate(lines):
+        m = KERNEL.match(line)
+        if m:
+            kernel, start = m.group(1), ln
+            if kernel_substr in kernel:
+                found.setdefault(kernel, 0)
+            continue
+        if kernel is None or kernel_substr not in kernel:
+            continue
+        t = line.strip()
+        m = re.match(r's_waitcnt vmcnt\((\d+)\)$', t)
+        if not m or int(m.group(1)) == 0 or ln == 0 or 'ASMSTART' not in lines[ln - 1]:
+            continue
+        n = int(m.group(1))
+        found[kernel] += 1
+        seen = 0
+        why = None
+        for back in range(ln - 1, start, -1):
+            b = lines[back].strip()
+            if LABEL.match(lines[back]):
+                why = 'only {} vector-memory instructions between the block\'s start and vmcnt({})'.format(seen, n)
+                break
+            if b.startswith(VMEM):
+                if not b.startswith('global_store'):
+                    why = 'a {} among the {} youngest vector-memory instructions before vmcnt({})'.format(b.split()[0], n, n)
+                    break
+                seen += 1
+                if seen == n:
+                    break
+        if why:
+            hits.append((kernel, ln + 1, why))
+    hits += [(k, 0, 'no counted wait found') for k, c in found.items() if c == 0]
+    return hits, len(found)
+
+
 def main():
-    hits = scan(device_isa(sys.argv[1:] or None))
+    isa = device_isa(sys.argv[1:] or None)
+    bad, n = scan_counted_waits(isa)
+    for kernel, ln, why in bad:
+        print('{}: line {}: {}'.format(kernel, ln, why))
+    print('{} counted wait(s) of {} k_conv2 instance(s) not backed by their stores'.format(len(bad), n))
+    hits = scan(isa)
     for kernel, ln, text in hits:
         dem = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-cxxfilt', kernel], stdout=subprocess.PIPE).stdout.decode().strip() or kernel
         print('{}: line {}: {}'.format(dem, ln, text))
     print('{} spill(s) under a restricted exec mask'.format(len(hits)))
-    return 1 if hits else 0
+    return 1 if hits or bad else 0
 
 
 if __name__ == '__main__':
