@@ -186,6 +186,8 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
     // more live registers, fwd 46.3 -> 51 us, bwd 55.6 -> 63 us per launch of 25 fields of 512 x 512; the arguments read
     // through a laundered kernarg pointer instead of SGPRs spilled to VGPR lanes — 69 v_readlane per tile gone, same time.)
     constexpr int NS = BWD ? 2 * R : R;          // global stores of one tile's epilogue (distinct rows: never merged)
+    // (that the NS youngest vector-memory operations before the wait ARE stores is checked on the ISA of every instance by
+    // tools/check_spills.py: scan_counted_waits, part of the CPU test suite)
     if (wg < ntiles) {
         issue(wg);
         request_rows(wg);
