@@ -32,7 +32,7 @@ def phantom(n, rng):
     return d
 
 
-def run(n=128, n_theta=60, n_epochs=100, lr=2e-8, fp=1e-3, quiet=False, mb=10):
+def run(n=128, n_theta=60, n_epochs=100, lr=2e-8, fp=1e-3, quiet=False, mb=10, propagator='fft'):
     """Simulate, write exchange/data, reconstruct, compare with the phantom: returns the figures main() prints
     (tests/test_gpu_convergence.py asserts them)."""
     import contextlib
@@ -42,7 +42,7 @@ def run(n=128, n_theta=60, n_epochs=100, lr=2e-8, fp=1e-3, quiet=False, mb=10):
     cwd = os.getcwd()
     with tempfile.TemporaryDirectory() as td:
         os.chdir(td)
-        s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=fp)
+        s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=fp, propagator=propagator)
         s.set_volume(d, 0.1 * d)
         prj = s.forward_angles(np.arange(n_theta))
         del s
@@ -53,7 +53,7 @@ def run(n=128, n_theta=60, n_epochs=100, lr=2e-8, fp=1e-3, quiet=False, mb=10):
             rd, rb = reconstruct_fullfield('data.h5', theta_st=0, theta_end=2 * np.pi, n_epochs=n_epochs, learning_rate=lr,
                                            minibatch_size=mb, energy_ev=5000, psize_cm=1e-7, free_prop_cm=fp, save_path='case',
                                            output_folder='out', shrink_cycle=None, seed=3, alpha_d=1e-9, alpha_b=1e-10, gamma=0,
-                                           initial_guess=[np.zeros_like(d), np.zeros_like(d)])
+                                           initial_guess=[np.zeros_like(d), np.zeros_like(d)], propagator=propagator)
         dt = time.time() - t0
         os.chdir(cwd)
     inner = (slice(n // 4, -n // 4),) * 3
