@@ -1779,7 +1779,7 @@ template <bool BWD, int H, bool PF> static int launch_conv_hp(bdof_ctx* c, ConvA
                 const int rounds = (run_tiles + slots - 1) / slots;
                 return 8 * ((run_tiles + rounds - 1) / rounds);
             };
-            BDOF_LAUNCH(ps, (k_conv2<BWD, H, PF>), dim3(plan(Conv2Cfg<H>::TX, 2)), dim3(Conv2Cfg<H>::THREADS), 0, c->stream, a);
+            BDOF_LAUNCH(ps, (k_conv2<BWD, H, PF>), dim3(plan(Conv2Cfg<H>::TX, 2)), dim3(Conv2Cfg<H>::THREADS), 0, c->sub_stream, a);
             return 0;
         }
     }
@@ -1791,7 +1791,7 @@ template <bool BWD, int H, bool PF> static int launch_conv_hp(bdof_ctx* c, ConvA
     }
     const int tiles = a.B * (a.NX / BDOF_CONV_TX) * (a.NY / BDOF_CONV_TY);
     const int grid = balanced_grid(c, tiles, 2);
-    BDOF_LAUNCH(ps, (k_conv<BWD, H, PF>), dim3(grid), dim3(BDOF_CONV_THREADS), lds, c->stream, a);
+    BDOF_LAUNCH(ps, (k_conv<BWD, H, PF>), dim3(grid), dim3(BDOF_CONV_THREADS), lds, c->sub_stream, a);
     return 0;
 }
 template <bool BWD, int H> static int launch_conv_h(bdof_ctx* c, ConvArgs& a, ProfScope& ps) {
@@ -1821,14 +1821,28 @@ static int conv_forward_sweep(bdof_ctx* c, int B, bool tape) {
     ConvInitArgs ia{c->probe, cur, obj, B, c->NX, c->NY, conv_carrier(c, 0), cs ? c->cstack : nullptr};
     hipLaunchKernelGGL(k_conv_init, dim3(egrid), dim3(256), 0, c->stream, ia);
     int r;
-    for (int z = 0; z < c->S; ++z) {
-        const bool last = z == c->S - 1;
-        cf* out = last ? c->bufB : (tape ? c->tape + (size_t)(z + 1) * fld : (cur == c->bufA ? c->bufC : c->bufA));
-        ConvArgs a{cur, out, nullptr, nullptr, obj, B, c->NX, c->NY, last ? -1 : z + 1, cs ? zero : conv_pad(c, z), conv_carrier(c, z + 1),
-                   c->k_conv, c->taps_dev + z % c->taps_copies, c->taps.ks, cs && !last ? c->cstack + (size_t)(z + 1) * plane : nullptr};
-        if ((r = launch_conv<false>(c, a))) return r;
-        cur = out;
+    // sub-batches on streams of their own, as on the transfer-function path (batch_groups): the ramp and tail of one group's
+    // launch are filled by the other's; the slices of a group follow each other on its stream, the groups meet again at the
+    // detector (the renormalisation reads batch element 0)
+    Group groups[BDOF_MAX_GROUPS];
+    const int ng = batch_groups(c, B, (c->NX / 32) * (c->NY / 32), 2, groups);
+    if ((r = fork_streams(c, ng))) return r;
+    for (int gi = 0; gi < ng; ++gi) {
+        use_group(c, groups[gi]);
+        const size_t off = (size_t)groups[gi].b0 * plane;
+        const ObjView gobj = sub_obj(c);
+        cf* gcur = cur;
+        for (int z = 0; z < c->S; ++z) {
+            const bool last = z == c->S - 1;
+            cf* out = last ? c->bufB : (tape ? c->tape + (size_t)(z + 1) * fld : (gcur == c->bufA ? c->bufC : c->bufA));
+            ConvArgs a{gcur + off, out + off, nullptr, nullptr, gobj, groups[gi].B, c->NX, c->NY, last ? -1 : z + 1, cs ? zero : conv_pad(c, z),
+                       conv_carrier(c, z + 1), c->k_conv, c->taps_dev + z % c->taps_copies, c->taps.ks,
+                       cs && !last ? c->cstack + (size_t)(z + 1) * plane : nullptr};
+            if ((r = launch_conv<false>(c, a))) { use_whole(c); return r; }
+            gcur = out;
+        }
     }
+    if ((r = join_streams(c, ng))) return r;
     hipLaunchKernelGGL(k_conv_scalars, dim3(1), dim3(64), 0, c->stream, c->bufB, cs ? cfl(c->c_pS) : conv_carrier(c, c->S), c->probe,
                        cs ? cfl(c->c_p0) : conv_carrier(c, 0), c->conv_scal);
     return 0;
@@ -1998,16 +2012,24 @@ int bdof_loss_grad_conv(bdof_ctx* c, int B, const int* angle_of_b, const int* xo
     }
     hipLaunchKernelGGL(k_conv_finish, dim3(1), dim3(256), 0, c->stream, c->partial, npart, 2, 1.0 / ((double)B * c->NX * c->NY),
                        seed_scale, c->loss_dev, gp, c->conv_scal);
-    // backward sweep
-    ObjView obj = c->obj;
-    cf* gcur = gp;
-    for (int z = c->S - 1; z >= 0; --z) {
-        cf* gout = gcur == c->bufB ? c->bufA : c->bufB;
-        ConvArgs a{gcur, gout, c->tape + (size_t)z * fld, c->grot, obj, B, c->NX, c->NY, z, zero, conv_carrier(c, z), c->k_conv, c->taps_dev + z % c->taps_copies, c->taps.ks,
-                   cs ? c->cstack + (size_t)z * plane : nullptr};
-        if ((r = launch_conv<true>(c, a))) return r;
-        gcur = gout;
+    // backward sweep, in the same sub-batches
+    Group groups[BDOF_MAX_GROUPS];
+    const int ng = batch_groups(c, B, (c->NX / 32) * (c->NY / 32), 2, groups);
+    if ((r = fork_streams(c, ng))) return r;
+    for (int gi = 0; gi < ng; ++gi) {
+        use_group(c, groups[gi]);
+        const size_t off = (size_t)groups[gi].b0 * plane;
+        const ObjView gobj = sub_obj(c);
+        cf* gcur = gp;
+        for (int z = c->S - 1; z >= 0; --z) {
+            cf* gout = gcur == c->bufB ? c->bufA : c->bufB;
+            ConvArgs a{gcur + off, gout + off, c->tape + (size_t)z * fld + off, c->grot + (size_t)groups[gi].b0 * c->S * plane, gobj, groups[gi].B, c->NX, c->NY, z,
+                       zero, conv_carrier(c, z), c->k_conv, c->taps_dev + z % c->taps_copies, c->taps.ks, cs ? c->cstack + (size_t)z * plane : nullptr};
+            if ((r = launch_conv<true>(c, a))) { use_whole(c); return r; }
+            gcur = gout;
+        }
     }
+    if ((r = join_streams(c, ng))) return r;
     HIPC(c, hipGetLastError());
     return 0;
 }

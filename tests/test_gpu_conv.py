@@ -161,8 +161,10 @@ def test_reconstruct_fullfield_vs_the_reference_loop(engine_mod, tmp_path, monke
     assert stats[2] <= 0.01 and stats[3] <= 5e-5, stats
 
 
-def test_reconstruct_ptychography_vs_the_reference_loop(engine_mod, tmp_path, monkeypatch):
-    """The ptychography entry point against golden vector G14 directly: the reference's own reconstruct_ptychography executed
+@pytest.mark.parametrize('streams', [None, '2'])
+def test_reconstruct_ptychography_vs_the_reference_loop(engine_mod, tmp_path, monkeypatch, streams):
+    """(streams = '2': the minibatch split over two streams, as large minibatches run — windows, carrier field and gradient rows
+    of the second group at their offsets.)  The ptychography entry point against golden vector G14 directly: the reference's own reconstruct_ptychography executed
     (make_golden.py --g14: (64, 64, 64) object, 64 x 64 wide gaussian probe, 4 positions x 2 angles in minibatches of 2, two
     epochs = 8 Adam steps, real-space propagator with 17 taps, far field; seed 42 through the frozen clock)."""
     import os
@@ -172,6 +174,8 @@ def test_reconstruct_ptychography_vs_the_reference_loop(engine_mod, tmp_path, mo
     gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
     sys.path.insert(0, gdir)
     import g13_inputs
+    if streams:
+        monkeypatch.setenv('BDOF_STREAMS', streams)
     g = np.load(os.path.join(gdir, 'g14_reconstruct_ptychography_64.npz'))
     obj_size, psz = tuple(int(v) for v in g['obj_size']), tuple(int(v) for v in g['probe_size'])
     init_d, init_b = g13_inputs.initial_guess(obj_size)
@@ -212,8 +216,9 @@ def test_second_tiling_equals_the_first(engine_mod, monkeypatch, ks, probe, shap
     else:
         pr, pi = 0.8 + 0.1 * rng.normal(size=(Y, X)), 0.1 * rng.normal(size=(Y, X))
     out = {}
-    for tiling in ('1', '2'):
-        monkeypatch.setenv('BDOF_CONV_TILING', tiling)
+    for tiling in ('1', '2', '2s'):          # '2s': the second tiling with the batch split over two streams (as large batches run)
+        monkeypatch.setenv('BDOF_CONV_TILING', tiling[0])
+        monkeypatch.setenv('BDOF_STREAMS', '2' if tiling == '2s' else '1')
         eng = engine_mod.MultisliceEngine(Y, X, S, B, with_grad=True)
         eng.set_physics(5000., 1e-7, 1e-4)
         eng.set_conv(5000., [1e-7] * 3, ks)
@@ -235,3 +240,6 @@ def test_second_tiling_equals_the_first(engine_mod, monkeypatch, ks, probe, shap
         assert abs(l1 - l2) <= 1e-6 * abs(l1)
         assert rel(gd2, gd1) <= 2e-6 and rel(gb2, gb1) <= 2e-6
         assert np.abs(gd1 - gd2).max() <= 1e-5 * np.abs(gd1).max()
+    # sub-batches on two streams: the same kernels on the same fields — the same bits
+    for a, b in zip(out['2'], out['2s']):
+        assert np.array_equal(a, b)
