@@ -104,7 +104,7 @@ int main(int argc, char** argv) {
         }
         {
             RowBwdArgs a{in, tape, out, grot, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};
-            float ms = time_it([&] { hipLaunchKernelGGL((k_row_bwd<N>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters);
+            float ms = time_it([&] { hipLaunchKernelGGL((k_row_bwd<N, 1>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters);
             printf("row_bwd   %8.2f us  %7.1f GB/s (40 B/px)\n", ms * 1e3, 40 * px / ms / 1e6);
         }
     }
