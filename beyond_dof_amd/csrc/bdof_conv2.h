@@ -290,7 +290,7 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
         asm volatile("" : "+v"(yo));
     }
 #ifdef BDOF_CONV2_STAMP
-    if (tid == 0)
+    if (tid == 64 * BDOF_CONV2_STAMP)          // -DBDOF_CONV2_STAMP=w: the stamps of wave w
         for (int k = 0; k < 8; ++k) atomicAdd(&g_conv2_stamp[k], st_acc[k]);
 #endif
 }
