@@ -82,6 +82,52 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void kp_prop(R
     }
 }
 
+// XCD-aware tile order for the same kernel: workgroups are dealt to the 8 XCDs round-robin, so with tile = blockIdx.x + k * grid
+// the 32 tiles of a wavefield — which write the 32 adjacent 128-byte segments of every output row — sit in 8 different L2s.
+// Here every XCD takes a contiguous eighth of the tiles (whole wavefields), walked in order by its workgroups.
+template <int NX>
+__global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void kx_prop(RowPropArgs a) {
+    typedef RowCfg<NX> C;
+    constexpr bool EX = false;
+    __shared__ cf smem[C::LDS_CF];
+    const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
+    __shared__ cf smem_tw[FftTw<NX>::LDS_CNT];
+    FftTw<NX> tw;
+    __shared__ cf smem_tail[7 * C::T];
+    tw.template load<EX>(a.twiddle, tid, smem_tw, smem_tail);
+    tw.sq = a.sq;
+    const int ntiles = a.B * a.NY / C::TILE;
+    const int xcd = blockIdx.x & 7, w = blockIdx.x >> 3, nw = ((int)gridDim.x - xcd + 7) >> 3;
+    const int t0 = (int)((long long)xcd * ntiles / 8), t1 = (int)((long long)(xcd + 1) * ntiles / 8);
+    for (int tile = t0 + w; tile < t1; tile += nw) {
+        const int row0 = tile * C::TILE;
+        const int b = row0 / a.NY, ky0 = row0 - b * a.NY;
+#pragma nounroll
+        for (int pass = 0; pass < C::PASSES; ++pass) {
+            const int r = pass * C::RPP + rl;
+            RowLds<C::T> lds{smem + r * C::RS};
+            cf u[8], hv[8];
+            const cf* src = a.in + (size_t)(row0 + r) * NX;
+            const cf* hrow = a.h + (size_t)(ky0 + r) * NX;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) u[m] = src[tid + m * C::T];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) hv[m] = hrow[tid + m * C::T];
+            line_fft<NX, -1, 1, EX>(u, tw, tid, lds);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                cf t = hv[m];
+                if (a.conj_h) t.y = -t.y;
+                u[m] = cmul(u[m], cscale(t, a.scale));
+            }
+            line_fft_partial<NX, +1, 2, EX>(u, tw, tid, lds);
+        }
+        __syncthreads();
+        transposed_tail<NX, +1, 2, EX>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, smem_tail, a.sq);
+        __syncthreads();
+    }
+}
+
 template <class F> static float run(F launch, int iters) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -122,12 +168,14 @@ int main() {
             const float t1 = run([&] { hipLaunchKernelGGL((kp_prop<N, false>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a2); }, iters);
             const float t2 = run([&] { hipLaunchKernelGGL((kp_prop<N, true>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a2); }, iters);
             const float t3 = run([&] { hipLaunchKernelGGL((kp_prop<N, false>), dim3(ncu * 2), dim3(BDOF_THREADS), 0, 0, a2); }, iters);
-            printf("B %4d grid %4d: production %7.2f us per 25   row prefetch %7.2f   row + h prefetch %7.2f   row prefetch, grid %d: %7.2f\n",
-                   B, grid, t0 * 1e3 * 25 / B, t1 * 1e3 * 25 / B, t2 * 1e3 * 25 / B, ncu * 2, t3 * 1e3 * 25 / B);
+            const float t4 = run([&] { hipLaunchKernelGGL((kx_prop<N>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a2); }, iters);
+            const float t5 = run([&] { hipLaunchKernelGGL((k_row_prop<N, false>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters);
+            printf("B %4d grid %4d: production %7.2f us per 25   row prefetch %7.2f   row + h prefetch %7.2f   row prefetch, grid %d: %7.2f   XCD-aware tile order %7.2f   production again %7.2f\n",
+                   B, grid, t0 * 1e3 * 25 / B, t1 * 1e3 * 25 / B, t2 * 1e3 * 25 / B, ncu * 2, t3 * 1e3 * 25 / B, t4 * 1e3 * 25 / B, t5 * 1e3 * 25 / B);
         }
         // same results?
         hipLaunchKernelGGL((k_row_prop<N, false>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a);
-        hipLaunchKernelGGL((kp_prop<N, false>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a2);
+        hipLaunchKernelGGL((kx_prop<N>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a2);
         CK(hipDeviceSynchronize());
         std::vector<float> r0((size_t)B * N * N * 2), r1(r0.size());
         CK(hipMemcpy(r0.data(), out, r0.size() * 4, hipMemcpyDeviceToHost));
