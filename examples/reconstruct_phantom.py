@@ -72,9 +72,10 @@ def main():
     fp = sys.argv[5] if len(sys.argv) > 5 else '1e-3'
     fp = 'inf' if fp == 'inf' else float(fp)
     mb = int(sys.argv[6]) if len(sys.argv) > 6 else 10
-    r = run(n, n_theta, n_epochs, lr, fp, mb=mb)
-    print('reconstruct_fullfield {}^3, {} angles, {} epochs in minibatches of {}: {:.1f} s ({:.1f} ms per Adam step, entry point to files)'.format(
-        n, n_theta, n_epochs, mb, r['seconds'], 1e3 * r['seconds'] / (n_epochs * max(1, n_theta // mb))))
+    propagator = sys.argv[7] if len(sys.argv) > 7 else 'fft'
+    r = run(n, n_theta, n_epochs, lr, fp, mb=mb, propagator=propagator)
+    print('reconstruct_fullfield (propagator {}) {}^3, {} angles, {} epochs in minibatches of {}: {:.1f} s ({:.1f} ms per Adam step, entry point to files)'.format(
+        propagator, n, n_theta, n_epochs, mb, r['seconds'], 1e3 * r['seconds'] / (n_epochs * max(1, n_theta // mb))))
     print('delta: correlation with the phantom {:.4f} (central half {:.4f}); relative L2 error {:.3f}; peak {:.3e} vs {:.3e}'.format(
         r['delta_corr'], r['delta_corr_inner'], r['delta_rel_l2'], r['delta_peak'], r['phantom_peak']))
     print('beta : correlation {:.4f}'.format(r['beta_corr']))
