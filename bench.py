@@ -41,26 +41,34 @@ PMC_KERNEL = {'row_fwd': 'k_row_fwd<512, false, true', 'col_prop': 'k_row_prop<5
               'rot_adjoint': 'k_rot_adjoint'}
 
 
-def pmc_traffic(kernel_class, n, mb):
+# the real-space path's kernels (bench.py --propagator conv, 17 taps) and its committed summaries
+PMC_KERNEL_CONV = {'row_fwd': 'k_conv2<false, 8', 'row_bwd': 'k_conv2<true, 8', 'rot_adjoint': 'k_rot_adjoint'}
+PMC_SUMMARY_CONV = os.path.join(ROOT, 'profiles', ROUND + '_pmc_traffic_conv.json')
+STATS_1STREAM_CONV = os.path.join(ROOT, 'profiles', ROUND + '_kernel_stats_conv.csv')
+
+
+def pmc_traffic(kernel_class, n, mb, conv=False):
     """Measured L2<->fabric bytes per launch of the class's kernel (512^3, 25 angles, whole-batch launches), or None."""
-    if (n, mb) != (512, 25) or not os.path.exists(PMC_SUMMARY):
+    summary = PMC_SUMMARY_CONV if conv else PMC_SUMMARY
+    if (n, mb) != (512, 25) or not os.path.exists(summary):
         return None
-    want = PMC_KERNEL[kernel_class]
-    for name, k in json.load(open(PMC_SUMMARY))['kernels'].items():
+    want = (PMC_KERNEL_CONV if conv else PMC_KERNEL)[kernel_class]
+    for name, k in json.load(open(summary))['kernels'].items():
         if name.startswith(want):
             return k['total_bytes_per_launch']
     return None
 
 
-def rocprof_avg_ms(kernel_class, n, mb):
+def rocprof_avg_ms(kernel_class, n, mb, conv=False):
     """Average dispatch duration of the class's kernel in the committed single-stream rocprofv3 --kernel-trace --stats summary
     of this command (512^3, 25 angles only), or None."""
-    if (n, mb) != (512, 25) or not os.path.exists(STATS_1STREAM):
+    stats = STATS_1STREAM_CONV if conv else STATS_1STREAM
+    if (n, mb) != (512, 25) or not os.path.exists(stats):
         return None
     import csv
-    want = PMC_KERNEL[kernel_class]
+    want = (PMC_KERNEL_CONV if conv else PMC_KERNEL)[kernel_class]
     calls = total = 0.0                       # a class may have several instances (the transfer-function step: forward and exact adjoint)
-    for row in csv.DictReader(open(STATS_1STREAM)):
+    for row in csv.DictReader(open(stats)):
         name = row['Name'].replace('void ', '')
         if name.startswith(want):
             total += float(row['TotalDurationNs'])
@@ -254,7 +262,7 @@ def roofline_pass(solver, batch, hyper, n, mb, S, conv=False):
             nbytes = bpp * px * (S if name == 'rot_adjoint' else 1)
             per_class[name] = {'timed_launches': cnt, 'avg_ms': ms / cnt, 'bytes_per_launch': nbytes,
                                'GBps': nbytes / (ms / cnt * 1e-3) / 1e9, 'frac': nbytes / (ms / cnt * 1e-3) / HBM_PEAK,
-                               'avg_ms_rocprof_1stream': None if conv else rocprof_avg_ms(name, n, mb)}
+                               'avg_ms_rocprof_1stream': rocprof_avg_ms(name, n, mb, conv)}
     if not per_class:
         return None
     share = {k: per_class[k]['avg_ms'] * launches_per_step[k] for k in per_class}
@@ -262,13 +270,13 @@ def roofline_pass(solver, batch, hyper, n, mb, S, conv=False):
     # step and the adjoint row kernel are, at 24 ms each) and the tie goes to the one FURTHER from the roofline
     dom = min((k for k in share if share[k] >= 0.95 * max(share.values())), key=lambda k: per_class[k]['frac'])
     d = per_class[dom]
-    tb = None if conv else pmc_traffic(dom, n, mb)
+    tb = pmc_traffic(dom, n, mb, conv)
     return {'bound': 'hbm', 'kernel': dom, 'achieved': d['GBps'], 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': d['frac'],
             'traffic': None if tb is None else tb / (d['avg_ms'] * 1e-3) / 1e9,
             'traffic_bytes_per_launch': tb, 'algorithmic_bytes_per_launch': d['bytes_per_launch'],
             'avg_launch_ms_events': d['avg_ms'], 'avg_launch_ms_rocprof': d['avg_ms_rocprof_1stream'],
-            'rocprof_summary': os.path.relpath(STATS_1STREAM, ROOT) if d['avg_ms_rocprof_1stream'] else None,
-            'traffic_source': (os.path.relpath(PMC_SUMMARY, ROOT) + ' (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE x1)') if tb else None,
+            'rocprof_summary': os.path.relpath(STATS_1STREAM_CONV if conv else STATS_1STREAM, ROOT) if d['avg_ms_rocprof_1stream'] else None,
+            'traffic_source': (os.path.relpath(PMC_SUMMARY_CONV if conv else PMC_SUMMARY, ROOT) + ' (rocprofv3 --pmc FETCH_SIZE x2, WRITE_SIZE x1)') if tb else None,
             'share_of_step_ms': share,
             'note': 'dominant kernel = largest share of the step (ties within 5 % go to the lower frac); achieved = algorithmic bytes of '
                     'one whole-minibatch launch / its average duration from the HIP events hipExtLaunchKernelGGL stamps with the '
