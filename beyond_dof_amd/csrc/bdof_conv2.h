@@ -178,7 +178,11 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
         for (int q = 0; q < R; ++q) {
             if (sraw[q] < 0) e.xin &= ~(1u << q);                          // a table entry that points nowhere
             const unsigned off = __umul24(x0 + i0 + q, a.NY) + y;
+#if defined(BDOF_CONV2_WHATIF) && (BDOF_CONV2_WHATIF & 1)
+            e.m1[q] = make_float2(1e-3f * (float)q, 0.f);                 // timing experiment (tools/kbench_conv2.hip): no operand loads
+#else
             e.m1[q] = a.obj.vol[(size_t)max(sraw[q], 0) * a.obj.volNY + yc];
+#endif
             if constexpr (BWD) e.tp[q] = tape_b[off];
             if constexpr (PF) e.pf[q] = a.pfield[off];                   // L2-resident plane shared by all wavefields
         }
@@ -275,7 +279,12 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
                 cf car = a.carrier;
                 if constexpr (PF) car = cur.pf[q];
                 if constexpr (!BWD) {
+#if defined(BDOF_CONV2_WHATIF) && (BDOF_CONV2_WHATIF & 2)
+                    const cf res = modulate_eps(acc, car, mm);             // timing experiment: no stores (kept alive by a test
+                    if (res.x == 123.456f) out_b[off] = res;               // that practically never passes)
+#else
                     out_b[off] = modulate_eps(acc, car, mm);
+#endif
                 } else {
                     const cf phi = cadd(cur.tp[q], car);
                     const cf tt = cmulc(acc, phi);

@@ -1,6 +1,8 @@
 // Development aid (not part of the product): where a workgroup of k_conv2 spends its cycles, by in-kernel stamps (s_memtime at the
 // phase boundaries of wave 0 of every workgroup), on the bench's shape — 25 fields of 512 x 512, 17 taps, object bound per wavefield.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DBDOF_CONV2_STAMP -o tools/kbench_conv2 tools/kbench_conv2.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -DBDOF_CONV2_STAMP=0 -o tools/kbench_conv2 tools/kbench_conv2.hip
+// (-DBDOF_CONV2_STAMP=w: the stamps of wave w; without it only the launch time; -DBDOF_CONV2_WHATIF=1|2|3: timing experiments that
+//  drop the operand loads (1) and / or the forward kernel's stores (2) — wrong results, what the kernel costs without them)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -18,14 +20,22 @@ template <bool BWD> static void run(const ConvArgs& a, int grid, int iters, cons
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_conv2<BWD, 8, false>), dim3(grid), dim3(C::THREADS), 0, 0, a);
     CK(hipDeviceSynchronize());
+#ifdef BDOF_CONV2_STAMP
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_conv2_stamp), zero, sizeof(zero)));
+#endif
     CK(hipEventRecord(e0));
     for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_conv2<BWD, 8, false>), dim3(grid), dim3(C::THREADS), 0, 0, a);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipGetLastError());
+#ifdef BDOF_CONV2_STAMP
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_conv2_stamp), sizeof(st)));
+#else
+    (void)zero;
+    printf("%s: %.2f us per launch (no stamps), grid %d\n", name, ms * 1e3 / iters, grid);
+    return;
+#endif
     double tot = 0;
     for (int k = 0; k < 8; ++k) tot += (double)st[k];
     static const char* ph[8] = {"operand requests + padding patch", "barrier (halo tile complete)", "y pass", "wait for the epilogue's operands",
