@@ -10,8 +10,8 @@
 //     alternating 16-byte slots, and the DMA image stays lane-linear (the one dummy unit per row is a masked lane);
 //   * windows of 4 outputs in both passes: 8 (64 + 2H) y-pass windows in two rounds, 512 x-pass windows — every wave
 //     issues the same FMA count in the x pass and the y pass's second round is 2H / 8 waves;
-//   * 53.9 KB of LDS in two static objects, 97-117 VGPRs: two workgroups per CU (three would need <= 80 registers; the
-//     kernel spills there);
+//   * 53.9 KB of LDS in two static objects, 97-117 VGPRs: two workgroups per CU (three need <= 80 registers: 64-112 bytes of
+//     scratch per lane, 59.9 / 94.9 us against 54.0 / 57.8 us forward / backward in tools/kbench_conv2.hip);
 //   * XCD-aware tile order (runs of strips per blockIdx % 8) so that the halos neighbouring tiles share are L2 hits;
 //   * the DMA and the loads carried into the next tile are issued by asm, with one counted wait per tile (below).
 // Reference: cnn_propagator/propagation.py:80-107 (the convolution of one slice), :109-110 (renormalisation, k_conv_final).
@@ -47,7 +47,11 @@ template <int H, int TXV = 64> struct Conv2Cfg {
     static constexpr int TXH = TX + 2 * H, TYH = TY + 2 * H, NP = TYH / 2, RU = NP | 1;
     static constexpr int UNITS = TXH * RU, NLOADS = (UNITS + 63) / 64, MP = (NLOADS + NW - 1) / NW;
     static constexpr int A_BYTES = NLOADS * 1024, M_BYTES = TXH * SM * 8, LDS = A_BYTES + M_BYTES;
+#ifdef BDOF_CONV2_MINW
+    static constexpr int MINW = BDOF_CONV2_MINW; // timing experiment (tools/kbench_conv2.hip)
+#else
     static constexpr int MINW = 4;               // waves per SIMD asked of the register allocator: two workgroups of 8 waves per CU
+#endif
     static_assert(H % 2 == 0 && NP % 2 == 0, "halo of even width: 16-byte units must not straddle the field's edge");
     static_assert(TX * TY == THREADS * R, "one x-pass window per thread");
 };

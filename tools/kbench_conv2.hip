@@ -61,7 +61,10 @@ int main() {
     CK(hipMemcpy(taps, &t, sizeof(t), hipMemcpyHostToDevice));
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     ObjView obj{vol, nullptr, nullptr, nullptr, nullptr, S, N, N};
-    const int nstrips = B * (N / 64), run_tiles = ((nstrips + 7) / 8) * (N / 32), slots = prop.multiProcessorCount * 2 / 8;
+#ifndef BDOF_CONV2_PER_CU
+#define BDOF_CONV2_PER_CU 2
+#endif
+    const int nstrips = B * (N / 64), run_tiles = ((nstrips + 7) / 8) * (N / 32), slots = prop.multiProcessorCount * BDOF_CONV2_PER_CU / 8;
     const int rounds = (run_tiles + slots - 1) / slots, grid = 8 * ((run_tiles + rounds - 1) / rounds);
     ConvArgs af{in, out, nullptr, nullptr, obj, B, N, N, 1, make_float2(0.f, 0.f), make_float2(1.f, 0.f), 1e-3f, taps, 17, nullptr};
     ConvArgs ab{in, out, tape, grot, obj, B, N, N, 1, make_float2(0.f, 0.f), make_float2(1.f, 0.f), 1e-3f, taps, 17, nullptr};
