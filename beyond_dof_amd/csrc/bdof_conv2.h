@@ -101,7 +101,11 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
     for (int m = 0; m < MP; ++m) {
         const int u = (wave + NW * m) * 64 + lane;
         const int i = u / RU, c = u - i * RU;
+#if defined(BDOF_CONV2_WHATIF) && (BDOF_CONV2_WHATIF & 4)
+        rel[m] = (unsigned)(min(i, TXH - 1) * a.NY + 2 * (min(c, NP - 1) % 16) + H) * 8u;    // timing experiment: every row's units from
+#else                                                                                          // TWO aligned 128-byte lines
         rel[m] = (unsigned)(min(i, TXH - 1) * a.NY + 2 * min(c, NP - 1)) * 8u;
+#endif
         act |= (wave + NW * m < C::NLOADS && i < TXH && c < NP) ? 1u << m : 0u;
     }
     unsigned oob = 0;            // bit m: the unit of load m lies outside the field (padding constant after landing)
@@ -122,7 +126,11 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
             for (int m = 0; m < MP; ++m) {
                 const int u = (wave + NW * m) * 64 + lane;
                 const int i = u / RU, c = u - i * RU;
+#if defined(BDOF_CONV2_WHATIF) && (BDOF_CONV2_WHATIF & 4)
+                const int x = x0 - H + i, y = y0 + 2 * (c % 16);
+#else
                 const int x = x0 - H + i, y = y0 - H + 2 * c;
+#endif
                 const bool in = (unsigned)x < (unsigned)a.NX && (unsigned)y < (unsigned)a.NY;
                 const unsigned off = (__umul24(min(max(x, 0), a.NX - 1), a.NY) + min(max(y, 0), a.NY - 2)) * 8u;
                 if ((act >> m) & 1u) {
