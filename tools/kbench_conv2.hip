@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <unistd.h>
 #include "../beyond_dof_amd/csrc/bdof_kernels.h"
 #include "../beyond_dof_amd/csrc/bdof_conv2.h"
 
@@ -34,6 +35,21 @@ template <bool BWD> static void run(const ConvArgs& a, int grid, int iters, cons
 #else
     (void)zero;
     printf("%s: %.2f us per launch (no stamps), grid %d\n", name, ms * 1e3 / iters, grid);
+    // the same launch with the GPU idle for `gap` microseconds before it: does the back-to-back figure depend on the clock the
+    // chip holds under sustained load?
+    for (int gap : {0, 200, 2000}) {
+        double sum = 0; float best = 1e9f;
+        for (int i = 0; i < 30; ++i) {
+            if (gap) usleep(gap);
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL((k_conv2<BWD, 8, false>), dim3(grid), dim3(C::THREADS), 0, 0, a);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float t; CK(hipEventElapsedTime(&t, e0, e1));
+            sum += t; best = t < best ? t : best;
+        }
+        printf("   one launch at a time, %4d us idle before each: mean %.2f us, best %.2f us\n", gap, sum / 30 * 1e3, best * 1e3);
+    }
     return;
 #endif
     double tot = 0;
