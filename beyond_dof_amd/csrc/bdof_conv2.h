@@ -244,11 +244,19 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
             cf win[R + 2 * H], o[R];
 #pragma unroll
             for (int q = 0; q < (R + 2 * H) / 2; ++q) {
+#if defined(BDOF_CONV2_WHATIF) && (BDOF_CONV2_WHATIF & 8)
+                const float4 v = make_float4(1e-3f * (float)(lane + q), 0.5f, (float)w, 1.f);     // timing experiment: no LDS reads in the passes
+#else
                 const float4 v = p[q];
+#endif
                 win[2 * q] = make_float2(v.x, v.y);
                 win[2 * q + 1] = make_float2(v.z, v.w);
             }
+#if defined(BDOF_CONV2_WHATIF) && (BDOF_CONV2_WHATIF & 16)
+            for (int q = 0; q < R; ++q) o[q] = cadd(win[q], win[q + 2 * H]);                       // timing experiment: no tap sums
+#else
             conv_window<BWD, H, R>(win, kt->ky, o);
+#endif
 #pragma unroll
             for (int q = 0; q < R; ++q) M[i * SM + R * w + q] = o[q];
         }
@@ -278,8 +286,16 @@ __global__ __launch_bounds__((Conv2Cfg<H, TXV>::THREADS), (Conv2Cfg<H, TXV>::MIN
             float2* grot_b = BWD ? a.grot + ((size_t)b * a.obj.S + a.zmod) * a.NX * a.NY : nullptr;
             cf win[R + 2 * H];
 #pragma unroll
+#if defined(BDOF_CONV2_WHATIF) && (BDOF_CONV2_WHATIF & 8)
+            for (int q = 0; q < R + 2 * H; ++q) win[q] = make_float2(1e-3f * (float)(lane + q), 0.5f);
+#else
             for (int q = 0; q < R + 2 * H; ++q) win[q] = M[(i0 + q) * SM + j];
+#endif
+#if defined(BDOF_CONV2_WHATIF) && (BDOF_CONV2_WHATIF & 16)
+            for (int q = 0; q < R; ++q) o[q] = cadd(win[q], win[q + 2 * H]);
+#else
             conv_window<BWD, H, R>(win, kt->kx, o);
+#endif
             const int y = y0 + j;
 #pragma unroll
             for (int q = 0; q < R; ++q) {
