@@ -200,9 +200,10 @@ class SocketGroup(object):
                 while len(self.peers) < self.size - 1:
                     conn, _ = srv.accept()
                     conn.settimeout(timeout)
-                    if _peer_uid(conn) != os.getuid():
+                    peer_uid = _peer_uid(conn)              # read before the socket is closed (getsockopt on a closed one: EBADF)
+                    if peer_uid != os.getuid():
                         conn.close()
-                        raise RuntimeError('rendezvous {}: a process of uid {} connected'.format(self.path, _peer_uid(conn)))
+                        raise RuntimeError('rendezvous {}: a process of uid {} connected'.format(self.path, peer_uid))
                     r, n = [int(v) for v in _decode(_recv_msg(conn))]
                     if n != self.size or not (0 < r < self.size) or r in self.peers:
                         conn.close()

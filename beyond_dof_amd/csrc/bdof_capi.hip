@@ -14,10 +14,12 @@
 #include "bdof_kernels.h"
 #include "bdof_conv2.h"
 #include "bdof_generic.h"
+#include "bdof_field.h"
 #include "bdof_resident.h"
 #include "bdof_comm.h"
 #include <rocfft/rocfft.h>
 #include <map>
+#include <array>
 
 #define BDOF_ERR_ARG (-1)
 #define BDOF_ERR_STATE (-2)
@@ -88,6 +90,7 @@ struct bdof_ctx {
     // float64 adjoint sweep (bdof_configure flag 64; generic engine)
     bool adj64 = false, have_h64 = false;
     std::map<int, std::pair<rocfft_plan, rocfft_plan>> gplans64;
+    std::map<std::array<int, 4>, std::pair<rocfft_plan, rocfft_plan>> fplans;      // bdof_fields_free_step: (NX, NY, B, double)
     double2 *g64 = nullptr, *hs64 = nullptr, *hdet64 = nullptr;
     rocfft_execution_info ginfo = nullptr;
     void* gwork = nullptr;
@@ -423,10 +426,14 @@ static void launch_row_unmod(bdof_ctx* c, int B, int z, const cf* in, cf* out, b
 }
 
 // B: L2 -> L1
-static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf* h, float scale, int conj_h) {
+// key: the slice whose copy of the dithered constants the launch takes (tw_of); -1 = that of the last A / A' launch.  The step
+// between slices z-1 and z runs with copy z-1 in the forward sweep (it follows A_{z-1}); its adjoint, which follows A'_z, is
+// handed z-1 explicitly, so that the adjoint step is the transpose of the very operator the forward sweep applied.
+static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf* h, float scale, int conj_h, int key = -1) {
     ProfScope ps(c, BDOF_K_COL_PROP, true);
-    RowPropArgs a{sub_field(c, in), sub_field(c, out), h, B, c->NY, scale, conj_h, tw_of(c, c->twX, c->NX, c->tw_tick)};
-    sq_of(c, c->tw_tick, a.sq);
+    const unsigned tick = key >= 0 ? (unsigned)key : c->tw_tick;
+    RowPropArgs a{sub_field(c, in), sub_field(c, out), h, B, c->NY, scale, conj_h, tw_of(c, c->twX, c->NX, tick)};
+    sq_of(c, tick, a.sq);
     DISPATCH_N(c->NX, {
         // the adjoint step runs the instance with exact transform constants (bdof_fft.h: that is where the gradient's error is made)
         if (conj_h ? BDOF_EX_ADJ : BDOF_EX_FWD_B) BDOF_LAUNCH(ps, (k_row_prop<N_, true>), dim3(rows_grid<N_>(c, B, c->NY)), dim3(BDOF_THREADS), 0, c->sub_stream, a);
@@ -914,6 +921,8 @@ static void free_generic(bdof_ctx* c) {
     c->gplans.clear();
     for (auto& kv : c->gplans64) { (void)rocfft_plan_destroy(kv.second.first); (void)rocfft_plan_destroy(kv.second.second); }
     c->gplans64.clear();
+    for (auto& kv : c->fplans) { (void)rocfft_plan_destroy(kv.second.first); (void)rocfft_plan_destroy(kv.second.second); }
+    c->fplans.clear();
     for (double2** q : {&c->g64, &c->hs64, &c->hdet64}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     c->have_h64 = false;
     if (c->ginfo) { (void)rocfft_execution_info_destroy(c->ginfo); c->ginfo = nullptr; }
@@ -1455,10 +1464,10 @@ int bdof_adjoint_range(bdof_ctx* c, int B, const int* angle_of_b, const int* xof
         // phi_{zt} = P^H psi_{zt+1} and G(phi_{zt}) = P^H G(psi_{zt+1}): real space -> R (transposed) -> adjoint step
         RealToHybArgs ra{sub_field(c, (const cf*)end_real), sub_field(c, c->bufA), Bg, c->NX, c->twY};
         DISPATCH_N(c->NY, { hipLaunchKernelGGL((k_row_real_to_hyb<N_>), dim3(rows_grid<N_>(c, Bg, c->NX)), dim3(BDOF_THREADS), 0, c->sub_stream, ra); });
-        launch_row_prop(c, Bg, c->bufA, rc1, c->hs, 1.f, 1);
+        launch_row_prop(c, Bg, c->bufA, rc1, c->hs, 1.f, 1, zt);
         RealToHybArgs rg{sub_field(c, (const cf*)g_end_real), sub_field(c, c->bufA), Bg, c->NX, c->twY};
         DISPATCH_N(c->NY, { hipLaunchKernelGGL((k_row_real_to_hyb<N_>), dim3(rows_grid<N_>(c, Bg, c->NX)), dim3(BDOF_THREADS), 0, c->sub_stream, rg); });
-        launch_row_prop(c, Bg, c->bufA, c->bufB, c->hs, 1.f, 1);
+        launch_row_prop(c, Bg, c->bufA, c->bufB, c->hs, 1.f, 1, zt);
     }
     for (int z = zt; z >= z0; --z) {
         for (int gi = 0; gi < ng; ++gi) {
@@ -1469,9 +1478,9 @@ int bdof_adjoint_range(bdof_ctx* c, int B, const int* angle_of_b, const int* xof
             gt.gpsi = z == z0 ? (cf*)g_start_real : nullptr;
             launch_row_bwd(c, Bg, z, c->bufB, rc1, z > z0 ? c->bufA : nullptr, 3, 1.f, &gt);
             if (z > z0) {
-                launch_row_prop(c, Bg, c->bufA, c->bufB, c->hs, 1.f, 1);
+                launch_row_prop(c, Bg, c->bufA, c->bufB, c->hs, 1.f, 1, z - 1);
                 launch_row_unmod(c, Bg, z, rc1, rc2, false, 1.f);
-                launch_row_prop(c, Bg, rc2, rc1, c->hs, 1.f, 1);
+                launch_row_prop(c, Bg, rc2, rc1, c->hs, 1.f, 1, z - 1);
             }
         }
     }
@@ -1566,6 +1575,138 @@ int bdof_tiles_grad_add(bdof_ctx* c, const void* grot_range, void* gvol, int B, 
     return 0;
 }
 
+// ---- whole-field / tile-batch operations in either precision (bdof_field.h) ------------------------------------------------
+static int field_plans(bdof_ctx* c, int NX, int NY, int B, bool dbl, rocfft_plan* fwd, rocfft_plan* inv) {
+    if (!g_rocfft_ready) { RFC(c, rocfft_setup()); g_rocfft_ready = true; }
+    const std::array<int, 4> key{NX, NY, B, dbl ? 1 : 0};
+    auto it = c->fplans.find(key);
+    if (it == c->fplans.end()) {
+        const size_t lengths[2] = {(size_t)NY, (size_t)NX};             // fastest dimension first
+        const rocfft_precision prec = dbl ? rocfft_precision_double : rocfft_precision_single;
+        rocfft_plan pf = nullptr, pi = nullptr;
+        RFC(c, rocfft_plan_create(&pf, rocfft_placement_inplace, rocfft_transform_type_complex_forward, prec, 2, lengths, (size_t)B, nullptr));
+        RFC(c, rocfft_plan_create(&pi, rocfft_placement_inplace, rocfft_transform_type_complex_inverse, prec, 2, lengths, (size_t)B, nullptr));
+        size_t w1 = 0, w2 = 0;
+        RFC(c, rocfft_plan_get_work_buffer_size(pf, &w1));
+        RFC(c, rocfft_plan_get_work_buffer_size(pi, &w2));
+        const size_t need = std::max(w1, w2);
+        if (need > c->gwork_sz) {
+            HIPC(c, hipStreamSynchronize(c->stream));
+            if (c->gwork) (void)hipFree(c->gwork);
+            c->gwork = nullptr;
+            c->gwork_sz = 0;
+            HIPC(c, hipMalloc(&c->gwork, need));
+            c->gwork_sz = need;
+        }
+        it = c->fplans.emplace(key, std::make_pair(pf, pi)).first;
+    }
+    if (!c->ginfo) {
+        RFC(c, rocfft_execution_info_create(&c->ginfo));
+        RFC(c, rocfft_execution_info_set_stream(c->ginfo, (void*)c->stream));
+    }
+    if (c->gwork_sz) RFC(c, rocfft_execution_info_set_work_buffer(c->ginfo, c->gwork, c->gwork_sz));
+    *fwd = it->second.first;
+    *inv = it->second.second;
+    return 0;
+}
+
+// fields[b] <- F^-1 ( h * F fields[b] ) for B fields [NX][NY] in place; h[kx][ky] carries 1 / (NX NY) (and any power of the
+// transfer function: np_funcs.py:42 composes in free space); is_double: complex128 fields and table, else complex64
+int bdof_fields_free_step(bdof_ctx* c, void* fields, int B, int NX, int NY, const void* h, int conj_h, int is_double) {
+    if (!c || !fields || !h || B < 1 || NX < 1 || NY < 1) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    rocfft_plan pf, pi;
+    int r = field_plans(c, NX, NY, B, is_double != 0, &pf, &pi);
+    if (r) return r;
+    void* buf[1] = {fields};
+    const size_t per = (size_t)NX * NY, n = per * B;
+    RFC(c, rocfft_execute(pf, buf, nullptr, c->ginfo));
+    if (is_double) hipLaunchKernelGGL(k_f_hmul<double2>, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, (double2*)fields, (const double2*)h, per, n, conj_h);
+    else hipLaunchKernelGGL(k_f_hmul<float2>, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, (float2*)fields, (const float2*)h, per, n, conj_h);
+    RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo));
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// y += alpha x on n complex numbers (either precision)
+int bdof_caxpy(bdof_ctx* c, void* y, const void* x, double alpha, size_t n, int is_double) {
+    if (!c || !y || !x) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    if (is_double) hipLaunchKernelGGL(k_f_axpy<double>, dim3(g_elem_grid(c, 2 * n)), dim3(256), 0, c->stream, (double*)y, (const double*)x, alpha, 2 * n);
+    else hipLaunchKernelGGL(k_f_axpy<float>, dim3(g_elem_grid(c, 2 * n)), dim3(256), 0, c->stream, (float*)y, (const float*)x, (float)alpha, 2 * n);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// complex64 <-> complex128 copies of n numbers
+int bdof_c_convert(bdof_ctx* c, void* dst, const void* src, size_t n, int to_double) {
+    if (!c || !dst || !src) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    if (to_double) hipLaunchKernelGGL(k_f_to_double, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, (const cf*)src, (double2*)dst, n);
+    else hipLaunchKernelGGL(k_f_to_float, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, (const double2*)src, (cf*)dst, n);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_tiles_gather_f64(bdof_ctx* c, const void* field, int FX, int FY, void* tiles, int B, int TX, int TY, const int* x0, const int* y0,
+                          int taper) {
+    int r = tiles_check(c, field, tiles, B, FX, FY, TX, TY, x0, y0);
+    if (r) return r;
+    if (taper < 0 || 2 * taper > TX || 2 * taper > TY) return fail(c, BDOF_ERR_ARG, "taper must fit the tile");
+    HIPC(c, hipSetDevice(c->device));
+    Tile64Args a{(double2*)field, (double2*)tiles, x0, y0, B, FX, FY, TX, TY, 0, 0, taper};
+    hipLaunchKernelGGL(k_tiles_gather64, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_tiles_scatter_f64(bdof_ctx* c, const void* tiles, void* field, int FX, int FY, int B, int TX, int TY, const int* x0, const int* y0,
+                           int halo_x, int halo_y) {
+    int r = tiles_check(c, field, tiles, B, FX, FY, TX, TY, x0, y0);
+    if (r) return r;
+    if (halo_x < 0 || halo_y < 0 || 2 * halo_x >= TX || 2 * halo_y >= TY) return fail(c, BDOF_ERR_ARG, "halo must leave a core");
+    HIPC(c, hipSetDevice(c->device));
+    Tile64Args a{(double2*)field, (double2*)tiles, x0, y0, B, FX, FY, TX, TY, halo_x, halo_y, 0};
+    hipLaunchKernelGGL(k_tiles_scatter64, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// bdof_forward_range in float64 on caller-owned complex128 fields [B][NX][NY], in place: slices z0 .. z0+nz-1 of the bound object
+// seen through the windows (xoff, yoff); modulation from the caller's (delta, beta) rows with k in float64, transforms by
+// rocFFT in double precision, h[kx][ky] = the transfer function / (NX NY) in float64.  cnn_propagator/np_funcs.py:36-43.
+int bdof_forward_range_f64(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz, void* fields,
+                           const void* h, double k, int prop_last) {
+    if (!c || !fields || !h) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    if (!c->obj_src) return fail(c, BDOF_ERR_STATE, "bdof_set_object (with (delta, beta) rows) has not been called");
+    if (B < 1) return fail(c, BDOF_ERR_ARG, "batch size must be positive");
+    if (z0 < 0 || nz < 1 || z0 + nz > c->S) return fail(c, BDOF_ERR_ARG, "slice range outside [0, S)");
+    if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
+    HIPC(c, hipSetDevice(c->device));
+    rocfft_plan pf, pi;
+    int r = field_plans(c, c->NX, c->NY, B, true, &pf, &pi);
+    if (r) return r;
+    ObjView o = c->obj;
+    o.vol = c->obj_src;
+    o.angle_of_b = angle_of_b;
+    o.xoff = xoff;
+    o.yoff = yoff;
+    const size_t per = (size_t)c->NX * c->NY, n = per * B;
+    void* buf[1] = {fields};
+    for (int z = z0; z < z0 + nz; ++z) {
+        Mod64Args m{(double2*)fields, o, B, c->NX, c->NY, z, k};
+        hipLaunchKernelGGL(k_f64_modulate, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, m);
+        if (z < z0 + nz - 1 || prop_last) {
+            RFC(c, rocfft_execute(pf, buf, nullptr, c->ginfo));
+            hipLaunchKernelGGL(k_f_hmul<double2>, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, (double2*)fields, (const double2*)h, per, n, 0);
+            RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo));
+        }
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
 int bdof_tape_to_real(bdof_ctx* c, int i, int B, void* out) {
     int r = check_ready(c, B);
     if (r) return r;
@@ -1640,7 +1781,7 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
             // the detector wave came out of a transfer-function step: seed -> R (transposed) -> adjoint step
             const cf* h = c->det_mode == BDOF_DET_NONE ? c->hs : (tf_all ? c->hcomb : c->hdet);
             npart += launch_loss_real(c, Bg, c->bufB, c->bufA, true, (cf*)out_wave, meas, 1.f, 1.f, seed_scale, carrier_det(c), c->pdet);
-            launch_row_prop(c, Bg, c->bufA, c->bufB, h, 1.f, 1);
+            launch_row_prop(c, Bg, c->bufA, c->bufB, h, 1.f, 1, c->S - 1);
         }
     }
     // backward sweep: A'_z (L1 -> L2), then the adjoint transfer-function step (L2 -> L1)
@@ -1660,10 +1801,10 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
                 if (z == 0) launch_row_bwd(c, groups[gi].B, z, c->bufB, nullptr, nullptr, 2);
                 else if (top) launch_row_bwd(c, groups[gi].B, z, c->bufB, rc_last, c->bufA, 0);
                 else launch_row_bwd(c, groups[gi].B, z, c->bufB, rc1, c->bufA, 3, 1.f);
-                if (z > 0) launch_row_prop(c, groups[gi].B, c->bufA, c->bufB, c->hs, 1.f, 1);
+                if (z > 0) launch_row_prop(c, groups[gi].B, c->bufA, c->bufB, c->hs, 1.f, 1, z - 1);
                 if (z > 1) {
                     launch_row_unmod(c, groups[gi].B, z, top ? rc_last : rc1, rc2, top, 1.f);
-                    launch_row_prop(c, groups[gi].B, rc2, rc1, c->hs, 1.f, 1);
+                    launch_row_prop(c, groups[gi].B, rc2, rc1, c->hs, 1.f, 1, z - 1);
                 }
                 continue;
             }
@@ -1672,7 +1813,7 @@ int bdof_loss_grad(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, c
                                z > 0 ? 1 : 2);
             else
                 launch_row_bwd(c, groups[gi].B, z, c->bufB, c->tape + (size_t)z * fld, z > 0 ? c->bufA : nullptr);
-            if (z > 0) launch_row_prop(c, groups[gi].B, c->bufA, c->bufB, c->hs, 1.f, 1);
+            if (z > 0) launch_row_prop(c, groups[gi].B, c->bufA, c->bufB, c->hs, 1.f, 1, z - 1);
         }
     }
     if ((r = join_streams(c, ng))) return r;

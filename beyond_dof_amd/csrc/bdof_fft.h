@@ -32,6 +32,9 @@ __device__ __forceinline__ cf cscale(cf a, float s) { return make_float2(a.x * s
 //    constant is exact to 1e-15 for 2 more FMAs — 6.1e-6 / 5.8e-6 / 3.7e-6 / 7.0e-6 on the same four numbers for +3.2 ms (4.8 %)
 //    of the cfg3 step.  The kernels that run once per step (detector plane, loss) use it; -DBDOF_EXACT_TRANSFORMS builds the
 //    per-slice kernels with it too (round 3's first default, kept for comparison).
+#if defined(BDOF_EXACT_TWIDDLES) || defined(BDOF_FAST_ADJOINT) || defined(BDOF_FAST_FORWARD)
+#error "BDOF_EXACT_TWIDDLES / BDOF_FAST_ADJOINT / BDOF_FAST_FORWARD (rounds 2-3) no longer exist: the per-slice kernels run with dithered constants; -DBDOF_EXACT_TRANSFORMS builds them with hi + lo tables"
+#endif
 #ifndef BDOF_EXACT_CONSTANTS
 #define BDOF_EXACT_CONSTANTS 1          // sqrt(1/2) as a hi + lo pair wherever no dithered value is handed in (mul_sqrt_half)
 #endif

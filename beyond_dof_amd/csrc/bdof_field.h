@@ -1,0 +1,104 @@
+// Whole-field / tile-batch operations of the tiled ("pfft") propagator in either precision (DESIGN: cfg4).
+//
+//  * free-space steps of a batch of fields in ONE transform pair (rocFFT, batched 2-D, in place): field <- F^-1 ( h * F field )
+//    with a caller-supplied table h[kx][ky] (the n-th power of the transfer function, 1 / (NX NY) folded in) — the long-range
+//    correction of the tiled propagator applies it once per stitch range to the whole field and to the tile batch;
+//  * the float64 tile path (TiledPropagator(precision='float64')): the reference's arithmetic is float64
+//    (cnn_propagator/np_funcs.py:20-42, quirk Q2) and a 1024-slice stack run through float32 transforms carries 1.5e-5 of
+//    rounding; here modulation, transforms (rocFFT double) and the transfer-function product are float64, unfused;
+//  * tile cut-out / write-back and axpy in float64.
+#pragma once
+#include "bdof_generic.h"
+
+// f[i] *= h[i mod per_field]     (C2 = float2 / double2)
+template <class C2>
+__global__ __launch_bounds__(256) void k_f_hmul(C2* __restrict__ f, const C2* __restrict__ h, size_t per_field, size_t n, int conj_h) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const C2 a = f[i];
+        C2 t = h[i % per_field];
+        if (conj_h) t.y = -t.y;
+        C2 o;
+        o.x = a.x * t.x - a.y * t.y;
+        o.y = a.x * t.y + a.y * t.x;
+        f[i] = o;
+    }
+}
+
+// y += alpha x on n real numbers
+template <class R>
+__global__ __launch_bounds__(256) void k_f_axpy(R* __restrict__ y, const R* __restrict__ x, R alpha, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += alpha * x[i];
+}
+
+__global__ __launch_bounds__(256) void k_f_to_double(const cf* __restrict__ src, double2* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = make_double2((double)src[i].x, (double)src[i].y);
+}
+__global__ __launch_bounds__(256) void k_f_to_float(const double2* __restrict__ src, cf* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = make_float2((float)src[i].x, (float)src[i].y);
+}
+
+// ---- tiles in float64: the same cut-out / write-back as k_tiles_gather (mode 0) / k_tiles_scatter (bdof_kernels.h) ----------
+struct Tile64Args {
+    double2* field;     // [FX][FY]
+    double2* tiles;     // [B][TX][TY]
+    const int* x0;
+    const int* y0;
+    int B, FX, FY, TX, TY, hx, hy, taper;
+};
+__device__ __forceinline__ double taper_weight64(int i, int n, int taper) {
+    const int e = min(i, n - 1 - i);
+    return e < taper ? 0.5 - 0.5 * cos(3.14159265358979323846 * ((double)e + 0.5) / (double)taper) : 1.0;
+}
+__global__ __launch_bounds__(256) void k_tiles_gather64(Tile64Args a) {
+    const int b = blockIdx.z;
+    const int ox = a.x0[b], oy = a.y0[b];
+    for (int x = blockIdx.y; x < a.TX; x += gridDim.y) {
+        double2* dst = a.tiles + ((size_t)b * a.TX + x) * a.TY;
+        const double2* src = a.field + (size_t)wrap_idx(ox + x, a.FX) * a.FY;
+        const double wx = taper_weight64(x, a.TX, a.taper);
+        for (int y = blockIdx.x * blockDim.x + threadIdx.x; y < a.TY; y += gridDim.x * blockDim.x) {
+            const double w = wx * taper_weight64(y, a.TY, a.taper);
+            const double2 v = src[wrap_idx(oy + y, a.FY)];
+            dst[y] = make_double2(v.x * w, v.y * w);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_tiles_scatter64(Tile64Args a) {
+    const int b = blockIdx.z;
+    const int ox = a.x0[b], oy = a.y0[b];
+    for (int x = a.hx + blockIdx.y; x < a.TX - a.hx; x += gridDim.y) {
+        const int xg = ox + x;
+        if (xg < 0 || xg >= a.FX) continue;
+        double2* dst = a.field + (size_t)xg * a.FY;
+        const double2* src = a.tiles + ((size_t)b * a.TX + x) * a.TY;
+        for (int y = a.hy + blockIdx.x * blockDim.x + threadIdx.x; y < a.TY - a.hy; y += gridDim.x * blockDim.x) {
+            const int yg = oy + y;
+            if (yg >= 0 && yg < a.FY) dst[yg] = src[y];
+        }
+    }
+}
+
+// phi = c psi, c = exp(i k delta) exp(-k beta) from the caller's (delta, beta) rows (cnn_propagator/np_funcs.py:37-40), float64
+struct Mod64Args {
+    double2* field;      // [B][NX][NY]
+    ObjView obj;         // .vol = the (delta, beta) rows themselves (not the float32 table of c - 1)
+    int B, NX, NY, z;
+    double k;
+};
+__global__ __launch_bounds__(256) void k_f64_modulate(Mod64Args a) {
+    const size_t n = (size_t)a.B * a.NX * a.NY;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int y = idx % a.NY;
+        const size_t r = idx / a.NY;
+        const int x = r % a.NX, b = r / a.NX;
+        const float2 db = g_mod_value(a.obj, b, x, y, a.z, a.NX);
+        if (db.x == 0.f && db.y == 0.f) continue;                   // vacuum: c = 1
+        double s, cs;
+        sincos(a.k * (double)db.x, &s, &cs);
+        const double e = exp(-a.k * (double)db.y);
+        const double2 v = a.field[idx];
+        a.field[idx] = make_double2(e * (v.x * cs - v.y * s), e * (v.x * s + v.y * cs));
+    }
+}

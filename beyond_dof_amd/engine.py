@@ -57,9 +57,12 @@ class MultisliceEngine(object):
         self._tables = None
 
     # ---- physics -------------------------------------------------------------------------------
-    def set_physics(self, energy_ev, psize_cm, free_prop_cm=None, variant='numpy_skip_last', pi=util.PI, field_shape=None):
+    def set_physics(self, energy_ev, psize_cm, free_prop_cm=None, variant='numpy_skip_last', pi=util.PI, field_shape=None,
+                    detector_kernel='TF'):
         """k and H exactly as cnn_propagator/np_funcs.py:19-32,45-57 derive them from energy / pixel size.  field_shape: this
-        engine's wavefields are tiles of a (FY, FX) field and apply that field's propagator (util.get_kernel_tile)."""
+        engine's wavefields are tiles of a (FY, FX) field and apply that field's propagator (util.get_kernel_tile).
+        detector_kernel: 'TF' (what np_funcs.py:55 forces), 'IR' (get_kernel_ir, np_funcs.py:59-61) or 'auto' (the sampling
+        criterion of np_funcs.py:51-53) for the step to a detector at a finite distance."""
         voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
         lmbda_nm = 1240. / energy_ev
         delta_nm = voxel_nm[-1]
@@ -67,6 +70,7 @@ class MultisliceEngine(object):
         hs = util.device_transfer_function(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, field_shape=field_shape)
         h00 = np.array(util.transfer_function_dc(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, field_shape=field_shape))
         hdet = hdet00 = None
+        self.det_kernel = 'TF'
         if free_prop_cm is None:
             det = _lib.DET_NONE
         elif isinstance(free_prop_cm, str):
@@ -75,8 +79,9 @@ class MultisliceEngine(object):
             det = _lib.DET_FAR
         else:
             det = _lib.DET_NEAR
-            hdet = util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi)
-            hdet00 = np.array(util.transfer_function_dc(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi))
+            self.det_kernel = util.detector_kernel_kind(detector_kernel, free_prop_cm * 1e7, lmbda_nm, voxel_nm, (self.ny, self.nx))
+            hdet = util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, kernel=self.det_kernel)
+            hdet00 = np.array(util.transfer_function_dc(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, kernel=self.det_kernel))
         self.det_mode = det
         self.variant = variant
         self.k = k
@@ -94,7 +99,8 @@ class MultisliceEngine(object):
             hs64 = util.device_transfer_function(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, field_shape=field_shape, dtype=np.complex128)
             hd64 = None
             if det == _lib.DET_NEAR:
-                hd64 = util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, dtype=np.complex128)
+                hd64 = util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, dtype=np.complex128,
+                                                     kernel=self.det_kernel)
             self.ctx.check(self.lib.bdof_set_physics_f64(self.h, hs64.ctypes.data, hd64.ctypes.data if hd64 is not None else None))
         if getattr(self, '_probe_args', None) is not None:
             self.set_probe(*self._probe_args)      # the carrier (field, calibration) of the probe depends on the physics
@@ -118,7 +124,7 @@ class MultisliceEngine(object):
             if variant == 'tf_all':
                 p = np.fft.ifft2(np.fft.fft2(p) * h)
             if self.det_mode == _lib.DET_NEAR:
-                hd = np.fft.ifftshift(util.get_kernel(free_prop_cm * 1e7, lmbda_nm, voxel_nm, (self.ny, self.nx), pi=pi))
+                hd = np.fft.ifftshift(util.centred_kernel(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, kernel=self.det_kernel))
                 p = np.fft.ifft2(np.fft.fft2(p) * hd)
             det = p
         return np.ascontiguousarray(stack), np.ascontiguousarray(det.T.astype(np.complex64))
@@ -135,7 +141,9 @@ class MultisliceEngine(object):
         hT = np.ascontiguousarray(np.fft.ifftshift(kern(voxel_nm[-1])).T.astype(np.complex128))
         hdT = None
         if self.det_mode == _lib.DET_NEAR:
-            hdT = np.ascontiguousarray(np.fft.ifftshift(kern(free_prop_cm * 1e7)).T.astype(np.complex128))
+            kd = kern(free_prop_cm * 1e7) if self.det_kernel == 'TF' else \
+                util.centred_kernel(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, kernel='IR')
+            hdT = np.ascontiguousarray(np.fft.ifftshift(kd).T.astype(np.complex128))
         p = np.ascontiguousarray(probe_c64.T.astype(np.complex128))
         self.ctx.check(self.lib.bdof_set_probe_field(self.h, p.ctypes.data, hT.ctypes.data, hdT.ctypes.data if hdT is not None else None))
 
@@ -194,7 +202,7 @@ class MultisliceEngine(object):
             det = np.fft.fft2(p_end)                                                                   # [ky][kx], un-shifted
         elif self.det_mode == _lib.DET_NEAR:
             voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
-            hd = np.fft.ifftshift(util.get_kernel(free_prop_cm * 1e7, 1240. / energy_ev, voxel_nm, (self.ny, self.nx), pi=pi))
+            hd = np.fft.ifftshift(util.centred_kernel(free_prop_cm * 1e7, 1240. / energy_ev, voxel_nm, self.ny, self.nx, pi=pi, kernel=self.det_kernel))
             det = np.fft.ifft2(np.fft.fft2(p_end) * hd).T                                              # [x][y]
         else:
             det = p_end.T

@@ -175,7 +175,8 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
         solver = FullfieldSolver(dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm * ds_level,
                                  free_prop_cm=free_prop_cm, probe_real=probe_real, probe_imag=probe_imag, variant=variant,
                                  comm=comm, device=comm.local_rank, coord_ls=coord_ls, propagator=propagator, kernel_size=kernel_size,
-                                 rotation=rotation, theta=theta, adjoint64=adjoint_precision == 'float64')
+                                 rotation=rotation, theta=theta, adjoint64=adjoint_precision == 'float64',
+                                 detector_kernel=kwargs.get('detector_kernel', 'TF'))   # 'IR' / 'auto': np_funcs.py:51-61
         solver.set_volume(obj_delta, obj_beta)
         solver.set_mask(mask)
         solver.set_measurements(np.abs(prj))
@@ -212,6 +213,11 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
                 if debug:
                     solver.ctx.sync()
                     print_flush('Minibatch done in {} s (rank {})'.format(time.time() - t00, rank))
+                    if i_batch % 10 == 0:
+                        # cnn_propagator/fullfield.py:372-374: |exit waves| of this rank's minibatch through the updated object
+                        temp_exit = solver.forward_angles(this_ind_batch)
+                        tiffio.write_tiff(np.abs(temp_exit), os.path.join(output_folder, 'exits', '{}-{}'.format(i_epoch, i_batch)),
+                                          dtype='float32', overwrite=True)
             this_loss = solver.loss_and_grad(this_ind_batch, want_loss=True)
             if size > 1:
                 this_loss = float(comm.allreduce_sum_host(np.array([this_loss]))[0]) / size

@@ -3,7 +3,9 @@ import os
 
 SUMMARY_PRESET_PTYCHO = ['obj_size', 'probe_size', 'output_folder', 'theta_downsample', 'n_theta', 'n_pos', 'n_epochs',
                          'learning_rate', 'alpha_d', 'alpha_b', 'gamma', 'n_dp_batch', 'minibatch_size', 'free_prop_cm',
-                         'psize_cm', 'energy_ev', 'fname', 'probe_mag_sigma', 'probe_phase_sigma', 'probe_phase_max']
+                         'psize_cm', 'energy_ev', 'fname', 'probe_mag_sigma', 'probe_phase_sigma', 'probe_phase_max',
+                         # not in the reference's preset: the precision the adjoint sweep was ASKED to run in and the one it runs in
+                         'adjoint_precision', 'adjoint_precision_effective']
 SUMMARY_PRESET_FF = ['obj_size', 'output_folder', 'theta_downsample', 'n_theta', 'n_epochs', 'learning_rate', 'alpha_d',
                      'alpha_b', 'gamma', 'minibatch_size', 'free_prop_cm', 'psize_cm', 'energy_ev', 'fname', 'object_type']
 

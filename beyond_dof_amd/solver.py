@@ -82,9 +82,15 @@ class _VolumeSolver(object):
         self.ctx.check(self.ctx.lib.bdof_get_loss(self.ctx.handle, ctypes.byref(loss)))
         return loss.value
 
+    def _g_is_local(self):
+        """self.g is about to be rewritten whole with this rank's own, unreduced gradient: the shard layout a sharded step
+        left behind no longer describes it (gradient_to_host would otherwise gather stale parts over it)."""
+        self._g_shards = None
+
     def gradient_to_host(self):
         """The gradient of the last step / loss_and_grad as (g_delta, g_beta), each (Y, X, Z).  After a sharded step every rank
-        holds the reduced gradient of its own 1/size of each slab only: the parts are gathered first."""
+        holds the reduced gradient of its own 1/size of each slab only: the parts are gathered first — the call is then a
+        COLLECTIVE, every rank must make it.  After loss_and_grad (or a step in the all-reduce form) it is a local read-back."""
         if self._g_shards:
             per_x = self.dim_z * self.dim_y * 2
             for x0, nx in self._g_shards:
@@ -327,7 +333,8 @@ class _VolumeSolver(object):
 class FullfieldSolver(_VolumeSolver):
     def __init__(self, dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm, free_prop_cm=None,
                  probe_real=None, probe_imag=None, variant='numpy_skip_last', comm=None, device=0, stream=None,
-                 coord_ls=None, propagator='fft', kernel_size=17, recompute=None, rotation='nearest', theta=None, adjoint64=None):
+                 coord_ls=None, propagator='fft', kernel_size=17, recompute=None, rotation='nearest', theta=None, adjoint64=None,
+                 detector_kernel='TF'):
         """propagator='fft': the transfer-function step of np_funcs.py (north-star path); 'conv': the truncated real-space
         kernel of propagation.py, what cnn_propagator/fullfield.py:87,102 calls (kernel_size taps per axis).
         rotation='nearest': the cnn variant's lookup tables, fused into the kernels (cnn_propagator/util.py:294-402);
@@ -348,7 +355,7 @@ class FullfieldSolver(_VolumeSolver):
         self.eng = MultisliceEngine(self.dim_y, self.dim_x, self.dim_z, self.mb, with_grad=True, device=device, stream=stream,
                                     recompute=recompute, adjoint64=adjoint64)
         self.ctx = self.eng.ctx
-        self.eng.set_physics(energy_ev, psize_cm, free_prop_cm, variant=variant)
+        self.eng.set_physics(energy_ev, psize_cm, free_prop_cm, variant=variant, detector_kernel=detector_kernel)
         if self.conv:
             self.eng.set_conv(energy_ev, psize_cm, kernel_size)
         if probe_real is None:
@@ -433,6 +440,7 @@ class FullfieldSolver(_VolumeSolver):
     def loss_and_grad(self, angle_idx, want_loss=True):
         """Data-term loss and its gradient w.r.t. the volume for this rank's angles (left in self.g, not reduced)."""
         self._rot_loss_grad(angle_idx)
+        self._g_is_local()
         self._produce()(0, self.dim_x)
         return self._get_loss() if want_loss else None
 
@@ -460,6 +468,7 @@ class FullfieldSolver(_VolumeSolver):
         self._probe_collect()
         nb = max(1, int(n_batch_per_update))
         if nb > 1:
+            self._g_is_local()
             self._produce(accumulate=self._acc > 0)(0, self.dim_x)
             self._acc += 1
             if self._acc == nb or last_of_epoch:
@@ -588,6 +597,7 @@ class PtychoSolver(_VolumeSolver):
     def _produce_all(self):
         ctx = self._last_ctx
         i_theta, xo, yo = self._last
+        self._g_is_local()
         ctx.check(ctx.lib.bdof_window_rotation_adjoint(ctx.handle, self.mb, i_theta, xo, yo, self.g.ptr, 0, 1.0))
         if ctx is not self.ctx:
             ctx.sync()                               # the tail of the step (exchange, Adam) runs on self.ctx's stream

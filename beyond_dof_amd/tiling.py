@@ -10,6 +10,21 @@ steepest ray the grid carries); before they have crossed the halo the cores are 
 re-cut with fresh halos (bdof_tiles_scatter / bdof_tiles_gather).  The tiles apply the FIELD's transfer function
 (util.get_kernel_tile), not that of a T-point mesh.
 
+Long-range correction (long_range=True; round 4).  The band-limited whole-field propagator has alternating tails
+~ lambda dz n / (2 pi x^2) after n slices that reach across the whole field; a tile sees no source beyond its halo, and at
+BASELINE cfg4's depth (1024 slices) that alone puts 2.2e-5 between the tiled and the whole-field exit wave — in float64,
+whatever the stitch interval (tools/cfg4_f64_torch.py).  Free space composes (P^n = F^-1 H^n F), so once per stitch range the
+missing part is added back:  psi_out = stitch(T psi_in) + D psi_in,  D = (whole-field free-space step over the range) - (the
+tiles' own free-space step, stitched) — one whole-field transform pair and one transform pair per tile per RANGE
+(bdof_fields_free_step), exact to first order in the object's phase over a range.  With ranges shorter than the band edge's
+phase-winding length, 4 dx^2 / (lambda dz) slices (16 at 5 keV / 1 nm — the default interval with the correction on), the
+tiling error at cfg4's depth is 9e-7 (64-pixel halo; 2e-6 with 32).
+
+precision='float64': the tiles run in float64 (bdof_forward_range_f64: rocFFT double transforms, point-wise kernels) on a
+complex128 field — the reference's own precision (np_funcs.py:20-42, quirk Q2).  Through float32 transforms the exit wave of a
+1024-slice stack carries 1.5e-5 of rounding (4.6e-7 sqrt(S)); 'auto' switches to float64 beyond 384 slices, where that
+passes ~0.9e-5.  Unfused, ~4x the time of the fused float32 kernels.
+
 Several GPUs (comm with size > 1): the tiles are dealt to the ranks round-robin; every rank keeps the whole field.  At a
 stitch a rank writes its own cores into a zeroed field and the fields are summed over the ranks (every pixel lies in
 exactly one core, so the sum only fills in); in the adjoint sweep the tapered scatter-add of the tiles and, at the end, the
@@ -25,10 +40,14 @@ from .engine import MultisliceEngine
 
 class TiledPropagator(object):
     def __init__(self, field_shape, n_slice, energy_ev, psize_cm, tile=512, halo=64, slices_per_exchange=None, safety=0.5,
-                 taper=None, variant='numpy_skip_last', device=0, pi=util.PI, with_grad=False, comm=None):
+                 taper=None, variant='numpy_skip_last', device=0, pi=util.PI, with_grad=False, comm=None, long_range='auto',
+                 precision='auto'):
         """field_shape (FY, FX); tile: fused plan size (64 ... 1024); halo: pixels per side that are recomputed, not kept; its
         outer `taper` pixels (default halo / 2) are ramped to zero so that the tile's periodic boundary has no jump.
-        slices_per_exchange: slices between two stitches; default safety * (halo - taper) / (lambda dz / (2 dx^2))."""
+        slices_per_exchange: slices between two stitches; default safety * (halo - taper) / (lambda dz / (2 dx^2)), or, with
+        the long-range correction, the band edge's phase-winding length 4 dx^2 / (lambda dz) if that is shorter.
+        long_range: True / False / 'auto' (on for the forward model of stacks deeper than one default stitch range; the
+        gradient sweep does not carry it yet).  precision: 'float32' / 'float64' / 'auto' (float64 beyond 384 slices)."""
         self.fy, self.fx = int(field_shape[0]), int(field_shape[1])
         self.n_slice, self.tile, self.halo = int(n_slice), int(tile), int(halo)
         if 2 * self.halo >= self.tile:
@@ -39,8 +58,27 @@ class TiledPropagator(object):
         voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
         lmbda_nm = 1240. / energy_ev
         self.spread_px = lmbda_nm * voxel_nm[2] / (2. * voxel_nm[0] ** 2)      # lateral reach of the band-edge ray per slice
+        geometric = max(1, int(safety * (self.halo - self.taper) / self.spread_px)) if self.halo > 0 else self.n_slice
+        self.with_grad = bool(with_grad)
+        if long_range == 'auto':
+            long_range = (not self.with_grad) and self.halo > 0 and self.n_slice > geometric and (comm is None or comm.size == 1) and \
+                (slices_per_exchange is None or slices_per_exchange < self.n_slice)
+        self.long_range = bool(long_range)
+        if self.long_range and self.with_grad:
+            raise ValueError('the long-range correction is implemented for the forward model (with_grad=False)')
+        if self.long_range and (comm is not None and comm.size > 1):
+            raise ValueError('the long-range correction runs on one rank (it transforms the whole field)')
+        if precision == 'auto':
+            precision = 'float64' if (self.n_slice > 384 and not self.with_grad and (comm is None or comm.size == 1)) else 'float32'
+        if precision not in ('float32', 'float64'):
+            raise ValueError("precision must be 'float32', 'float64' or 'auto'")
+        if precision == 'float64' and (self.with_grad or (comm is not None and comm.size > 1)):
+            raise ValueError("precision='float64' is implemented for the forward model on one rank")
+        self.precision = precision
+        # slices in which the band edge's phase pi lambda dz / (2 dx)^2 winds by pi: beyond it the first-order correction degrades
+        self.winding = max(1, int(4. * voxel_nm[0] ** 2 / (lmbda_nm * voxel_nm[2])))
         if slices_per_exchange is None:
-            slices_per_exchange = max(1, int(safety * (self.halo - self.taper) / self.spread_px)) if self.halo > 0 else self.n_slice
+            slices_per_exchange = min(geometric, self.winding) if self.long_range else geometric
         self.seg = max(1, int(slices_per_exchange))
         # tile origins: cores tile the field, halos reach periodically across its edges
         ox = [i * self.core - self.halo for i in range(-(-self.fx // self.core))]
@@ -55,7 +93,6 @@ class TiledPropagator(object):
         self.y0 = np.ascontiguousarray(y0[self.comm.rank::self.comm.size])
         self.n_tiles = len(self.x0)
         # gradient: tape-free range sweeps with a per-range gradient buffer (bdof_adjoint_range); the ctx holds no [B][S] workspace
-        self.with_grad = bool(with_grad)
         if self.with_grad and variant != 'tf_all':
             raise ValueError("the tiled gradient is written for variant='tf_all' (a transfer-function step after every slice)")
         self.eng = MultisliceEngine(self.tile, self.tile, self.n_slice, self.n_tiles, with_grad=self.with_grad, device=device,
@@ -66,9 +103,38 @@ class TiledPropagator(object):
         self.eng.set_probe_none()
         self.idx = DeviceBuffer.from_host(self.ctx, np.stack([np.zeros(self.n_tiles, dtype=np.int32), self.x0, self.y0]))
         n = self.n_tiles * self.tile * self.tile
-        self.tiles_in = DeviceBuffer(self.ctx, n * 8, np.complex64, (self.n_tiles, self.tile, self.tile))
-        self.tiles_out = DeviceBuffer(self.ctx, n * 8, np.complex64, (self.n_tiles, self.tile, self.tile))
-        self.field = DeviceBuffer(self.ctx, self.fx * self.fy * 8, np.complex64, (self.fx, self.fy))
+        self.dbl = precision == 'float64'
+        ctype = np.complex128 if self.dbl else np.complex64
+        cb = 16 if self.dbl else 8
+        self.tiles_in = DeviceBuffer(self.ctx, n * cb, ctype, (self.n_tiles, self.tile, self.tile))
+        self.tiles_out = None if self.dbl else DeviceBuffer(self.ctx, n * 8, np.complex64, (self.n_tiles, self.tile, self.tile))
+        self.field = DeviceBuffer(self.ctx, self.fx * self.fy * cb, ctype, (self.fx, self.fy))
+        voxel = voxel_nm
+        self._kernel = lambda power, shape, fshape: self._free_table(voxel[2], lmbda_nm, voxel, shape, fshape, pi, power, ctype)
+        self.k64 = 2. * pi * voxel_nm[2] / lmbda_nm
+        self.h64 = DeviceBuffer.from_host(self.ctx, self._kernel(1, (self.tile, self.tile), (self.fy, self.fx))) if self.dbl else None
+        self._pow_tables = {}
+        if self.long_range:
+            self.tiles_free = DeviceBuffer(self.ctx, n * cb, ctype, (self.n_tiles, self.tile, self.tile))
+            self.whole = DeviceBuffer(self.ctx, self.fx * self.fy * cb, ctype, (self.fx, self.fy))
+
+    @staticmethod
+    def _free_table(dist_nm, lmbda_nm, voxel_nm, shape, field_shape, pi, power, ctype):
+        """The `power`-th power of the transfer function of one slice step for bdof_fields_free_step: un-shifted, [kx][ky],
+        1 / (NX NY) folded in, formed in float64 (H = exp(i phase): the power is taken on the phase)."""
+        ny, nx = shape
+        if tuple(shape) == tuple(field_shape):
+            h = util.get_kernel(dist_nm * power, lmbda_nm, voxel_nm, (ny, nx), pi=pi)
+        else:
+            h = util.get_kernel_tile(dist_nm * power, lmbda_nm, voxel_nm, (ny, nx), field_shape, pi=pi)
+        return np.ascontiguousarray((np.fft.ifftshift(h) / float(nx * ny)).T.astype(ctype))
+
+    def _tables(self, power):
+        """(tile table, field table) of `power` consecutive free-space steps, on the device; built once per distinct power."""
+        if power not in self._pow_tables:
+            self._pow_tables[power] = (DeviceBuffer.from_host(self.ctx, self._kernel(power, (self.tile, self.tile), (self.fy, self.fx))),
+                                       DeviceBuffer.from_host(self.ctx, self._kernel(power, (self.fy, self.fx), (self.fy, self.fx))))
+        return self._pow_tables[power]
 
     # ---- object --------------------------------------------------------------------------------
     def set_object_slab(self, delta2d, beta2d):
@@ -96,13 +162,33 @@ class TiledPropagator(object):
         variant == 'tf_all')."""
         lib, h, p = self.lib, self.h, self.idx.ptr
         a, xo, yo = p, p + 4 * self.n_tiles, p + 8 * self.n_tiles
+        B, T, dbl = self.n_tiles, self.tile, int(self.dbl)
+        gather = lib.bdof_tiles_gather_f64 if self.dbl else lib.bdof_tiles_gather
         for z0, nz in self.segments():
             last = z0 + nz == self.n_slice
-            self.ctx.check(lib.bdof_tiles_gather(h, self.field.ptr, self.fx, self.fy, self.tiles_in.ptr, self.n_tiles, self.tile, self.tile, xo, yo,
-                                                 self.taper))
-            self.ctx.check(lib.bdof_forward_range(h, self.n_tiles, a, xo, yo, z0, nz, self.tiles_in.ptr, self.tiles_out.ptr,
-                                                  int(not last or self.variant == 'tf_all')))
-            self._stitch(self.tiles_out)
+            prop_last = int(not last or self.variant == 'tf_all')
+            nprop = nz - 1 + prop_last                       # transfer-function steps of this range
+            self.ctx.check(gather(h, self.field.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.taper))
+            corr = self.long_range and nprop > 0
+            if corr:
+                # D psi_in: what the field's own propagator does over the range in free space, minus what the tiles' does
+                t_tab, f_tab = self._tables(nprop)
+                nb = self.tiles_in.nbytes
+                self.ctx.check(lib.bdof_memcpy_d2d(h, self.tiles_free.ptr, self.tiles_in.ptr, nb))
+                self.ctx.check(lib.bdof_fields_free_step(h, self.tiles_free.ptr, B, T, T, t_tab.ptr, 0, dbl))
+                self.ctx.check(lib.bdof_memcpy_d2d(h, self.whole.ptr, self.field.ptr, self.field.nbytes))
+                self.ctx.check(lib.bdof_fields_free_step(h, self.whole.ptr, 1, self.fx, self.fy, f_tab.ptr, 0, dbl))
+            if self.dbl:
+                self.ctx.check(lib.bdof_forward_range_f64(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, self.h64.ptr, self.k64, prop_last))
+                out = self.tiles_in
+            else:
+                self.ctx.check(lib.bdof_forward_range(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, self.tiles_out.ptr, prop_last))
+                out = self.tiles_out
+            if corr:
+                self.ctx.check(lib.bdof_caxpy(h, out.ptr, self.tiles_free.ptr, -1.0, B * T * T, dbl))
+            self._stitch(out)
+            if corr:
+                self.ctx.check(lib.bdof_caxpy(h, self.field.ptr, self.whole.ptr, 1.0, self.fx * self.fy, dbl))
 
     def _sum_over_ranks(self, buf):
         if self.comm.size > 1:
@@ -113,14 +199,16 @@ class TiledPropagator(object):
         p = self.idx.ptr
         if self.comm.size > 1:
             self.ctx.check(self.lib.bdof_memset(self.h, self.field.ptr, 0, self.field.nbytes))
-        self.ctx.check(self.lib.bdof_tiles_scatter(self.h, tiles.ptr, self.field.ptr, self.fx, self.fy, self.n_tiles, self.tile, self.tile,
-                                                   p + 4 * self.n_tiles, p + 8 * self.n_tiles, self.halo, self.halo))
+        scatter = self.lib.bdof_tiles_scatter_f64 if self.dbl else self.lib.bdof_tiles_scatter
+        self.ctx.check(scatter(self.h, tiles.ptr, self.field.ptr, self.fx, self.fy, self.n_tiles, self.tile, self.tile,
+                               p + 4 * self.n_tiles, p + 8 * self.n_tiles, self.halo, self.halo))
         self._sum_over_ranks(self.field)
 
     def forward(self, probe_real, probe_imag):
-        """Exit wave (FY, FX) complex64 of the probe (FY, FX) through the object."""
+        """Exit wave (FY, FX) of the probe (FY, FX) through the object: complex64, or complex128 with precision='float64'.
+        The probe is rounded to complex64 first, as np_funcs.py:20-21 does."""
         probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.fy, self.fx))
-        self.field.upload(np.ascontiguousarray(probe.T.astype(np.complex64)))
+        self.field.upload(np.ascontiguousarray(probe.T.astype(np.complex64).astype(self.field.dtype)))
         self.forward_device()
         self.ctx.sync()
         return np.ascontiguousarray(self.field.download().T)
@@ -174,3 +262,35 @@ class TiledPropagator(object):
             return loss, np.ascontiguousarray(g[..., 0].T), np.ascontiguousarray(g[..., 1].T)
         gd, gb = util.rows_to_volume(g)
         return loss, gd, gb
+
+
+class WholeFieldPropagator(object):
+    """np_funcs.py:36-43 on the WHOLE (FY, FX) field in float64 on the device: c = exp(i k delta) exp(-k beta) from the object's
+    rows, rocFFT double-precision transforms of the field, the field's own transfer function (bdof_forward_range_f64 with one
+    "tile" that is the field).  What the tiled propagator is measured against at depths the host cannot reach in a test
+    (1024 slices of 4096^2 in complex128 take 393 s of host FFTs, 3 s here); itself checked against the host's float64
+    run at 96 slices (tests/test_gpu_tiling.py)."""
+
+    def __init__(self, field_shape, n_slice, energy_ev, psize_cm, variant='numpy_skip_last', device=0, pi=util.PI):
+        self.fy, self.fx, self.n_slice, self.variant = int(field_shape[0]), int(field_shape[1]), int(n_slice), variant
+        voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
+        lmbda_nm = 1240. / energy_ev
+        self.eng = MultisliceEngine(self.fy, self.fx, self.n_slice, 1, with_grad=False, device=device, engine='generic')
+        self.ctx, self.lib, self.h = self.eng.ctx, self.eng.lib, self.eng.h
+        self.k64 = 2. * pi * voxel_nm[2] / lmbda_nm
+        self.h64 = DeviceBuffer.from_host(self.ctx, TiledPropagator._free_table(voxel_nm[2], lmbda_nm, voxel_nm, (self.fy, self.fx),
+                                                                                (self.fy, self.fx), pi, 1, np.complex128))
+        self.field = DeviceBuffer(self.ctx, self.fx * self.fy * 16, np.complex128, (self.fx, self.fy))
+        self.idx = DeviceBuffer.from_host(self.ctx, np.zeros(3, dtype=np.int32))
+
+    set_object_slab = TiledPropagator.set_object_slab
+    set_object = TiledPropagator.set_object
+
+    def forward(self, probe_real, probe_imag):
+        probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.fy, self.fx))
+        self.field.upload(np.ascontiguousarray(probe.T.astype(np.complex64).astype(np.complex128)))
+        p = self.idx.ptr
+        self.ctx.check(self.lib.bdof_forward_range_f64(self.h, 1, p, p + 4, p + 8, 0, self.n_slice, self.field.ptr, self.h64.ptr, self.k64,
+                                                       int(self.variant == 'tf_all')))
+        self.ctx.sync()
+        return np.ascontiguousarray(self.field.download().T)

@@ -26,7 +26,8 @@ def get_kernel(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=PI):
 def get_kernel_ir(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=PI):
     """Impulse-response form of the Fresnel kernel (cnn_propagator/util.py:105-127): the real-space kernel sampled on the
     pixel grid, Fourier transformed, times the pixel area.  The reference's propagator never selects it (np_funcs.py:55
-    forces 'TF'); kept as the `kernel='IR'` option of device_transfer_function."""
+    forces 'TF' after computing the sampling criterion of :51-53); here it is the detector step's `detector_kernel='IR'`
+    option (detector_kernel below, MultisliceEngine.set_physics), 'auto' applies the reference's criterion."""
     ny, nx = int(grid_shape[0]), int(grid_shape[1])
     k = 2 * pi / lmbda_nm
     sy, sx = voxel_nm[0] * ny, voxel_nm[1] * nx
@@ -68,24 +69,45 @@ def get_kernel_tile(dist_nm, lmbda_nm, voxel_nm, tile_shape, field_shape, pi=PI)
     return np.exp(1j * k * dist_nm) * np.exp(-1j * pi * lmbda_nm * dist_nm * (uu ** 2 + vv ** 2))
 
 
-def device_transfer_function(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI, field_shape=None, dtype=np.complex64):
+def detector_kernel_kind(kind, dist_nm, lmbda_nm, voxel_nm, grid_shape):
+    """'TF' or 'IR' for the detector step.  'auto' is the criterion cnn_propagator/np_funcs.py:51-53 computes (and then
+    overrides with 'TF' at :55): transfer function where the mean voxel size exceeds lambda z / L, impulse response otherwise."""
+    if kind in ('TF', 'IR'):
+        return kind
+    if kind != 'auto':
+        raise ValueError("detector_kernel must be 'TF', 'IR' or 'auto'")
+    voxel_nm = np.asarray(voxel_nm, dtype=float)
+    size_nm = np.array(grid_shape) * voxel_nm[:len(grid_shape)]
+    crit_samp = lmbda_nm * dist_nm / np.prod(size_nm) ** (1. / len(size_nm))
+    return 'TF' if np.prod(voxel_nm) ** (1. / 3) > crit_samp else 'IR'
+
+
+def centred_kernel(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI, field_shape=None, kernel='TF'):
+    """The centred (ny, nx) multiplier of one propagation step: get_kernel, get_kernel_tile (a tile of a larger field) or
+    get_kernel_ir (kernel='IR', whole fields only)."""
+    if kernel == 'IR':
+        if field_shape is not None:
+            raise ValueError("kernel='IR' is defined for whole fields, not for tiles of a larger one")
+        return get_kernel_ir(dist_nm, lmbda_nm, voxel_nm, (ny, nx), pi=pi)
+    if kernel != 'TF':
+        raise ValueError("kernel must be 'TF' or 'IR'")
+    if field_shape is None:
+        return get_kernel(dist_nm, lmbda_nm, voxel_nm, (ny, nx), pi=pi)
+    return get_kernel_tile(dist_nm, lmbda_nm, voxel_nm, (ny, nx), field_shape, pi=pi)
+
+
+def device_transfer_function(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI, field_shape=None, dtype=np.complex64, kernel='TF'):
     """H prepared for libbdof: un-shifted [ky][kx], 1/(NX*NY) folded in, complex64 (complex128: the float64 adjoint sweep's
     table, bdof_set_physics_f64).  field_shape: the (ny, nx) wavefield is a tile of a larger field whose propagator it applies
-    (get_kernel_tile)."""
-    if field_shape is None:
-        h = get_kernel(dist_nm, lmbda_nm, voxel_nm, (ny, nx), pi=pi)
-    else:
-        h = get_kernel_tile(dist_nm, lmbda_nm, voxel_nm, (ny, nx), field_shape, pi=pi)
+    (get_kernel_tile).  kernel='IR': the impulse-response form (get_kernel_ir, cnn_propagator/util.py:105-127)."""
+    h = centred_kernel(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi, field_shape, kernel)
     hs = np.fft.ifftshift(h) / float(nx * ny)
     return np.ascontiguousarray(hs.astype(dtype))
 
 
-def transfer_function_dc(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI, field_shape=None):
+def transfer_function_dc(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi=PI, field_shape=None, kernel='TF'):
     """(re, im) of ifftshift(H)[0][0]: the factor a constant wave picks up in one transfer-function step."""
-    if field_shape is None:
-        h = get_kernel(dist_nm, lmbda_nm, voxel_nm, (ny, nx), pi=pi)
-    else:
-        h = get_kernel_tile(dist_nm, lmbda_nm, voxel_nm, (ny, nx), field_shape, pi=pi)
+    h = centred_kernel(dist_nm, lmbda_nm, voxel_nm, ny, nx, pi, field_shape, kernel)
     v = complex(np.fft.ifftshift(h)[0, 0])
     return v.real, v.imag
 

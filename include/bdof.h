@@ -163,6 +163,33 @@ int bdof_tiles_gather_adjoint(bdof_ctx* ctx, const void* tiles, void* field, int
 int bdof_tiles_grad_add(bdof_ctx* ctx, const void* grot_range, void* gvol, int B, int TX, int TY, const int* x0, const int* y0, int z0, int nz);
 int bdof_field_loss_seed(bdof_ctx* ctx, void* field, const float* meas, int FX, int FY);
 
+/* Long-range correction and float64 path of the tiled propagator (round 4; DESIGN "cfg4").
+ * The band-limited whole-field propagator of np_funcs.py:42 has alternating tails ~ lambda dz n / (2 pi x^2) after n slices that
+ * reach across the whole field; a tile never sees sources beyond its halo, and at 1024 slices that alone is 2.2e-5 of the exit
+ * wave — in float64, whatever the stitch interval.  Free space composes (P^n = F^-1 H^n F), so once per stitch range the part
+ * the tiles miss is added back: D psi_in = (whole-field free-space step over the range) - (the tiles' own, stitched), exact
+ * to first order in the object's phase over one range; with ranges shorter than the band edge's phase-winding length
+ * (4 dx^2 / (lambda dz) = 16 slices at 5 keV / 1 nm) the tiling error drops to 1e-6.
+ * bdof_fields_free_step: fields[b] <- F^-1 ( h * F fields[b] ) for B fields [NX][NY] in place (rocFFT, one batched transform
+ *   pair); h[kx][ky] (device) carries 1 / (NX NY) and whatever power of the transfer function the caller folded in;
+ *   conj_h: the adjoint step; is_double: complex128 fields and table, else complex64.  Any NX, NY rocFFT takes.
+ * bdof_caxpy: y += alpha x on n complex numbers; bdof_c_convert: complex64 <-> complex128 copy.
+ * bdof_tiles_gather_f64 / bdof_tiles_scatter_f64: bdof_tiles_gather / bdof_tiles_scatter on complex128 fields and tiles.
+ * bdof_forward_range_f64: bdof_forward_range on caller-owned complex128 fields [B][NX][NY] IN PLACE, everything in float64 —
+ *   what the reference computes in (np_funcs.py:20-42 promote to complex128, quirk Q2): c = exp(i k delta) exp(-k beta) from
+ *   the (delta, beta) rows of bdof_set_object, rocFFT double-precision transforms, h[kx][ky] / (NX NY) in float64 (device).
+ *   Unfused (an accuracy path, ~4x the time of the fused float32 kernels): a 1024-slice stack through float32 transforms
+ *   carries 1.5e-5 of rounding, this path none. */
+int bdof_fields_free_step(bdof_ctx* ctx, void* fields, int B, int NX, int NY, const void* h, int conj_h, int is_double);
+int bdof_caxpy(bdof_ctx* ctx, void* y, const void* x, double alpha, size_t n, int is_double);
+int bdof_c_convert(bdof_ctx* ctx, void* dst, const void* src, size_t n, int to_double);
+int bdof_tiles_gather_f64(bdof_ctx* ctx, const void* field, int FX, int FY, void* tiles, int B, int TX, int TY, const int* x0,
+                          const int* y0, int taper);
+int bdof_tiles_scatter_f64(bdof_ctx* ctx, const void* tiles, void* field, int FX, int FY, int B, int TX, int TY, const int* x0,
+                           const int* y0, int halo_x, int halo_y);
+int bdof_forward_range_f64(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
+                           void* fields, const void* h, double k, int prop_last);
+
 /* probe_array[i] of np_funcs.py:43 (wave after slice i), device out [B][NX][NY]; valid after a
  * bdof_forward(keep_tape=1) (bdof_loss_grad reuses the tape for its own purposes and invalidates it). */
 int bdof_tape_to_real(bdof_ctx* ctx, int i, int B, void* out);

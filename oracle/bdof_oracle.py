@@ -76,8 +76,8 @@ def _propagate(wavefront, h):
 # ---------------------------------------------------------------------------
 def multislice_propagate_batch_numpy(grid_delta_batch, grid_beta_batch, probe_real, probe_imag, energy_ev,
                                      psize_cm, free_prop_cm=None, obj_batch_shape=None,
-                                     variant='numpy_skip_last', pi=PI, return_probe_array=True):
-    """Restates cnn_propagator/np_funcs.py:15-65.
+                                     variant='numpy_skip_last', pi=PI, return_probe_array=True, detector_kernel='TF'):
+    """Restates cnn_propagator/np_funcs.py:15-65.  detector_kernel='IR': the branch of :58-61 that :55 disables.
 
     ``variant='numpy_skip_last'`` is the reference numpy behaviour (no propagation
     after the last slice, np_funcs.py:41); ``'tf_all'`` propagates after every
@@ -118,7 +118,10 @@ def multislice_propagate_batch_numpy(grid_delta_batch, grid_beta_batch, probe_re
             wavefront = np.fft.fftshift(np.fft.fft2(wavefront), axes=[1, 2])
         else:
             dist_nm = free_prop_cm * 1e7
-            h = get_kernel(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=pi)   # np_funcs.py:55 forces 'TF'
+            if detector_kernel == 'TF':                                      # np_funcs.py:55 forces 'TF'
+                h = get_kernel(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=pi)
+            else:                                                            # np_funcs.py:58-61
+                h = get_kernel_ir(dist_nm, lmbda_nm, voxel_nm, grid_shape, pi=pi)
             wavefront = _propagate(wavefront, h)
     return wavefront, np.array(probe_array)
 
@@ -131,7 +134,7 @@ def multislice_propagate_batch_numpy(grid_delta_batch, grid_beta_batch, probe_re
 # ---------------------------------------------------------------------------
 def multislice_loss_and_grad(grid_delta_batch, grid_beta_batch, probe_real, probe_imag, energy_ev, psize_cm,
                              meas_abs, free_prop_cm=None, variant='numpy_skip_last', pi=PI,
-                             return_probe_grad=False):
+                             return_probe_grad=False, detector_kernel='TF'):
     """loss = mean((|d| - meas_abs)**2) over (B,Y,X) and its gradient w.r.t. the
     (already rotated / windowed) delta and beta batches, shape [B,Y,X,S]."""
     B, Y, X, S = grid_delta_batch.shape
@@ -157,7 +160,7 @@ def multislice_loss_and_grad(grid_delta_batch, grid_beta_batch, probe_real, prob
     elif free_prop_cm == 'inf':
         d = np.fft.fftshift(np.fft.fft2(psi), axes=[1, 2])
     else:
-        hd = get_kernel(free_prop_cm * 1e7, lmbda_nm, voxel_nm, (Y, X, S), pi=pi)
+        hd = (get_kernel if detector_kernel == 'TF' else get_kernel_ir)(free_prop_cm * 1e7, lmbda_nm, voxel_nm, (Y, X, S), pi=pi)
         d = _propagate(psi, hd)
 
     absd = np.abs(d)
@@ -168,7 +171,7 @@ def multislice_loss_and_grad(grid_delta_batch, grid_beta_batch, probe_real, prob
     G = 2.0 * resid * unit / (B * Y * X)           # G(d) = dL/dRe + i dL/dIm
 
     def prop_adj(G, hh):
-        # P = F^-1 diag(ifftshift hh) F is unitary (|hh| = 1): P^H uses conj(hh)
+        # P = F^-1 diag(ifftshift hh) F: P^H = F^-1 diag(conj hh) F for any multiplier (unitary when |hh| = 1)
         return np.fft.ifft2(np.fft.ifftshift(np.fft.fftshift(np.fft.fft2(G), axes=[1, 2]) * np.conj(hh), axes=[1, 2]))
 
     if free_prop_cm is None:

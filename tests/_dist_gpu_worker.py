@@ -40,8 +40,13 @@ def main(out_dir):
         losses.append(s.step(i, mine, 1e-7, alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11, want_loss=True, n_slabs=4, sharded=sharded))
     g = s.gradient_to_host()
     d, b = s.get_volume()
+    # a sharded step followed by loss_and_grad: self.g then holds this rank's own whole gradient, and gradient_to_host must
+    # read it back as it is (the shard layout of the step before no longer applies)
+    s.step(len(sched), mine, 0.0, want_loss=False, n_slabs=4, sharded=sharded)
+    s.loss_and_grad(mine)
+    lg = s.gradient_to_host()
     np.savez(os.path.join(out_dir, 'rank{}_{}.npz'.format(comm.rank, int(sharded))), d=d, b=b, gd=g[0], gb=g[1], losses=np.array(losses),
-             sched=np.array(sched))
+             sched=np.array(sched), lgd=lg[0], lgb=lg[1])
     comm.Barrier()
     comm.close()
 

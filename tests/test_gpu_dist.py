@@ -78,6 +78,10 @@ def test_two_ranks_on_one_gpu_match_the_union_minibatch(tmp_path):
     assert np.array_equal(s0['d'], r0['d']) and np.array_equal(s0['b'], r0['b'])
     # gradient_to_host() after a sharded step gathers the ranks' parts: the all-reduce form's gradient, on both ranks
     assert np.array_equal(s0['gd'], r0['gd']) and np.array_equal(s1['gd'], r0['gd']) and np.array_equal(s0['gb'], r0['gb'])
+    # step(sharded) -> loss_and_grad -> gradient_to_host: the rank's own unreduced gradient, not a gather of stale shards over it
+    for k in ('lgd', 'lgb'):
+        assert np.array_equal(s0[k], r0[k]) and np.array_equal(s1[k], r1[k]), k
+        assert not np.array_equal(s0[k], s1[k])           # the two ranks hold different angles
 
     # single rank, union minibatch (cnn_propagator/fullfield.py:343-351: the ranks' chunks tile the sorted minibatch)
     from beyond_dof_amd import util

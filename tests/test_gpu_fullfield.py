@@ -82,11 +82,17 @@ def test_reconstruct_fullfield_end_to_end(tmp_path, monkeypatch):
     d2, b2 = reconstruct_fullfield('data.h5', n_epochs='auto', max_nepochs=3, crit_conv_rate=1e-9, learning_rate=lr,
                                    minibatch_size=mb, energy_ev=5000, psize_cm=1e-7, free_prop_cm=fp, save_path='case',
                                    output_folder='out2', initial_guess=[init_d, init_b], shrink_cycle=1, seed=7,
-                                   save_intermediate=True, **kw)
+                                   save_intermediate=True, debug=True, **kw)
     s.set_volume(d2, b2)
     l1 = s.loss_and_grad(sched[0])
     assert l1 < l0
     assert os.path.exists(os.path.join('case', 'out2', 'intermediate', 'current.tiff'))
+    # debug=True: |exit waves| of every tenth minibatch (cnn_propagator/fullfield.py:372-374) — here minibatch 0 of each epoch;
+    # the last dump is the forward model of the volume after the first step of the last epoch
+    dumps = sorted(os.listdir(os.path.join('case', 'out2', 'exits')))
+    assert dumps and all(name.endswith('-0.tiff') for name in dumps), dumps
+    ex = tiffio.read_tiff(os.path.join('case', 'out2', 'exits', dumps[0]))
+    assert ex.shape == (mb, n, n) and np.all(np.isfinite(ex)) and abs(ex.mean() - 1) < 0.1
 
 
 def test_reconstruct_fullfield_optimizable_probe_and_accumulation(tmp_path, monkeypatch):

@@ -85,6 +85,49 @@ def test_forward_and_gradient_vs_oracle(engine_mod, Y, X, fp, variant):
     assert rel(gb, rgb) <= 2e-4
 
 
+@pytest.mark.parametrize('probe,variant', [('plane', 'numpy_skip_last'), ('random', 'tf_all'), ('gaussian', 'numpy_skip_last')])
+def test_impulse_response_detector_kernel_on_the_device(engine_mod, golden_dir, probe, variant):
+    """get_kernel_ir (cnn_propagator/util.py:105-127) as the detector step's multiplier — the branch of
+    np_funcs.py:58-61 that :55 disables — on the device: set_physics(detector_kernel='IR') uploads it in place of the
+    transfer function (table, carrier factor H[0,0], the carrier field's detector plane).  The host function is pinned by
+    golden vector G8 (the reference's own get_kernel_ir executed); the device wave, loss and gradient against the oracle
+    with the same kernel.  'auto' applies the reference's criterion (:51-53): 1000 nm behind a 64-nm field it picks 'IR'."""
+    from beyond_dof_amd import util
+    g = np.load(os.path.join(golden_dir, 'g8_kernel_ir_upsample.npz'))
+    for key in ('Hir_32_32_50', 'Hir_32_32_1000', 'Hir_9_12_1000'):                  # the host function the device table comes from
+        ny, nx, dist = (int(v) for v in key.split('_')[1:])
+        assert rel(util.get_kernel_ir(float(dist), 0.248, [1., 1., 1.], (ny, nx)), g[key]) <= 1e-12
+    B, Y, X, S, fp = 2, 64, 64, 6, 1e-4
+    rng = np.random.default_rng(5)
+    delta = rng.uniform(0, 2e-5, size=(B, Y, X, S))
+    beta = 0.1 * delta
+    if probe == 'plane':
+        pr, pi = np.ones((Y, X)), np.zeros((Y, X))
+    elif probe == 'gaussian':
+        pr, pi = orc.gaussian_probe((Y, X), Y / 10., Y / 10., 0.5)
+    else:
+        pr, pi = 1 + 0.1 * rng.normal(size=(Y, X)), 0.1 * rng.normal(size=(Y, X))
+    assert util.detector_kernel_kind('auto', fp * 1e7, 0.248, [1., 1., 1.], (Y, X)) == 'IR'
+    assert util.detector_kernel_kind('auto', 10.0, 0.248, [1., 1., 1.], (Y, X)) == 'TF'
+    eng = engine_mod.MultisliceEngine(Y, X, S, B, with_grad=True)
+    eng.set_physics(5000., 1e-7, fp, variant=variant, detector_kernel='auto')
+    assert eng.det_kernel == 'IR'
+    eng.set_probe(pr, pi)
+    eng.set_object_batch(delta, beta)
+    wave = eng.forward(B)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, fp, delta.shape, variant=variant,
+                                                  return_probe_array=False, detector_kernel='IR')
+    tf, _ = orc.multislice_propagate_batch_numpy(delta, beta, pr, pi, 5000., 1e-7, fp, delta.shape, variant=variant, return_probe_array=False)
+    assert rel(ref, tf) > 1e-2                                       # a different operator, not a rounding of the same one
+    assert rel(np.abs(wave) ** 2, np.abs(ref) ** 2) <= 1e-5 and rel(wave, ref) <= 5e-6, (rel(np.abs(wave) ** 2, np.abs(ref) ** 2), rel(wave, ref))
+    meas = np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))
+    loss = eng.loss_grad(B, meas)
+    gd, gb = eng.grad_batch_to_host(B)
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, pr, pi, 5000., 1e-7, meas, fp, variant, detector_kernel='IR')
+    assert abs(loss - rl) <= 1e-5 * abs(rl), (loss, rl)
+    assert rel(gd, rgd) <= 2e-4 and rel(gb, rgb) <= 2e-4, (rel(gd, rgd), rel(gb, rgb))
+
+
 @pytest.mark.parametrize('B,Y,X,S,fp', [(3, 256, 256, 16, 1e-4), (2, 512, 512, 8, 1e-4), (1, 1024, 1024, 3, None),
                                         (1, 512, 1024, 3, 'inf')])
 def test_larger_sizes_vs_oracle(engine_mod, B, Y, X, S, fp):
@@ -430,6 +473,57 @@ def test_cfg2_full_size_fullfield_step_vs_oracle(engine_mod):
                                                with_reg=False)
     assert abs(loss - rl) <= 1e-6 * rl
     assert rel(gd, rgd) <= 1e-4 and rel(gb, rgb) <= 1e-4
+
+
+def test_cfg3_full_size_solver_step_vs_oracle(engine_mod):
+    """BASELINE configs[2] through the SOLVER at its stated size (cnn_propagator/fullfield.py:340-362): 512^3 charcoal-like
+    volume (bench.py's), the 200-angle rotation tables, a two-angle minibatch — rotation gather, forward through all 512
+    slices, loss, adjoint sweep, rotation adjoint, then one Adam step (the first of an epoch: the step in which a float32
+    gradient shows) with L1 + TV, mask and clip — against the float64 oracle.  Bounds: forward intensities 1e-6, volume
+    gradient 1e-5, delta after the step 1e-5 (measured in round 3 as a tool: 1.2e-7, 6.1e-6, 6.5e-6).  The oracle's 2 x 512
+    slices of 512^2 in complex128 take a couple of minutes on the box's cores."""
+    from scipy.ndimage import uniform_filter
+    from beyond_dof_amd.solver import FullfieldSolver
+    n, n_theta, fp, lr = 512, 200, 1e-4, 1e-7
+    reg = dict(alpha_d=1.5e-8, alpha_b=1.5e-9, gamma=1e-11)
+    rng = np.random.default_rng(3)
+    od = uniform_filter(rng.random((n, n, n)) * 2e-6, size=3, mode='wrap')
+    ob = 0.1 * od
+    coords = orc.rotation_lookup([n, n, n], n_theta)
+    idx = np.array([7, 134])
+    one, zero = np.ones((n, n)), np.zeros((n, n))
+    rot = np.stack([orc.apply_rotation(np.stack([od, ob], axis=3), coords[j]) for j in idx])
+    ref_wave, _ = orc.multislice_propagate_batch_numpy(rot[..., 0], rot[..., 1], one, zero, 5000., 1e-7, fp, rot[..., 0].shape,
+                                                       return_probe_array=False)
+    del rot
+    prj = np.zeros((n_theta, n, n), dtype=np.float32)
+    prj[idx] = np.abs(ref_wave) * (1 + 0.05 * rng.normal(size=ref_wave.shape))
+    s = FullfieldSolver(n, n, n, n_theta, len(idx), 5000., 1e-7, free_prop_cm=fp, coord_ls=coords)
+    s.set_volume(od, ob)
+    s.set_measurements(prj)
+    e_int = rel(np.abs(s.forward_angles(idx)) ** 2, np.abs(ref_wave) ** 2)
+    loss = s.loss_and_grad(idx)
+    gd, gb = s.gradient_to_host()
+    rl, rgd, rgb = orc.fullfield_loss_and_grad(od, ob, coords, idx, prj[idx].astype(np.float64), one, zero, 5000., 1e-7, free_prop_cm=fp,
+                                               with_reg=False)
+    e_g = (rel(gd, rgd), rel(gb, rgb))
+    del gd, gb
+    mask = np.ones((n, n, n), dtype=np.float32)
+    mask[:, :4, :] = 0
+    s.set_mask(mask)
+    s.reset_moments()
+    s.step(0, idx, lr, reg['alpha_d'], reg['alpha_b'], reg['gamma'])
+    d1, b1 = s.get_volume()
+    rd, rb = orc.regularizer_grad(od, ob, **reg)
+    x, _, _ = orc.apply_gradient_adam(np.array([od, ob]), np.array([rgd + rd, rgb + rb]), 0, None, None, step_size=lr)
+    x = np.clip(x * mask, 0, None)
+    dev = np.abs(d1 - x[0])
+    e_d, far = rel(d1, x[0]), float(np.mean(dev > 0.01 * lr))
+    print('cfg3 solver step at 512^3: intensity', e_int, 'loss', abs(loss - rl) / rl, 'gradient', e_g, 'delta after one Adam step', e_d,
+          'voxels > 0.01 step away', far, 'beta', rel(b1, x[1]))
+    assert e_int <= 1e-6 and abs(loss - rl) <= 1e-6 * rl
+    assert e_g[0] <= 1e-5 and e_g[1] <= 1e-5, e_g
+    assert e_d <= 1e-5 and far <= 1e-5 and rel(b1, x[1]) <= 1e-4, (e_d, far, rel(b1, x[1]))
 
 
 @pytest.mark.parametrize('fp,variant', [(None, 'numpy_skip_last'), (1e-4, 'tf_all'), ('inf', 'numpy_skip_last'), ('inf', 'tf_all')])

@@ -173,6 +173,8 @@ def test_reconstruct_ptychography_vs_the_reference_loop_fft(tmp_path, monkeypatc
                                     seed=42, probe_mag_sigma=sigma, probe_phase_sigma=sigma, probe_phase_max=0.5,
                                     adjoint_precision=adjoint_precision)
     assert float(g['delta_moved_max']) >= 5 * lr
+    summary = dict(line.split(None, 1) for line in open('case/out/summary.txt').read().splitlines() if len(line.split(None, 1)) == 2)
+    assert summary['adjoint_precision'].strip() == adjoint_precision and summary['adjoint_precision_effective'].strip() == adjoint_precision
     d, b = d[::2, ::2, ::2], b[::2, ::2, ::2]
     rel = lambda a, c: np.linalg.norm(a - c) / np.linalg.norm(c)
     dev, devb = np.abs(d - g['delta_sub']), np.abs(b - g['beta_sub'])
@@ -188,6 +190,47 @@ def test_reconstruct_ptychography_vs_the_reference_loop_fft(tmp_path, monkeypatc
         # measured: delta 1.7e-5 (1.85e-5 with exact adjoint twiddles: it is a lottery over ~100 voxels), beta 1.7e-6 relative
         # after eight Adam steps, no voxel more than 0.014 of a step away (round 2, residual in float32: 4.9e-5 / 0.045)
         assert stats[0] <= 0.05 and stats[1] <= 3e-5 and stats[3] <= 1e-5 and stats[4] == 0.0, stats
+
+
+def test_first_step_engine_that_cannot_be_set_up_is_reported_and_recorded(tmp_path, monkeypatch, capsys):
+    """The default adjoint_precision='first-step' builds a second engine; where that fails (it holds a float32 tape and float64
+    buffers of its own) the run continues in float32 — outside the 1e-5 bound — so it must SAY so and RECORD it: one message
+    that names the consequence, `adjoint_precision_effective  float32` in summary.txt.  An explicit request fails instead."""
+    import sys
+    import __graft_entry__ as entry
+    entry.build()
+    from beyond_dof_amd import h5io, ptychography
+    from beyond_dof_amd._lib import BdofError
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, gdir)
+    import g13_inputs
+    g = np.load(os.path.join(gdir, 'g17_reconstruct_ptychography_fft_64.npz'))
+    obj_size, psz, sigma = tuple(int(v) for v in g['obj_size']), tuple(int(v) for v in g['probe_size']), float(g['probe_sigma'])
+    init_d, init_b = g13_inputs.initial_guess(obj_size)
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('case')
+    h5io.write_dataset('case/data.h5', 'exchange/data', g['prj'])
+    real, asked = ptychography.PtychoSolver, []
+
+    def failing(*a, **kw):
+        asked.append(kw.get('adjoint64'))
+        if kw.get('adjoint64') == 'first':
+            raise BdofError('bdof_configure: out of device memory (forced by the test)')
+        return real(*a, **kw)
+    monkeypatch.setattr(ptychography, 'PtychoSolver', failing)
+    run = lambda **kw: ptychography.reconstruct_ptychography(
+        'data.h5', [tuple(int(v) for v in p) for p in g['probe_pos']], psz, obj_size, theta_st=0, theta_end=2 * np.pi, n_epochs=1,
+        learning_rate=2e-7, minibatch_size=2, energy_ev=5000, psize_cm=1e-7, save_path='case', output_folder='out',
+        initial_guess=[init_d, init_b], probe_type='gaussian', dynamic_dropping=False, seed=42, probe_mag_sigma=sigma,
+        probe_phase_sigma=sigma, probe_phase_max=0.5, **kw)
+    d, _ = run()
+    assert asked == ['first', None] and np.all(np.isfinite(d))
+    out = capsys.readouterr().out
+    assert "adjoint_precision='first-step' could not be set up" in out and "continuing with 'float32'" in out and 'forced by the test' in out
+    summary = dict(line.split(None, 1) for line in open('case/out/summary.txt').read().splitlines() if len(line.split(None, 1)) == 2)
+    assert summary['adjoint_precision'].strip() == 'first-step' and summary['adjoint_precision_effective'].strip() == 'float32'
+    with pytest.raises(BdofError):
+        run(adjoint_precision='first-step')
 
 
 def test_cfg5_solver_step_at_full_shape():
