@@ -49,11 +49,16 @@ _SIGNATURES = {
     'bdof_tiles_gather_adjoint': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     'bdof_tiles_grad_add': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int]),
     'bdof_field_loss_seed': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int]),
+    'bdof_set_transfer_f64': (ctypes.c_int, [_vp, _vp]),
+    'bdof_forward_range_h': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, _vp]),
     'bdof_fields_free_step': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int]),
     'bdof_caxpy': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_double, ctypes.c_size_t, ctypes.c_int]),
     'bdof_c_convert': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_size_t, ctypes.c_int]),
     'bdof_tiles_gather_f64': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     'bdof_tiles_scatter_f64': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int]),
+    'bdof_tiles_gather_mixed': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
+    'bdof_tiles_scatter_diff64': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int]),
     'bdof_forward_range_f64': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_double, ctypes.c_int]),
     'bdof_tape_to_real': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     'bdof_loss_grad': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),

@@ -51,6 +51,9 @@ struct bdof_ctx {
     int tw_dither = 0;
     unsigned tw_tick = 0;          // the slice of the last A / A' launch: the transfer-function launch that follows takes the same copy
     cf *hs = nullptr, *hdet = nullptr, *hcomb = nullptr, *probe = nullptr;
+    cf* hs_d = nullptr;            // bdof_set_transfer_f64: hs_copies dithered float32 copies of the slice step's table (bdof_field.h)
+    int hs_copies = 0;
+    const cf* hs_override = nullptr;   // bdof_forward_range_h: the table of this call's transfer-function steps
     cf *bufA = nullptr, *bufB = nullptr, *tape = nullptr;
     float2* grot = nullptr;
     double2 *gcar = nullptr, *gt0 = nullptr;     // adjoint carrier per wavefield (AdjCarrier, bdof_kernels.h)
@@ -432,6 +435,10 @@ static void launch_row_unmod(bdof_ctx* c, int B, int z, const cf* in, cf* out, b
 static void launch_row_prop(bdof_ctx* c, int B, const cf* in, cf* out, const cf* h, float scale, int conj_h, int key = -1) {
     ProfScope ps(c, BDOF_K_COL_PROP, true);
     const unsigned tick = key >= 0 ? (unsigned)key : c->tw_tick;
+    if (h == c->hs) {
+        if (c->hs_override) h = c->hs_override;
+        else if (c->hs_copies > 0) h = c->hs_d + (size_t)(tick % (unsigned)c->hs_copies) * c->NX * c->NY;      // the slice's dithered copy
+    }
     RowPropArgs a{sub_field(c, in), sub_field(c, out), h, B, c->NY, scale, conj_h, tw_of(c, c->twX, c->NX, tick)};
     sq_of(c, tick, a.sq);
     DISPATCH_N(c->NX, {
@@ -931,6 +938,7 @@ static void free_generic(bdof_ctx* c) {
 
 static void free_workspace(bdof_ctx* c) {
     free_generic(c);
+    if (c->hs_d) { (void)hipFree(c->hs_d); c->hs_d = nullptr; c->hs_copies = 0; }
     void* ptrs[] = {c->cstack, c->cdet64, c->pdet64, c->pdetT64, c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->taps_dev, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->gpsi0, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
@@ -1134,7 +1142,41 @@ int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det
     c->variant = variant;
     c->have_physics = true;
     c->have_h64 = false;             // float64 adjoint: the caller follows up with bdof_set_physics_f64
+    c->hs_copies = 0;                // dithered copies of the old table: the caller follows up with bdof_set_transfer_f64
     c->mod_dirty = true;
+    return 0;
+}
+
+// The slice step's transfer function in float64 ([ky][kx], 1 / (NX NY) folded in — what bdof_set_physics' hs was rounded from):
+// the streaming engine's per-slice launches then multiply by DITHERED float32 copies of it, copy z mod D for slice z
+// (bdof_field.h: k_dither_copies; D = BDOF_H_DITHER, default 64 capped at 256 MiB of tables, 0 = off), the adjoint step by the
+// conjugate of the copy the forward step used.  A fixed float32 table is the same perturbation of every slice: its error grows
+// linearly with the number of slices (np_funcs.py:42 runs float64).
+int bdof_set_transfer_f64(bdof_ctx* c, const double* hs64) {
+    if (!c || !hs64) return BDOF_ERR_ARG;
+    if (!c->have_physics) return fail(c, BDOF_ERR_STATE, "bdof_set_physics has not been called");
+    if (c->generic) return 0;                          // rocFFT engine: one table (the LDS-resident kernel keeps its own, too)
+    static const int want = [] { const char* e = std::getenv("BDOF_H_DITHER"); return e ? std::max(0, std::min(256, atoi(e))) : 64; }();
+    const size_t n = (size_t)c->NX * c->NY;
+    int D = want;
+    while (D > 1 && (size_t)D * n * sizeof(cf) > ((size_t)256 << 20)) D /= 2;
+    if (D < 2) { c->hs_copies = 0; return 0; }
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (c->hs_d) { (void)hipFree(c->hs_d); c->hs_d = nullptr; }
+    c->hs_copies = 0;
+    double2* tmp = nullptr;
+    HIPC(c, hipMalloc(&tmp, n * sizeof(double2)));
+    hipError_t e = hipMalloc(&c->hs_d, (size_t)D * n * sizeof(cf));
+    if (e != hipSuccess) { (void)hipFree(tmp); c->hs_d = nullptr; return fail(c, (int)e, "hipMalloc of the dithered transfer-function copies failed"); }
+    e = hipMemcpy(tmp, hs64, n * sizeof(double2), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_dither_copies, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, tmp, c->hs_d, n, D);
+        e = hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(c, (int)e, "building the dithered transfer-function copies failed");
+    c->hs_copies = D;
     return 0;
 }
 
@@ -1435,6 +1477,15 @@ int bdof_forward_range(bdof_ctx* c, int B, const int* angle_of_b, const int* xof
     return 0;
 }
 
+int bdof_forward_range_h(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
+                         const void* in_real, void* out_real, int prop_last, const void* h) {
+    if (!c || !h) return BDOF_ERR_ARG;
+    c->hs_override = (const cf*)h;
+    const int r = bdof_forward_range(c, B, angle_of_b, xoff, yoff, z0, nz, in_real, out_real, prop_last);
+    c->hs_override = nullptr;
+    return r;
+}
+
 // Adjoint of bdof_forward_range(prop_last = 1) in the tape-free form: the forward wave is marched back from the range's end
 // state beside the adjoint field.  end_real: psi_{z0+nz} (what bdof_forward_range returned), g_end_real: G(psi_{z0+nz});
 // g_start_real receives G(psi_{z0}); the gradient rows of the range go to grot_range [B][nz][NX][NY] (pairs).
@@ -1668,6 +1719,32 @@ int bdof_tiles_scatter_f64(bdof_ctx* c, const void* tiles, void* field, int FX, 
     HIPC(c, hipSetDevice(c->device));
     Tile64Args a{(double2*)field, (double2*)tiles, x0, y0, B, FX, FY, TX, TY, halo_x, halo_y, 0};
     hipLaunchKernelGGL(k_tiles_scatter64, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// complex64 tiles cut out of a complex128 field (tapered, periodic) / written back into it:
+// field[core] = (accumulate ? field[core] : 0) + tiles_a - tiles_b (tiles_b nullable), the sum formed in float64
+int bdof_tiles_gather_mixed(bdof_ctx* c, const void* field64, int FX, int FY, void* tiles, int B, int TX, int TY, const int* x0, const int* y0,
+                            int taper) {
+    int r = tiles_check(c, field64, tiles, B, FX, FY, TX, TY, x0, y0);
+    if (r) return r;
+    if (taper < 0 || 2 * taper > TX || 2 * taper > TY) return fail(c, BDOF_ERR_ARG, "taper must fit the tile");
+    HIPC(c, hipSetDevice(c->device));
+    TileMixArgs a{(double2*)field64, nullptr, nullptr, (cf*)tiles, x0, y0, B, FX, FY, TX, TY, 0, 0, taper, 0};
+    hipLaunchKernelGGL(k_tiles_gather_mixed, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_tiles_scatter_diff64(bdof_ctx* c, const void* tiles_a, const void* tiles_b, void* field64, int FX, int FY, int B, int TX, int TY,
+                              const int* x0, const int* y0, int halo_x, int halo_y, int accumulate) {
+    int r = tiles_check(c, field64, tiles_a, B, FX, FY, TX, TY, x0, y0);
+    if (r) return r;
+    if (halo_x < 0 || halo_y < 0 || 2 * halo_x >= TX || 2 * halo_y >= TY) return fail(c, BDOF_ERR_ARG, "halo must leave a core");
+    HIPC(c, hipSetDevice(c->device));
+    TileMixArgs a{(double2*)field64, (const cf*)tiles_a, (const cf*)tiles_b, nullptr, x0, y0, B, FX, FY, TX, TY, halo_x, halo_y, 0, accumulate};
+    hipLaunchKernelGGL(k_tiles_scatter_diff64, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;
 }

@@ -80,6 +80,52 @@ __global__ __launch_bounds__(256) void k_tiles_scatter64(Tile64Args a) {
     }
 }
 
+// float32 tiles of a float64 field (the field of the float32 tiled path with the long-range correction stays in float64: its
+// bulk is carried by the whole-field free-space step in double, the tiles add the object's part)
+struct TileMixArgs {
+    double2* field;       // [FX][FY]
+    const cf* ta;         // [B][TX][TY]
+    const cf* tb;         // nullable
+    cf* tiles;            // gather target
+    const int* x0;
+    const int* y0;
+    int B, FX, FY, TX, TY, hx, hy, taper, accumulate;
+};
+__global__ __launch_bounds__(256) void k_tiles_gather_mixed(TileMixArgs a) {
+    const int b = blockIdx.z;
+    const int ox = a.x0[b], oy = a.y0[b];
+    for (int x = blockIdx.y; x < a.TX; x += gridDim.y) {
+        cf* dst = a.tiles + ((size_t)b * a.TX + x) * a.TY;
+        const double2* src = a.field + (size_t)wrap_idx(ox + x, a.FX) * a.FY;
+        const double wx = taper_weight64(x, a.TX, a.taper);
+        for (int y = blockIdx.x * blockDim.x + threadIdx.x; y < a.TY; y += gridDim.x * blockDim.x) {
+            const double w = wx * taper_weight64(y, a.TY, a.taper);
+            const double2 v = src[wrap_idx(oy + y, a.FY)];
+            dst[y] = make_float2((float)(v.x * w), (float)(v.y * w));
+        }
+    }
+}
+// field[core] = (accumulate ? field[core] : 0) + ta - tb   on the cores of the tiles, in float64
+__global__ __launch_bounds__(256) void k_tiles_scatter_diff64(TileMixArgs a) {
+    const int b = blockIdx.z;
+    const int ox = a.x0[b], oy = a.y0[b];
+    for (int x = a.hx + blockIdx.y; x < a.TX - a.hx; x += gridDim.y) {
+        const int xg = ox + x;
+        if (xg < 0 || xg >= a.FX) continue;
+        double2* dst = a.field + (size_t)xg * a.FY;
+        const size_t row = ((size_t)b * a.TX + x) * a.TY;
+        for (int y = a.hy + blockIdx.x * blockDim.x + threadIdx.x; y < a.TY - a.hy; y += gridDim.x * blockDim.x) {
+            const int yg = oy + y;
+            if (yg < 0 || yg >= a.FY) continue;
+            const cf va = a.ta[row + y];
+            double dx = (double)va.x, dy = (double)va.y;
+            if (a.tb) { const cf vb = a.tb[row + y]; dx -= (double)vb.x; dy -= (double)vb.y; }
+            if (a.accumulate) { const double2 o = dst[yg]; dx += o.x; dy += o.y; }
+            dst[yg] = make_double2(dx, dy);
+        }
+    }
+}
+
 // phi = c psi, c = exp(i k delta) exp(-k beta) from the caller's (delta, beta) rows (cnn_propagator/np_funcs.py:37-40), float64
 struct Mod64Args {
     double2* field;      // [B][NX][NY]
@@ -100,5 +146,28 @@ __global__ __launch_bounds__(256) void k_f64_modulate(Mod64Args a) {
         const double e = exp(-a.k * (double)db.y);
         const double2 v = a.field[idx];
         a.field[idx] = make_double2(e * (v.x * cs - v.y * s), e * (v.x * s + v.y * cs));
+    }
+}
+
+// D float32 copies of a float64 complex table whose roundings average to the float64 values (the dithered transform constants
+// of bdof_fft.h, applied to the transfer function h): in copy d each part of entry i is rounded DOWN or UP — up in a fraction
+// p = (x - lo) / (hi - lo) of the copies, spread evenly over d with a golden-ratio phase per entry — so that the mean over any
+// run of L copies is x to ulp / L.  The launches of slice z take copy z mod D: a fixed float32 table is the same small
+// perturbation of every slice, and its error adds up coherently (1.4e-5 of the exit wave after 1024 slices, measured with
+// everything else in float64); the dithered copies' errors cancel (1e-6).
+__device__ __forceinline__ float dither_round(double x, int d, double phase) {
+    float lo = (float)x;
+    if ((double)lo > x) lo = nextafterf(lo, -INFINITY);
+    const float hi = nextafterf(lo, INFINITY);
+    if ((double)lo == x) return lo;
+    const double p = (x - (double)lo) / ((double)hi - (double)lo);
+    return floor((d + 1) * p + phase) > floor(d * p + phase) ? hi : lo;
+}
+__global__ __launch_bounds__(256) void k_dither_copies(const double2* __restrict__ src, cf* __restrict__ dst, size_t n, int D) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double2 v = src[i];
+        const double g = (double)(i % 1048573) * 0.6180339887498949;
+        const double ph = g - floor(g), ph2 = ph + 0.5 - floor(ph + 0.5);
+        for (int d = 0; d < D; ++d) dst[(size_t)d * n + i] = make_float2(dither_round(v.x, d, ph), dither_round(v.y, d, ph2));
     }
 }

@@ -67,7 +67,8 @@ class MultisliceEngine(object):
         lmbda_nm = 1240. / energy_ev
         delta_nm = voxel_nm[-1]
         k = 2. * pi * delta_nm / lmbda_nm
-        hs = util.device_transfer_function(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, field_shape=field_shape)
+        hs64 = util.device_transfer_function(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, field_shape=field_shape, dtype=np.complex128)
+        hs = hs64.astype(np.complex64)
         h00 = np.array(util.transfer_function_dc(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, field_shape=field_shape))
         hdet = hdet00 = None
         self.det_kernel = 'TF'
@@ -95,8 +96,9 @@ class MultisliceEngine(object):
         self.ctx.check(self.lib.bdof_set_physics(self.h, k, hs.ctypes.data, hdet.ctypes.data if hdet is not None else None,
                                                  h00.ctypes.data, hdet00.ctypes.data if hdet00 is not None else None,
                                                  det, _VARIANT[variant]))
+        # the same table in float64: the streaming kernels multiply by dithered float32 copies of it (bdof_set_transfer_f64)
+        self.ctx.check(self.lib.bdof_set_transfer_f64(self.h, hs64.ctypes.data))
         if self.adjoint64:
-            hs64 = util.device_transfer_function(delta_nm, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, field_shape=field_shape, dtype=np.complex128)
             hd64 = None
             if det == _lib.DET_NEAR:
                 hd64 = util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, dtype=np.complex128,

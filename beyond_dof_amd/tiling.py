@@ -20,10 +20,14 @@ tiles' own free-space step, stitched) — one whole-field transform pair and one
 phase-winding length, 4 dx^2 / (lambda dz) slices (16 at 5 keV / 1 nm — the default interval with the correction on), the
 tiling error at cfg4's depth is 9e-7 (64-pixel halo; 2e-6 with 32).
 
-precision='float64': the tiles run in float64 (bdof_forward_range_f64: rocFFT double transforms, point-wise kernels) on a
-complex128 field — the reference's own precision (np_funcs.py:20-42, quirk Q2).  Through float32 transforms the exit wave of a
-1024-slice stack carries 1.5e-5 of rounding (4.6e-7 sqrt(S)); 'auto' switches to float64 beyond 384 slices, where that
-passes ~0.9e-5.  Unfused, ~4x the time of the fused float32 kernels.
+Precision.  With the correction on, the FIELD is complex128 while it propagates: the whole-field free-space step (rocFFT, double)
+carries its bulk from range to range, and the tiles — the fused float32 row kernels, with dithered transform constants AND a
+dithered transfer function (bdof_set_transfer_f64: a fixed float32 H is the same perturbation in every slice, 1.4e-5 of the
+exit wave after 1024 slices all by itself) — add T psi - T_free psi, the object's part.  cfg4 (4096^2, 1024 slices, 512^2 tiles,
+64-pixel halo): 5.8e-6 from the float64 whole field in 343 ms (round 3, no correction, fixed H: 2.7e-5 in 218 ms; the
+whole-field float32 rocFFT engine: 1.9e-4 in 620 ms).  precision='float64' runs the tiles themselves in float64
+(bdof_forward_range_f64: rocFFT double transforms + point-wise kernels, unfused): 9e-7 in 1.59 s — the reference's own precision
+(np_funcs.py:20-42, quirk Q2); 'auto' takes it beyond 2048 slices.
 
 Several GPUs (comm with size > 1): the tiles are dealt to the ranks round-robin; every rank keeps the whole field.  At a
 stitch a rank writes its own cores into a zeroed field and the fields are summed over the ranks (every pixel lies in
@@ -69,7 +73,8 @@ class TiledPropagator(object):
         if self.long_range and (comm is not None and comm.size > 1):
             raise ValueError('the long-range correction runs on one rank (it transforms the whole field)')
         if precision == 'auto':
-            precision = 'float64' if (self.n_slice > 384 and not self.with_grad and (comm is None or comm.size == 1)) else 'float32'
+            # fused float32 kernels (dithered transform constants and transfer function): 5.8e-6 at 1024 slices, growing like sqrt(S)
+            precision = 'float64' if (self.n_slice > 2048 and not self.with_grad and (comm is None or comm.size == 1)) else 'float32'
         if precision not in ('float32', 'float64'):
             raise ValueError("precision must be 'float32', 'float64' or 'auto'")
         if precision == 'float64' and (self.with_grad or (comm is not None and comm.size > 1)):
@@ -109,31 +114,41 @@ class TiledPropagator(object):
         self.tiles_in = DeviceBuffer(self.ctx, n * cb, ctype, (self.n_tiles, self.tile, self.tile))
         self.tiles_out = None if self.dbl else DeviceBuffer(self.ctx, n * 8, np.complex64, (self.n_tiles, self.tile, self.tile))
         self.field = DeviceBuffer(self.ctx, self.fx * self.fy * cb, ctype, (self.fx, self.fy))
-        voxel = voxel_nm
-        self._kernel = lambda power, shape, fshape: self._free_table(voxel[2], lmbda_nm, voxel, shape, fshape, pi, power, ctype)
+        self._phys = (voxel_nm[2], lmbda_nm, voxel_nm, pi)
         self.k64 = 2. * pi * voxel_nm[2] / lmbda_nm
-        self.h64 = DeviceBuffer.from_host(self.ctx, self._kernel(1, (self.tile, self.tile), (self.fy, self.fx))) if self.dbl else None
+        self.h64 = DeviceBuffer.from_host(self.ctx, self._free_table(1, (self.tile, self.tile), np.complex128)) if self.dbl else None
         self._pow_tables = {}
         if self.long_range:
+            # float32 tiles: the field itself is kept in complex128 while it propagates (the whole-field free-space step in
+            # double carries its bulk, the fused float32 kernels add the object's part); float64 tiles: everything is double
             self.tiles_free = DeviceBuffer(self.ctx, n * cb, ctype, (self.n_tiles, self.tile, self.tile))
-            self.whole = DeviceBuffer(self.ctx, self.fx * self.fy * cb, ctype, (self.fx, self.fy))
+            self.whole64 = DeviceBuffer(self.ctx, self.fx * self.fy * 16, np.complex128, (self.fx, self.fy))
+            self.field64 = self.field if self.dbl else DeviceBuffer(self.ctx, self.fx * self.fy * 16, np.complex128, (self.fx, self.fy))
+            # tiles that see vacuum whatever the object: window origins beyond the volume (the fused free-space step)
+            self.vac = DeviceBuffer.from_host(self.ctx, np.stack([np.zeros(self.n_tiles, dtype=np.int32),
+                                                                  np.full(self.n_tiles, 1 << 28, dtype=np.int32), self.y0]))
 
-    @staticmethod
-    def _free_table(dist_nm, lmbda_nm, voxel_nm, shape, field_shape, pi, power, ctype):
-        """The `power`-th power of the transfer function of one slice step for bdof_fields_free_step: un-shifted, [kx][ky],
-        1 / (NX NY) folded in, formed in float64 (H = exp(i phase): the power is taken on the phase)."""
+    def _free_table(self, power, shape, ctype, fused_layout=False):
+        """The `power`-th power of one slice step's transfer function on a (ny, nx) grid of this field, un-shifted, 1 / (NX NY)
+        folded in, formed in float64 (H is exp(i phase): the power is taken on the phase, i.e. on the distance).
+        [kx][ky] for bdof_fields_free_step / bdof_forward_range_f64; fused_layout: [ky][kx], the row kernels' order."""
+        dist_nm, lmbda_nm, voxel_nm, pi = self._phys
         ny, nx = shape
-        if tuple(shape) == tuple(field_shape):
+        if tuple(shape) == (self.fy, self.fx):
             h = util.get_kernel(dist_nm * power, lmbda_nm, voxel_nm, (ny, nx), pi=pi)
         else:
-            h = util.get_kernel_tile(dist_nm * power, lmbda_nm, voxel_nm, (ny, nx), field_shape, pi=pi)
-        return np.ascontiguousarray((np.fft.ifftshift(h) / float(nx * ny)).T.astype(ctype))
+            h = util.get_kernel_tile(dist_nm * power, lmbda_nm, voxel_nm, (ny, nx), (self.fy, self.fx), pi=pi)
+        h = np.fft.ifftshift(h) / float(nx * ny)
+        return np.ascontiguousarray((h if fused_layout else h.T).astype(ctype))
 
     def _tables(self, power):
-        """(tile table, field table) of `power` consecutive free-space steps, on the device; built once per distinct power."""
+        """(tile table, field table) of `power` consecutive free-space steps, on the device; built once per distinct power.
+        The field's is complex128 [kx][ky]; the tiles' complex128 [kx][ky] (float64 tiles) or complex64 [ky][kx] (fused kernels)."""
         if power not in self._pow_tables:
-            self._pow_tables[power] = (DeviceBuffer.from_host(self.ctx, self._kernel(power, (self.tile, self.tile), (self.fy, self.fx))),
-                                       DeviceBuffer.from_host(self.ctx, self._kernel(power, (self.fy, self.fx), (self.fy, self.fx))))
+            T = (self.tile, self.tile)
+            t = self._free_table(power, T, np.complex128) if self.dbl else self._free_table(power, T, np.complex64, fused_layout=True)
+            self._pow_tables[power] = (DeviceBuffer.from_host(self.ctx, t),
+                                       DeviceBuffer.from_host(self.ctx, self._free_table(power, (self.fy, self.fx), np.complex128)))
         return self._pow_tables[power]
 
     # ---- object --------------------------------------------------------------------------------
@@ -162,33 +177,67 @@ class TiledPropagator(object):
         variant == 'tf_all')."""
         lib, h, p = self.lib, self.h, self.idx.ptr
         a, xo, yo = p, p + 4 * self.n_tiles, p + 8 * self.n_tiles
-        B, T, dbl = self.n_tiles, self.tile, int(self.dbl)
-        gather = lib.bdof_tiles_gather_f64 if self.dbl else lib.bdof_tiles_gather
+        B, T = self.n_tiles, self.tile
+        if not self.long_range:
+            gather = lib.bdof_tiles_gather_f64 if self.dbl else lib.bdof_tiles_gather
+            for z0, nz in self.segments():
+                prop_last = int(z0 + nz < self.n_slice or self.variant == 'tf_all')
+                self.ctx.check(gather(h, self.field.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.taper))
+                if self.dbl:
+                    self.ctx.check(lib.bdof_forward_range_f64(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, self.h64.ptr, self.k64, prop_last))
+                    self._stitch(self.tiles_in)
+                else:
+                    self.ctx.check(lib.bdof_forward_range(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, self.tiles_out.ptr, prop_last))
+                    self._stitch(self.tiles_out)
+            return
+        # Long-range correction: psi_out = P_field^n psi_in + stitch(T psi_in - T_free psi_in) per range — the field's own
+        # free-space step over the range (one transform pair of the whole field, in double) carries the wave, the tiles add what
+        # the object does to it; T_free is the tiles' own free-space step, so what the tiles miss of the field's propagator
+        # (its long-range tails) drops out to first order in the object's phase over one range.
+        v = self.vac.ptr
+        va, vx, vy = v, v + 4 * B, v + 8 * B
+        npx = self.fx * self.fy
+        if not self.dbl:
+            self.ctx.check(lib.bdof_c_convert(h, self.field64.ptr, self.field.ptr, npx, 1))
+        f, w = self.field64, self.whole64
         for z0, nz in self.segments():
-            last = z0 + nz == self.n_slice
-            prop_last = int(not last or self.variant == 'tf_all')
+            prop_last = int(z0 + nz < self.n_slice or self.variant == 'tf_all')
             nprop = nz - 1 + prop_last                       # transfer-function steps of this range
-            self.ctx.check(gather(h, self.field.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.taper))
-            corr = self.long_range and nprop > 0
-            if corr:
-                # D psi_in: what the field's own propagator does over the range in free space, minus what the tiles' does
-                t_tab, f_tab = self._tables(nprop)
-                nb = self.tiles_in.nbytes
-                self.ctx.check(lib.bdof_memcpy_d2d(h, self.tiles_free.ptr, self.tiles_in.ptr, nb))
-                self.ctx.check(lib.bdof_fields_free_step(h, self.tiles_free.ptr, B, T, T, t_tab.ptr, 0, dbl))
-                self.ctx.check(lib.bdof_memcpy_d2d(h, self.whole.ptr, self.field.ptr, self.field.nbytes))
-                self.ctx.check(lib.bdof_fields_free_step(h, self.whole.ptr, 1, self.fx, self.fy, f_tab.ptr, 0, dbl))
             if self.dbl:
-                self.ctx.check(lib.bdof_forward_range_f64(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, self.h64.ptr, self.k64, prop_last))
-                out = self.tiles_in
+                self.ctx.check(lib.bdof_tiles_gather_f64(h, f.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.taper))
             else:
+                self.ctx.check(lib.bdof_tiles_gather_mixed(h, f.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.taper))
+            if nprop == 0:                                   # a last single slice without a step: nothing to correct
+                if self.dbl:
+                    self.ctx.check(lib.bdof_forward_range_f64(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, self.h64.ptr, self.k64, 0))
+                    self.ctx.check(lib.bdof_tiles_scatter_f64(h, self.tiles_in.ptr, f.ptr, self.fx, self.fy, B, T, T, xo, yo, self.halo, self.halo))
+                else:
+                    self.ctx.check(lib.bdof_forward_range(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, self.tiles_out.ptr, 0))
+                    self.ctx.check(lib.bdof_tiles_scatter_diff64(h, self.tiles_out.ptr, None, f.ptr, self.fx, self.fy, B, T, T, xo, yo,
+                                                                 self.halo, self.halo, 0))
+                continue
+            t_tab, f_tab = self._tables(nprop)
+            self.ctx.check(lib.bdof_memcpy_d2d(h, w.ptr, f.ptr, npx * 16))
+            self.ctx.check(lib.bdof_fields_free_step(h, w.ptr, 1, self.fx, self.fy, f_tab.ptr, 0, 1))
+            if self.dbl:
+                self.ctx.check(lib.bdof_memcpy_d2d(h, self.tiles_free.ptr, self.tiles_in.ptr, self.tiles_in.nbytes))
+                self.ctx.check(lib.bdof_fields_free_step(h, self.tiles_free.ptr, B, T, T, t_tab.ptr, 0, 1))
+                self.ctx.check(lib.bdof_forward_range_f64(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, self.h64.ptr, self.k64, prop_last))
+                self.ctx.check(lib.bdof_caxpy(h, self.tiles_in.ptr, self.tiles_free.ptr, -1.0, B * T * T, 1))
+                self.ctx.check(lib.bdof_tiles_scatter_f64(h, self.tiles_in.ptr, f.ptr, self.fx, self.fy, B, T, T, xo, yo, self.halo, self.halo))
+                self.ctx.check(lib.bdof_caxpy(h, w.ptr, f.ptr, 1.0, npx, 1))        # (f holds the difference on every core = everywhere)
+            else:
+                # T_free through the SAME fused kernels (one vacuum slice stepped with H^n): both terms of the difference carry
+                # the same dithered constants, and no rocFFT float32 drift enters
+                self.ctx.check(lib.bdof_forward_range_h(h, B, va, vx, vy, z0, 1, self.tiles_in.ptr, self.tiles_free.ptr, 1, t_tab.ptr))
                 self.ctx.check(lib.bdof_forward_range(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, self.tiles_out.ptr, prop_last))
-                out = self.tiles_out
-            if corr:
-                self.ctx.check(lib.bdof_caxpy(h, out.ptr, self.tiles_free.ptr, -1.0, B * T * T, dbl))
-            self._stitch(out)
-            if corr:
-                self.ctx.check(lib.bdof_caxpy(h, self.field.ptr, self.whole.ptr, 1.0, self.fx * self.fy, dbl))
+                self.ctx.check(lib.bdof_tiles_scatter_diff64(h, self.tiles_out.ptr, self.tiles_free.ptr, w.ptr, self.fx, self.fy, B, T, T, xo, yo,
+                                                             self.halo, self.halo, 1))
+            f, w = w, f
+        if f is not self.field64:                            # an odd number of swaps: the result sits in the other buffer
+            self.ctx.check(lib.bdof_memcpy_d2d(h, self.field64.ptr, f.ptr, npx * 16))
+        if not self.dbl:
+            self.ctx.check(lib.bdof_c_convert(h, self.field.ptr, self.field64.ptr, npx, 0))
 
     def _sum_over_ranks(self, buf):
         if self.comm.size > 1:
@@ -278,8 +327,8 @@ class WholeFieldPropagator(object):
         self.eng = MultisliceEngine(self.fy, self.fx, self.n_slice, 1, with_grad=False, device=device, engine='generic')
         self.ctx, self.lib, self.h = self.eng.ctx, self.eng.lib, self.eng.h
         self.k64 = 2. * pi * voxel_nm[2] / lmbda_nm
-        self.h64 = DeviceBuffer.from_host(self.ctx, TiledPropagator._free_table(voxel_nm[2], lmbda_nm, voxel_nm, (self.fy, self.fx),
-                                                                                (self.fy, self.fx), pi, 1, np.complex128))
+        hk = np.fft.ifftshift(util.get_kernel(voxel_nm[2], lmbda_nm, voxel_nm, (self.fy, self.fx), pi=pi)) / float(self.fx * self.fy)
+        self.h64 = DeviceBuffer.from_host(self.ctx, np.ascontiguousarray(hk.T.astype(np.complex128)))      # [kx][ky]
         self.field = DeviceBuffer(self.ctx, self.fx * self.fy * 16, np.complex128, (self.fx, self.fy))
         self.idx = DeviceBuffer.from_host(self.ctx, np.zeros(3, dtype=np.int32))
 

@@ -180,6 +180,17 @@ int bdof_field_loss_seed(bdof_ctx* ctx, void* field, const float* meas, int FX, 
  *   the (delta, beta) rows of bdof_set_object, rocFFT double-precision transforms, h[kx][ky] / (NX NY) in float64 (device).
  *   Unfused (an accuracy path, ~4x the time of the fused float32 kernels): a 1024-slice stack through float32 transforms
  *   carries 1.5e-5 of rounding, this path none. */
+/* The slice step's transfer function in float64 ([ky][kx], 1 / (NX NY) folded in: what bdof_set_physics' hs was rounded from;
+ * call it after bdof_set_physics).  The streaming engine's per-slice launches then multiply by dithered float32 copies of it —
+ * copy z mod D for slice z, the adjoint step by the conjugate of the copy its forward step used — whose roundings average to the
+ * float64 values: a fixed float32 table is the same perturbation in every slice and its error grows linearly with depth
+ * (1.4e-5 of the exit wave after 1024 slices with everything else in float64; 1e-6 with the copies).  np_funcs.py:42 multiplies
+ * by a complex128 H.  D = env BDOF_H_DITHER (default 64, at most 256 MiB of copies; 0 switches it off). */
+int bdof_set_transfer_f64(bdof_ctx* ctx, const double* hs64);
+/* bdof_forward_range with the table of its transfer-function steps supplied by the caller (device, [ky][kx] complex64 like hs):
+ * the tiled propagator's free-space step over a whole stitch range (H^n) through the fused kernels. */
+int bdof_forward_range_h(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
+                         const void* in_real, void* out_real, int prop_last, const void* h);
 int bdof_fields_free_step(bdof_ctx* ctx, void* fields, int B, int NX, int NY, const void* h, int conj_h, int is_double);
 int bdof_caxpy(bdof_ctx* ctx, void* y, const void* x, double alpha, size_t n, int is_double);
 int bdof_c_convert(bdof_ctx* ctx, void* dst, const void* src, size_t n, int to_double);
@@ -187,6 +198,14 @@ int bdof_tiles_gather_f64(bdof_ctx* ctx, const void* field, int FX, int FY, void
                           const int* y0, int taper);
 int bdof_tiles_scatter_f64(bdof_ctx* ctx, const void* tiles, void* field, int FX, int FY, int B, int TX, int TY, const int* x0,
                            const int* y0, int halo_x, int halo_y);
+/* The float32 tiled path with the long-range correction keeps its FIELD in complex128: the whole-field free-space step carries
+ * the bulk of the wave in double, the complex64 tiles (fused kernels) add the object's part, T psi - T_free psi.
+ * bdof_tiles_gather_mixed: complex64 tiles cut out of the complex128 field (tapered, periodic);
+ * bdof_tiles_scatter_diff64: field[core] = (accumulate ? field[core] : 0) + tiles_a - tiles_b (tiles_b nullable), in float64. */
+int bdof_tiles_gather_mixed(bdof_ctx* ctx, const void* field64, int FX, int FY, void* tiles, int B, int TX, int TY, const int* x0,
+                            const int* y0, int taper);
+int bdof_tiles_scatter_diff64(bdof_ctx* ctx, const void* tiles_a, const void* tiles_b, void* field64, int FX, int FY, int B, int TX, int TY,
+                              const int* x0, const int* y0, int halo_x, int halo_y, int accumulate);
 int bdof_forward_range_f64(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
                            void* fields, const void* h, double k, int prop_last);
 

@@ -270,11 +270,12 @@ def test_cfg4_at_its_stated_depth_1024_slices():
     The host's float64 run of this depth takes 393 s, so the reference is the library's own float64 WHOLE-FIELD propagation
     (WholeFieldPropagator: rocFFT double transforms of the 4096^2 field, float64 modulation) — first validated here against the
     host's float64 run at 96 slices (<= 1e-12), then run at 1024.
-    The default plan at this depth: float64 tiles + the long-range correction, stitched every 16 slices (64 ranges) — exit wave
-    and intensity within 1e-5 of the whole field (the north star's bound; measured ~1e-6).  On record beside it, with their
-    bounds: the same plan in float32 (the rounding of 4096 float32 line transforms per tile: ~1.5e-5), and the float64 tiles
-    WITHOUT the correction at round 3's interval (the tiling error proper, 2.2e-5: the whole-field propagator's long-range
-    tails, which no tile sees)."""
+    * the default plan at this depth — fused float32 tiles with dithered constants and transfer function, the long-range
+      correction with the field in float64, stitched every 16 slices (64 ranges): exit wave and intensity within the north
+      star's 1e-5 (measured 5.8e-6);
+    * precision='float64' (rocFFT double tiles): within 2e-6 (measured 9.1e-7: what is left of the tiling error);
+    * float64 tiles WITHOUT the correction at round 3's interval: the tiling error proper, 2.2e-5 — the whole-field
+      propagator's long-range tails, which no tile sees; on record with its bounds, it is what the correction removes."""
     from beyond_dof_amd.tiling import TiledPropagator, WholeFieldPropagator
     n = 4096
     slab, probe = _cfg4_inputs(n)
@@ -290,11 +291,11 @@ def test_cfg4_at_its_stated_depth_1024_slices():
     ref = wf.forward(probe, zero)
     del wf
     res = {}
-    for name, kw in (('default', {}), ('float32', dict(precision='float32')),
+    for name, kw in (('default', {}), ('float64', dict(precision='float64')),
                      ('no_correction', dict(precision='float64', long_range=False))):
         tp = TiledPropagator((n, n), S, 5000., 1e-7, tile=512, halo=64, **kw)
         if name == 'default':
-            assert tp.precision == 'float64' and tp.long_range and tp.seg == 16 and len(tp.segments()) == 64 and tp.n_tiles == 121
+            assert tp.precision == 'float32' and tp.long_range and tp.seg == 16 and len(tp.segments()) == 64 and tp.n_tiles == 121
         elif name == 'no_correction':
             assert tp.seg == 129 and len(tp.segments()) == 8
         tp.set_object_slab(slab, 0.1 * slab)
@@ -303,7 +304,7 @@ def test_cfg4_at_its_stated_depth_1024_slices():
         res[name] = (rel(out, ref), rel(np.abs(out) ** 2, np.abs(ref) ** 2))
     print('cfg4 at 1024 slices vs the float64 whole field (wave, intensity):', res, '; float64 engine vs the host at 96 slices:', e96)
     assert max(res['default']) <= 1e-5, res
-    assert max(res['float32']) <= 2.5e-5, res
+    assert max(res['float64']) <= 2e-6, res
     assert 1.5e-5 <= res['no_correction'][0] <= 3e-5, res
 
 

@@ -101,6 +101,21 @@ int main(int argc, char** argv) {
             ms = time_it([&] { hipLaunchKernelGGL((kv_prop<N, 1>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters); printf("  prop memory-only %8.2f us\n", ms * 1e3);
             ms = time_it([&] { hipLaunchKernelGGL((kv_prop<N, 2>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters); printf("  prop compute-only%8.2f us\n", ms * 1e3);
             ms = time_it([&] { hipLaunchKernelGGL((kv_prop<N, 3>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters); printf("  prop plain-store %8.2f us\n", ms * 1e3);
+            ms = time_it([&] { hipLaunchKernelGGL((kv_prop<N, 4>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a); }, iters); printf("  prop in-register exchanges %8.2f us\n", ms * 1e3);
+            if (per_cu == 2) {          // the in-register variant against the production form, same inputs
+                std::vector<cf> r0(fld), r5(fld);
+                hipLaunchKernelGGL((kv_prop<N, 0>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a);
+                CK(hipMemcpy(r0.data(), out, fld * 8, hipMemcpyDeviceToHost));
+                CK(hipMemset(out, 0, fld * 8));
+                hipLaunchKernelGGL((kv_prop<N, 5>), dim3(grid), dim3(BDOF_THREADS), 0, 0, a);
+                CK(hipMemcpy(r5.data(), out, fld * 8, hipMemcpyDeviceToHost));
+                double num = 0, den = 0;
+                for (size_t i = 0; i < fld; ++i) {
+                    num += (double)(r0[i].x - r5[i].x) * (r0[i].x - r5[i].x) + (double)(r0[i].y - r5[i].y) * (r0[i].y - r5[i].y);
+                    den += (double)r0[i].x * r0[i].x + (double)r0[i].y * r0[i].y;
+                }
+                printf("  in-register vs production result: rel L2 %.3e\n", sqrt(num / den));
+            }
         }
         {
             RowBwdArgs a{in, tape, out, grot, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};

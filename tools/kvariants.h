@@ -1,9 +1,12 @@
 // Experimental variants of the propagation row kernel for A/B timing in kbench (development aid).
 #pragma once
 #include "../beyond_dof_amd/csrc/bdof_kernels.h"
+#include "../beyond_dof_amd/csrc/bdof_fft_reg.h"
 
 // MODE 0: full; 1: memory only (load, one LDS hop for the transposition, transposed store; no butterflies);
 // 2: compute only (no global loads of u/h, result stored by one lane only); 3: full but plain (non-transposed) store
+// 4: full with the stage exchanges in registers (bdof_fft_reg.h; h read as if laid out in the permuted order: timing);
+// 5: the same with h gathered through fft512_perm from the natural-order table (correct results, for the comparison with 0)
 template <int NX, int MODE>
 __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void kv_prop(RowPropArgs a) {
     typedef RowCfg<NX> C;
@@ -33,6 +36,16 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void kv_prop(R
 #pragma unroll
                 for (int m = 0; m < 8; ++m) { u[m] = make_float2(tid * 0.001f + m, 1.f - m); hv[m] = make_float2(0.5f, 0.25f * m); }
             }
+            if constexpr ((MODE == 4 || MODE == 5) && NX == 512) {
+                if (MODE == 5) {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) hv[m] = hrow[fft512_perm(tid, m)];
+                }
+                fft512_reg_forward<1, false>(u, tw, tid);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) u[m] = cmul(u[m], cscale(hv[m], a.scale));
+                fft512_reg_inverse_partial<2, false>(u, tw, tid, lds);
+            } else
             if (MODE == 1) {
                 const int bs = lds.slot(tid);
 #pragma unroll
