@@ -29,7 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ROUND = 'r03'
+ROUND = 'r04'
 # algorithmic bytes per pixel per launch (they sum to SURVEY §8(d)'s 104 B per slice-step)
 BYTES_PER_PX = {'row_fwd': 24.0, 'col_prop': 16.0, 'row_bwd': 40.0, 'rot_adjoint': 8.0}
 HBM_PEAK = 8.0e12
@@ -47,13 +47,25 @@ PMC_SUMMARY_CONV = os.path.join(ROOT, 'profiles', ROUND + '_pmc_traffic_conv.jso
 STATS_1STREAM_CONV = os.path.join(ROOT, 'profiles', ROUND + '_kernel_stats_conv.csv')
 
 
+def same_build(recorded):
+    """A committed profile summary belongs to this run only if it was taken on the same kernel sources and compiler flags
+    (beyond_dof_amd._lib.build_id: the summaries carry it, bench.py's line carries it)."""
+    from beyond_dof_amd._lib import build_id
+    mine = build_id()
+    return bool(recorded) and recorded.get('source_sha256') == mine['source_sha256'] and recorded.get('flags') == mine['flags']
+
+
 def pmc_traffic(kernel_class, n, mb, conv=False):
-    """Measured L2<->fabric bytes per launch of the class's kernel (512^3, 25 angles, whole-batch launches), or None."""
+    """Measured L2<->fabric bytes per launch of the class's kernel (512^3, 25 angles, whole-batch launches), or None — also when
+    the committed summary was taken on other sources or flags than the library being timed."""
     summary = PMC_SUMMARY_CONV if conv else PMC_SUMMARY
     if (n, mb) != (512, 25) or not os.path.exists(summary):
         return None
+    doc = json.load(open(summary))
+    if not same_build(doc.get('build')):
+        return None
     want = (PMC_KERNEL_CONV if conv else PMC_KERNEL)[kernel_class]
-    for name, k in json.load(open(summary))['kernels'].items():
+    for name, k in doc['kernels'].items():
         if name.startswith(want):
             return k['total_bytes_per_launch']
     return None
@@ -63,7 +75,8 @@ def rocprof_avg_ms(kernel_class, n, mb, conv=False):
     """Average dispatch duration of the class's kernel in the committed single-stream rocprofv3 --kernel-trace --stats summary
     of this command (512^3, 25 angles only), or None."""
     stats = STATS_1STREAM_CONV if conv else STATS_1STREAM
-    if (n, mb) != (512, 25) or not os.path.exists(stats):
+    stamp = os.path.splitext(stats)[0] + '.build.json'
+    if (n, mb) != (512, 25) or not os.path.exists(stats) or not os.path.exists(stamp) or not same_build(json.load(open(stamp))):
         return None
     import csv
     want = (PMC_KERNEL_CONV if conv else PMC_KERNEL)[kernel_class]
@@ -419,6 +432,9 @@ def main():
                           'adjoint': 'recompute (tape-free)' if args.recompute else 'tape',
                           'transform_constants': 'one float32 table' if os.environ.get('BDOF_TW_DITHER') in ('0', '1') else
                           'dithered over the slices, {} copies (DESIGN 4)'.format(os.environ.get('BDOF_TW_DITHER', '64')),
+                          'transfer_function': 'one float32 table' if os.environ.get('BDOF_H_DITHER') in ('0', '1') else
+                          'dithered over the slices, {} copies'.format(os.environ.get('BDOF_H_DITHER', '64')),
+                          'build': _lib.build_id(),
                           'hbm_used_GiB': solver.ctx.mem_used() / 2.0 ** 30},
                'roofline': roof}
         if world == 1 and not args.no_cpu_baseline:

@@ -114,6 +114,24 @@ EXPORTED_SYMBOLS = sorted(_SIGNATURES)
 _lib = None
 
 
+def build_id():
+    """What the measured numbers of a run belong to: a hash of the kernel sources (csrc/*, include/bdof.h), the compiler flags
+    libbdof.so was built with (libbdof.so.flags) and a hash of the library file itself.  bench.py puts it in its JSON line and
+    the profile summaries under profiles/ carry it (tools/pmc_summary.py, tools/rocpd_summary.py): a traffic figure or a
+    rocprofv3 duration read back from a committed file is only quoted next to a run of the same sources and flags."""
+    import hashlib
+    root = os.path.dirname(_HERE)
+    h = hashlib.sha256()
+    csrc = os.path.join(_HERE, 'csrc')
+    files = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc))] + [os.path.join(root, 'include', 'bdof.h')]
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0')
+        h.update(open(f, 'rb').read())
+    flags = open(LIB_PATH + '.flags').read() if os.path.exists(LIB_PATH + '.flags') else None
+    lib = hashlib.sha256(open(LIB_PATH, 'rb').read()).hexdigest()[:16] if os.path.exists(LIB_PATH) else None
+    return {'source_sha256': h.hexdigest()[:16], 'flags': flags, 'lib_sha256': lib}
+
+
 class BdofError(RuntimeError):
     pass
 

@@ -20,4 +20,5 @@ def create_summary(save_path, locals_dict, var_list=None, preset=None):
         os.makedirs(save_path)
     with open(os.path.join(save_path, 'summary.txt'), 'w') as f:
         for var_name in var_list:
-            f.write('{:<20}{}\n'.format(var_name, str(locals_dict.get(var_name))))
+            # the reference's '{:<20}{}' layout; a name that fills the column still gets a blank before its value
+            f.write('{:<20}{}{}\n'.format(var_name, '' if len(var_name) < 20 else ' ', str(locals_dict.get(var_name))))

@@ -6,8 +6,8 @@
  *   gcc -O2 -I include examples/cabi_forward.c -o cabi_forward -L beyond_dof_amd -lbdof -Wl,-rpath,$PWD/beyond_dof_amd
  *
  * File layout (little endian): int32 NY, NX, S, B, det_mode, variant; double k, h00[2], hdet00[2], a0[2];
- * float hs[NX*NY*2]; float hdet[NX*NY*2] (det_mode 1 only); float probe_eps[NX*NY*2]; float rows[B*S*NX*NY*2];
- * float meas[B*NX*NY]. */
+ * float hs[NX*NY*2]; double hs64[NX*NY*2] (the same table before it was rounded: bdof_set_transfer_f64); float hdet[NX*NY*2]
+ * (det_mode 1 only); float probe_eps[NX*NY*2]; float rows[B*S*NX*NY*2]; float meas[B*NX*NY]. */
 #include <stdio.h>
 #include <stdlib.h>
 #include "bdof.h"
@@ -38,6 +38,7 @@ int main(int argc, char** argv) {
     const int NY = hdr[0], NX = hdr[1], S = hdr[2], B = hdr[3], det = hdr[4], variant = hdr[5];
     const size_t fld = (size_t)NX * NY;
     float* hs = slurp(f, fld * 2 * sizeof(float));
+    double* hs64 = slurp(f, fld * 2 * sizeof(double));
     float* hdet = det == BDOF_DET_NEAR ? slurp(f, fld * 2 * sizeof(float)) : NULL;
     float* probe = slurp(f, fld * 2 * sizeof(float));
     float* rows = slurp(f, (size_t)B * S * fld * 2 * sizeof(float));
@@ -48,6 +49,7 @@ int main(int argc, char** argv) {
     CHECK(bdof_ctx_create(&ctx, 0, NULL));
     CHECK(bdof_configure(ctx, NY, NX, S, B, 1));
     CHECK(bdof_set_physics(ctx, dbl[0], hs, hdet, &dbl[1], &dbl[3], det, variant));
+    CHECK(bdof_set_transfer_f64(ctx, hs64));         /* the slice step's H in float64: the kernels use dithered float32 copies of it */
     CHECK(bdof_set_probe(ctx, probe, dbl[5], dbl[6]));
 
     void *d_rows = NULL, *d_meas = NULL, *d_wave = NULL;

@@ -58,6 +58,7 @@ def test_c_host_drives_the_library(tmp_path, fp, monkeypatch):
         f.write(struct.pack('<6i', Y, X, S, B, det, 0))
         f.write(struct.pack('<7d', k, h00[0], h00[1], hdet00[0], hdet00[1], a0.real, a0.imag))
         f.write(hs.tobytes())
+        f.write(util.device_transfer_function(voxel_nm[-1], lmbda_nm, voxel_nm, Y, X, dtype=np.complex128).tobytes())
         if hdet is not None:
             f.write(hdet.tobytes())
         f.write(eps.tobytes())

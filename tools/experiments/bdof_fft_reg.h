@@ -22,7 +22,7 @@
 //   lane bit 2: v_mov_dpp row_shr:4 / row_shl:4 with bank masks (two)
 //   lane bits 1, 0: v_mov_dpp quad_perm + v_cndmask (four)
 #pragma once
-#include "bdof_fft.h"
+#include "../../beyond_dof_amd/csrc/bdof_fft.h"
 
 __device__ __forceinline__ void xl_swap32(float& a, float& b) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);

@@ -1,7 +1,7 @@
 // Experimental variants of the propagation row kernel for A/B timing in kbench (development aid).
 #pragma once
 #include "../beyond_dof_amd/csrc/bdof_kernels.h"
-#include "../beyond_dof_amd/csrc/bdof_fft_reg.h"
+#include "experiments/bdof_fft_reg.h"
 
 // MODE 0: full; 1: memory only (load, one LDS hop for the transposition, transposed store; no butterflies);
 // 2: compute only (no global loads of u/h, result stored by one lane only); 3: full but plain (non-transposed) store

@@ -5,7 +5,11 @@ WRITE_SIZE (KB) is exact.   usage: pmc_summary.py FETCH.csv|.db WRITE.csv|.db ou
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from beyond_dof_amd._lib import build_id  # noqa: E402
 
 
 def per_kernel(path):
@@ -32,7 +36,7 @@ def main():
         out[short] = {'dispatches': len(f), 'read_bytes_per_launch': 2.0 * 1024 * sum(f) / len(f),
                       'write_bytes_per_launch': 1024 * sum(w) / len(w)}
         out[short]['total_bytes_per_launch'] = out[short]['read_bytes_per_launch'] + out[short]['write_bytes_per_launch']
-    json.dump({'corrections': {'FETCH_SIZE': 'KB x 1024 x 2', 'WRITE_SIZE': 'KB x 1024'}, 'kernels': out},
+    json.dump({'corrections': {'FETCH_SIZE': 'KB x 1024 x 2', 'WRITE_SIZE': 'KB x 1024'}, 'build': build_id(), 'kernels': out},
               open(sys.argv[3], 'w'), indent=1, sort_keys=True)
     for k, v in sorted(out.items()):
         print('{:<45} n={:<5} read {:8.1f} MB  write {:8.1f} MB'.format(k, v['dispatches'], v['read_bytes_per_launch'] / 1e6,

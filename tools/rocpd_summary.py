@@ -3,9 +3,14 @@
    `--kernel-trace --stats` run), and, for a `--pmc` run, the per-kernel mean of each counter.
 usage: rocpd_summary.py stats RESULTS.db OUT.csv | pmc RESULTS.db OUT.csv"""
 import csv
+import json
 import math
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from beyond_dof_amd._lib import build_id  # noqa: E402
 
 
 def stats(db, out):
@@ -22,6 +27,7 @@ def stats(db, out):
             mean = sum(v) / float(len(v))
             sd = math.sqrt(sum((x - mean) ** 2 for x in v) / max(len(v) - 1, 1))
             w.writerow([name, len(v), sum(v), round(mean, 6), round(100.0 * sum(v) / total, 2), min(v), max(v), round(sd, 6)])
+    json.dump(build_id(), open(os.path.splitext(out)[0] + '.build.json', 'w'), indent=1, sort_keys=True)     # what was profiled
 
 
 def pmc(db, out):
