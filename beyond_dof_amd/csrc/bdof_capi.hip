@@ -51,6 +51,7 @@ struct bdof_ctx {
     int tw_dither = 0;
     unsigned tw_tick = 0;          // the slice of the last A / A' launch: the transfer-function launch that follows takes the same copy
     cf *hs = nullptr, *hdet = nullptr, *hcomb = nullptr, *probe = nullptr;
+    cf* hsT_d = nullptr;           // the same copies in the LDS-resident kernel's [kx][ky] order
     cf* hs_d = nullptr;            // bdof_set_transfer_f64: hs_copies dithered float32 copies of the slice step's table (bdof_field.h)
     int hs_copies = 0;
     const cf* hs_override = nullptr;   // bdof_forward_range_h: the table of this call's transfer-function steps
@@ -829,10 +830,11 @@ static int resident_run(bdof_ctx* c, int B, const float* meas, void* out_wave, b
     }
     ProfScope ps(c, BDOF_K_ROW_FWD);
     const bool grad = do_grad && meas;
-    ResArgs a{c->probe, c->hsT, c->hdetT, grad ? c->tape : nullptr, (size_t)c->Bmax * c->NX * c->NY, c->grot, c->obj, c->res_carrier,
+    const bool hdith = c->hs_copies > 0 && c->hsT_d;
+    ResArgs a{c->probe, hdith ? c->hsT_d : c->hsT, c->hdetT, grad ? c->tape : nullptr, (size_t)c->Bmax * c->NX * c->NY, c->grot, c->obj, c->res_carrier,
               carrier_det(c), c->pstack, c->pdet, meas, (cf*)out_wave, c->partial, c->twR, B, c->S, c->det_mode,
               c->variant == BDOF_VARIANT_TF_ALL ? 1 : 0, grad ? 1 : 0, c->k, 2.f / ((float)B * (float)c->NX * (float)c->NY), c->meas_dev,
-              c->meas_dev ? meas_dref(c) : 0.f, grad ? c->gpsi0 : nullptr, c->pdet ? c->pdet64 : nullptr};
+              hdith ? c->hs_copies : 0, c->meas_dev ? meas_dref(c) : 0.f, grad ? c->gpsi0 : nullptr, c->pdet ? c->pdet64 : nullptr};
     const int grid = B < c->npartial ? B : c->npartial;
     int r = 0, waves = 1;
     switch (c->NX) {
@@ -939,6 +941,7 @@ static void free_generic(bdof_ctx* c) {
 static void free_workspace(bdof_ctx* c) {
     free_generic(c);
     if (c->hs_d) { (void)hipFree(c->hs_d); c->hs_d = nullptr; c->hs_copies = 0; }
+    if (c->hsT_d) { (void)hipFree(c->hsT_d); c->hsT_d = nullptr; }
     void* ptrs[] = {c->cstack, c->cdet64, c->pdet64, c->pdetT64, c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->taps_dev, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->gpsi0, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
@@ -1164,6 +1167,7 @@ int bdof_set_transfer_f64(bdof_ctx* c, const double* hs64) {
     HIPC(c, hipSetDevice(c->device));
     HIPC(c, hipStreamSynchronize(c->stream));
     if (c->hs_d) { (void)hipFree(c->hs_d); c->hs_d = nullptr; }
+    if (c->hsT_d) { (void)hipFree(c->hsT_d); c->hsT_d = nullptr; }
     c->hs_copies = 0;
     double2* tmp = nullptr;
     HIPC(c, hipMalloc(&tmp, n * sizeof(double2)));
@@ -1173,6 +1177,22 @@ int bdof_set_transfer_f64(bdof_ctx* c, const double* hs64) {
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_dither_copies, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, tmp, c->hs_d, n, D);
         e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess && c->resident) {
+        // the LDS-resident kernel multiplies its field image [kx][ky] element by element: the same copies, transposed
+        std::vector<double> t(2 * n);
+        for (int ky = 0; ky < c->NY; ++ky)
+            for (int kx = 0; kx < c->NX; ++kx) {
+                t[2 * ((size_t)kx * c->NY + ky)] = hs64[2 * ((size_t)ky * c->NX + kx)];
+                t[2 * ((size_t)kx * c->NY + ky) + 1] = hs64[2 * ((size_t)ky * c->NX + kx) + 1];
+            }
+        e = hipMalloc(&c->hsT_d, (size_t)D * n * sizeof(cf));
+        if (e == hipSuccess) e = hipMemcpy(tmp, t.data(), n * sizeof(double2), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_dither_copies, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, tmp, c->hsT_d, n, D);
+            e = hipStreamSynchronize(c->stream);
+        }
+        c->res_dirty = true;
     }
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(c, (int)e, "building the dithered transfer-function copies failed");

@@ -295,7 +295,8 @@ template <int N, int T, int SIGN, bool EX = false> __device__ __forceinline__ vo
 
 struct ResArgs {
     const cf* probe;       // [N][N] eps part of the probe, [x][y]
-    const cf* hsT;         // [kx][ky] transfer function / (N*N)
+    const cf* hsT;         // [kx][ky] transfer function / (N*N); hD > 0: hD dithered copies of it, one after the other — the
+                           // step after slice z (and its adjoint) multiplies by copy z mod hD (bdof_set_transfer_f64)
     const cf* hdetT;       // [kx][ky] detector transfer function / (N*N)   (near field)
     cf* tape;              // nullable: phi_z tape, slice z of wavefield b at tape + z * tape_stride + b * N * N
     size_t tape_stride;
@@ -316,6 +317,7 @@ struct ResArgs {
     int B, S, det_mode, tf_all, do_grad;
     float k, seed_scale;
     int meas_dev;          // `meas` holds m - |carrier_det| (loss_seed_dev, bdof_kernels.h)
+    int hD;                // dithered copies of hsT (0: one table)
     float dref;
     cf* gpsi0;             // nullable [B][N][N]: G(psi_0), the probe gradient per wavefield
     const double2* pdet64; // nullable: `pdet` in float64 — the residual |d| - m is then formed in float64 (loss_seed_f64)
@@ -551,6 +553,9 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
     for (int e = tid; e < 2 * N; e += T) tw[e] = a.twiddle[e];      // hi parts, then lo parts (upload_twiddle)
     const bool far = a.det_mode == BDOF_DET_FAR;
     const size_t fsz = (size_t)N * N;
+    // the table of the step after slice z: its dithered copy z mod hD (a fixed float32 table is the same perturbation in every
+    // slice; bdof_set_transfer_f64), the adjoint of that step the conjugate of the same copy
+    auto hs_of = [&](int z) -> const cf* { return a.hD > 0 ? a.hsT + (size_t)(z % a.hD) * fsz : a.hsT; };
     for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
         const int y0 = a.obj.yoff ? a.obj.yoff[b] : 0;
         cf* tape0 = a.tape ? a.tape + b * fsz : nullptr;           // slice z of this wavefield: tape0 + z * tape_stride
@@ -582,9 +587,9 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     em.csh = a.carrier[a.S + z + 1];
                     em.pz = a.pstack ? a.pstack + (size_t)(z + 1) * fsz : nullptr;
                     em.y0 = y0;
-                    res_prop<N, T, false>(f, a.hsT, tw, tid, em);
+                    res_prop<N, T, false>(f, hs_of(z), tw, tid, em);
                 } else if (a.tf_all && !far) {
-                    res_prop<N, T, false>(f, a.hsT, tw, tid);
+                    res_prop<N, T, false>(f, hs_of(z), tw, tid);
                 }
                 if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;      // read two propagation steps from now
             }
@@ -597,9 +602,9 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                 if (tid < N) rowbuf[((z + 2) % 3) * N + tid] = r2;
                 if (z + 1 < a.S) {
                     // the next slice's factors: in flight during the last two passes of the step
-                    res_prop<N, T, false>(f, a.hsT, tw, tid, none, [&]() { Pipe::load_factors(a, rowbuf + ((z + 1) % 3) * N, y0, tid, m); });
+                    res_prop<N, T, false>(f, hs_of(z), tw, tid, none, [&]() { Pipe::load_factors(a, rowbuf + ((z + 1) % 3) * N, y0, tid, m); });
                 } else if (a.tf_all && !far) {
-                    res_prop<N, T, false>(f, a.hsT, tw, tid);
+                    res_prop<N, T, false>(f, hs_of(z), tw, tid);
                 }
             }
         }
@@ -693,7 +698,7 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     eb.car = cadd(a.carrier[z], a.carrier[a.S + z]);      // cbar a_z: constant part of phi_z
                     eb.pz = a.pstack ? a.pstack + (size_t)z * fsz : nullptr;
                     eb.y0 = y0;
-                    res_prop<N, T, true>(f, a.hsT, tw, tid, eb);
+                    res_prop<N, T, true>(f, hs_of(z), tw, tid, eb);
                 } else {
                     // the slice the adjoint sweep starts from when no transfer-function step follows the last slice
                     Pipe::load_factors(a, rowbuf + (z % 3) * N, y0, tid, m);
@@ -705,12 +710,12 @@ __global__ __launch_bounds__(T, WPE) void k_resident(ResArgs a) {
                     EpiNone none;
                     if (z < a.S - 1) {
                         // this slice's factors and tape: in flight during the last two passes of the adjoint step
-                        res_prop<N, T, true>(f, a.hsT, tw, tid, none, [&]() {
+                        res_prop<N, T, true>(f, hs_of(z), tw, tid, none, [&]() {
                             Pipe::load_factors(a, rowbuf + (z % 3) * N, y0, tid, m);
                             Pipe::load_field(tape, tid, t);
                         });
                     } else {
-                        res_prop<N, T, true>(f, a.hsT, tw, tid);       // slice S - 1 was loaded before the detector step
+                        res_prop<N, T, true>(f, hs_of(z), tw, tid);       // slice S - 1 was loaded before the detector step
                     }
                 }
                 Point::adjoint(f, t, m, cadd(a.carrier[z], a.carrier[a.S + z]), a.pstack ? a.pstack + (size_t)z * fsz : nullptr, a.k, gdst, tid);

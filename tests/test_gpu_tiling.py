@@ -321,7 +321,7 @@ def test_cfg4_tile_size_two_ranges_and_gradient_vs_oracle():
     gradient of the WHOLE-FIELD model.  The latter differs by the tiling itself, not by round-off: the adjoint of the stitch
     hands every tile a hard-edged piece of the (noise-driven, white) adjoint field, whose edge fringes wrap around the tile's
     period — in float64 on the CPU 3.3e-3 / 1.7e-3 / 1.2e-3 of the gradient at halos of 16 / 32 / 48 pixels (128^2 tiles) while
-    the forward wave and the loss agree to 3e-6 / 2e-7 (tools/runs/r3 notes in DESIGN §5): the exact gradient of a loss that is
+    the forward wave and the loss agree to 3e-6 / 2e-7 (MEASUREMENTS.md, round 3, cfg4): the exact gradient of a loss that is
     2e-7 from the whole field's is still 1e-3 from its gradient."""
     from beyond_dof_amd.tiling import TiledPropagator
     n, S, seg = 1024, 20, 16
