@@ -664,6 +664,11 @@ static int generic_plans(bdof_ctx* c, int B, rocfft_plan* fwd, rocfft_plan* inv,
     return 0;
 }
 
+// the transfer function of the step after slice z: its dithered float32 copy where the caller handed the float64 table over
+static const cf* hs_slice(const bdof_ctx* c, int z) {
+    return c->hs_copies > 0 ? c->hs_d + (size_t)((unsigned)z % (unsigned)c->hs_copies) * c->NX * c->NY : c->hs;
+}
+
 static int g_elem_grid(const bdof_ctx* c, size_t n) { return (int)std::min<size_t>((n + 255) / 256, (size_t)c->ncu * 16); }
 
 // one transfer-function step in place: field <- F^-1' ( h * F field )
@@ -695,7 +700,7 @@ static int generic_forward_sweep(bdof_ctx* c, int B, bool tape, rocfft_plan pf, 
         }
         const bool last = z == c->S - 1;
         if (!last || (tf_all && c->det_mode != BDOF_DET_FAR)) {
-            if ((r = generic_prop(c, B, pf, pi, c->bufA, c->hs, 0))) return r;
+            if ((r = generic_prop(c, B, pf, pi, c->bufA, hs_slice(c, z), 0))) return r;      // the slice's dithered copy of H
             a *= c->h00;
         }
     }
@@ -784,7 +789,7 @@ static int generic_loss_grad(bdof_ctx* c, int B, const float* meas, void* out_wa
     }
     for (int z = c->S - 1; z >= 0; --z) {
         const bool prop_after = z < c->S - 1 || (tf_all && c->det_mode != BDOF_DET_FAR);
-        if (prop_after && (r = generic_prop(c, B, pf, pi, c->bufA, c->hs, 1))) return r;
+        if (prop_after && (r = generic_prop(c, B, pf, pi, c->bufA, hs_slice(c, z), 1))) return r;      // conj of the forward step's copy
         ProfScope ps(c, BDOF_K_ROW_BWD);
         GBwdArgs ba{c->bufA, c->tape + (size_t)z * fld, c->grot, c->obj, B, c->NX, c->NY, z, c->k, carrier_phi_at(c, z), c->pstack ? 1 : 0,
                     adj_carrier_at(c, c->S - 1 - z)};
@@ -1158,7 +1163,6 @@ int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det
 int bdof_set_transfer_f64(bdof_ctx* c, const double* hs64) {
     if (!c || !hs64) return BDOF_ERR_ARG;
     if (!c->have_physics) return fail(c, BDOF_ERR_STATE, "bdof_set_physics has not been called");
-    if (c->generic) return 0;                          // rocFFT engine: one table (the LDS-resident kernel keeps its own, too)
     static const int want = [] { const char* e = std::getenv("BDOF_H_DITHER"); return e ? std::max(0, std::min(256, atoi(e))) : 64; }();
     const size_t n = (size_t)c->NX * c->NY;
     int D = want;

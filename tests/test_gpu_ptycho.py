@@ -184,12 +184,14 @@ def test_reconstruct_ptychography_vs_the_reference_loop_fft(tmp_path, monkeypatc
         # measured: delta 1.6e-6, beta 2.6e-7, no voxel more than 0.001 of a step away
         assert stats[0] <= 0.01 and stats[1] <= 5e-6 and stats[3] <= 2e-6 and stats[4] == 0.0, stats
     elif adjoint_precision == 'first-step':
-        # float64 for the first minibatch of each epoch only (2 of the 8 steps here, 1 in hundreds at cfg5's size)
-        assert stats[0] <= 0.02 and stats[1] <= 1e-5 and stats[3] <= 5e-6 and stats[4] == 0.0, stats
+        # float64 for the first minibatch of each epoch only (2 of the 8 steps here, 1 in hundreds at cfg5's size): 2.1e-6
+        assert stats[0] <= 0.02 and stats[1] <= 5e-6 and stats[3] <= 2e-6 and stats[4] == 0.0, stats
     else:
-        # measured: delta 1.7e-5 (1.85e-5 with exact adjoint twiddles: it is a lottery over ~100 voxels), beta 1.7e-6 relative
-        # after eight Adam steps, no voxel more than 0.014 of a step away (round 2, residual in float32: 4.9e-5 / 0.045)
-        assert stats[0] <= 0.05 and stats[1] <= 3e-5 and stats[3] <= 1e-5 and stats[4] == 0.0, stats
+        # all float32, the LDS-resident kernel alone.  Round 4: the kernel multiplies by the slice's DITHERED copy of the transfer
+        # function (bdof_set_transfer_f64) — a fixed float32 H was the same perturbation in all 64 slices of both sweeps:
+        # delta 1.7e-5 -> 7.0e-6, beta 1.7e-6 -> 9.4e-7, no voxel more than 0.005 of a step away.  Inside the north star's 1e-5
+        # without any float64 sweep (round 2, residual in float32 as well: 4.9e-5)
+        assert stats[0] <= 0.02 and stats[1] <= 1e-5 and stats[3] <= 5e-6 and stats[4] == 0.0, stats
 
 
 def test_first_step_engine_that_cannot_be_set_up_is_reported_and_recorded(tmp_path, monkeypatch, capsys):
