@@ -251,6 +251,28 @@ def rehearse_cpu(args, out):
     return 0
 
 
+def device_copy_rate(ctx, nbytes=1 << 30, reps=4):
+    """What a plain device-to-device copy reaches on THIS box right now, bytes read + written per second (stream-ordered time
+    stamps around `reps` copies of `nbytes`): the practical ceiling next to the 8 TB/s datasheet figure the fractions are priced at."""
+    import ctypes
+    from beyond_dof_amd._lib import DeviceBuffer
+    lib, h = ctx.lib, ctx.handle
+    a, b = DeviceBuffer(ctx, nbytes), DeviceBuffer(ctx, nbytes)
+    ctx.check(lib.bdof_memset(h, a.ptr, 1, nbytes))
+    ctx.check(lib.bdof_memcpy_d2d(h, b.ptr, a.ptr, nbytes))
+    ctx.sync()
+    ctx.check(lib.bdof_timer_mark(h, 2))
+    for _ in range(reps):
+        ctx.check(lib.bdof_memcpy_d2d(h, b.ptr, a.ptr, nbytes))
+    ctx.check(lib.bdof_timer_mark(h, 3))
+    ctx.sync()
+    ms = ctypes.c_double(0)
+    ctx.check(lib.bdof_timer_elapsed(h, 2, 3, ctypes.byref(ms)))
+    a.free()
+    b.free()
+    return 2.0 * nbytes * reps / (ms.value * 1e-3)
+
+
 def roofline_pass(solver, batch, hyper, n, mb, S, conv=False):
     """One step with the sub-batch streams off and every launch bracketed by HIP events on the stream it is launched on."""
     eng = solver.eng
@@ -405,6 +427,7 @@ def main():
     S = n
     roof = None if args.no_profile or args.rotation != 'nearest' else roofline_pass(solver, my_batches[0], hyper, n, mb, S, conv=args.propagator == 'conv')
     loss = solver.loss_and_grad(my_batches[0], want_loss=True)
+    copy_rate = device_copy_rate(solver.ctx) if (rank == 0 and roof is not None) else None
     comm.Barrier()
 
     if rank == 0:
@@ -412,6 +435,10 @@ def main():
         if roof is not None:
             roof['whole_step_frac'] = (72.0 if args.propagator == 'conv' else 104.0) * n * n * (slice_steps / world) / elapsed / HBM_PEAK
             roof['sub_batch_streams_in_timed_region'] = groups
+            roof['device_copy_GBps'] = copy_rate / 1e9
+            roof['device_copy_note'] = ('a plain device-to-device copy of 1 GiB on this box, read + written bytes per second: the practical '
+                                        'HBM ceiling beside the 8 TB/s the fractions are priced at (whole_step_frac x 8000 / this = the step '
+                                        'relative to a copy)')
         out = {'metric': 'multislice fwd+adjoint slice-steps/s (full Adam iteration: rotation, forward, loss, adjoint, '
                          'gradient exchange, regulariser+Adam)',
                'value': slice_steps / elapsed, 'unit': 'slice-steps/s', 'n_gpus': world, 'steps': args.steps,

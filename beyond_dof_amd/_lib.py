@@ -59,6 +59,10 @@ _SIGNATURES = {
     'bdof_tiles_gather_mixed': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int]),
     'bdof_tiles_scatter_diff64': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int,
                                                  ctypes.c_int, ctypes.c_int]),
+    'bdof_tiles_scatter_adjoint_mixed': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_int,
+                                                        ctypes.c_int]),
+    'bdof_tiles_gather_adjoint_diff64': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp,
+                                                        ctypes.c_int, ctypes.c_int]),
     'bdof_forward_range_f64': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp, _vp, ctypes.c_double, ctypes.c_int]),
     'bdof_tape_to_real': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp]),
     'bdof_loss_grad': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),

@@ -1756,7 +1756,34 @@ int bdof_tiles_gather_mixed(bdof_ctx* c, const void* field64, int FX, int FY, vo
     if (taper < 0 || 2 * taper > TX || 2 * taper > TY) return fail(c, BDOF_ERR_ARG, "taper must fit the tile");
     HIPC(c, hipSetDevice(c->device));
     TileMixArgs a{(double2*)field64, nullptr, nullptr, (cf*)tiles, x0, y0, B, FX, FY, TX, TY, 0, 0, taper, 0};
-    hipLaunchKernelGGL(k_tiles_gather_mixed, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_tiles_gather_mixed, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a, 0);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// adjoint of bdof_tiles_scatter_diff64 w.r.t. tiles_a: complex64 tiles = the complex128 field on every tile's core, zero elsewhere
+int bdof_tiles_scatter_adjoint_mixed(bdof_ctx* c, const void* field64, int FX, int FY, void* tiles, int B, int TX, int TY, const int* x0,
+                                     const int* y0, int halo_x, int halo_y) {
+    int r = tiles_check(c, field64, tiles, B, FX, FY, TX, TY, x0, y0);
+    if (r) return r;
+    if (halo_x < 0 || halo_y < 0 || 2 * halo_x >= TX || 2 * halo_y >= TY) return fail(c, BDOF_ERR_ARG, "halo must leave a core");
+    HIPC(c, hipSetDevice(c->device));
+    TileMixArgs a{(double2*)field64, nullptr, nullptr, (cf*)tiles, x0, y0, B, FX, FY, TX, TY, halo_x, halo_y, 0, 0};
+    hipLaunchKernelGGL(k_tiles_gather_mixed, dim3((TY + 255) / 256, std::min(TX, 64), B), dim3(256), 0, c->stream, a, 1);
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// adjoint of bdof_tiles_gather_mixed, on a difference of tiles: field64 (+)= sum of the tapered (tiles_a - tiles_b) pixels at the
+// positions they were cut from (periodically); tiles_b nullable
+int bdof_tiles_gather_adjoint_diff64(bdof_ctx* c, const void* tiles_a, const void* tiles_b, void* field64, int FX, int FY, int B, int TX, int TY,
+                                     const int* x0, const int* y0, int taper, int accumulate) {
+    int r = tiles_check(c, field64, tiles_a, B, FX, FY, TX, TY, x0, y0);
+    if (r) return r;
+    if (taper < 0 || 2 * taper > TX || 2 * taper > TY) return fail(c, BDOF_ERR_ARG, "taper must fit the tile");
+    HIPC(c, hipSetDevice(c->device));
+    TileMixArgs a{(double2*)field64, (const cf*)tiles_a, (const cf*)tiles_b, nullptr, x0, y0, B, FX, FY, TX, TY, 0, 0, taper, accumulate};
+    hipLaunchKernelGGL(k_tiles_gather_adjoint_diff64, dim3(std::min(FX, c->ncu * 8)), dim3(256), 0, c->stream, a);
     HIPC(c, hipGetLastError());
     return 0;
 }

@@ -91,11 +91,25 @@ struct TileMixArgs {
     const int* y0;
     int B, FX, FY, TX, TY, hx, hy, taper, accumulate;
 };
-__global__ __launch_bounds__(256) void k_tiles_gather_mixed(TileMixArgs a) {
+// mode 0: tile = field (periodic) x taper window.  mode 1: tile = the field on the tile's CORE, zero on the halo and beyond the
+// field's edge — the adjoint of the write-back (k_tiles_gather's two modes, from a float64 field)
+__global__ __launch_bounds__(256) void k_tiles_gather_mixed(TileMixArgs a, int mode) {
     const int b = blockIdx.z;
     const int ox = a.x0[b], oy = a.y0[b];
     for (int x = blockIdx.y; x < a.TX; x += gridDim.y) {
         cf* dst = a.tiles + ((size_t)b * a.TX + x) * a.TY;
+        if (mode == 1) {
+            const int xg = ox + x;
+            const bool xin = x >= a.hx && x < a.TX - a.hx && xg >= 0 && xg < a.FX;
+            const double2* srow = a.field + (size_t)(xin ? xg : 0) * a.FY;
+            for (int y = blockIdx.x * blockDim.x + threadIdx.x; y < a.TY; y += gridDim.x * blockDim.x) {
+                const int yg = oy + y;
+                const bool in = xin && y >= a.hy && y < a.TY - a.hy && yg >= 0 && yg < a.FY;
+                const double2 v = srow[in ? yg : 0];
+                dst[y] = in ? make_float2((float)v.x, (float)v.y) : make_float2(0.f, 0.f);
+            }
+            continue;
+        }
         const double2* src = a.field + (size_t)wrap_idx(ox + x, a.FX) * a.FY;
         const double wx = taper_weight64(x, a.TX, a.taper);
         for (int y = blockIdx.x * blockDim.x + threadIdx.x; y < a.TY; y += gridDim.x * blockDim.x) {
@@ -122,6 +136,45 @@ __global__ __launch_bounds__(256) void k_tiles_scatter_diff64(TileMixArgs a) {
             if (a.tb) { const cf vb = a.tb[row + y]; dx -= (double)vb.x; dy -= (double)vb.y; }
             if (a.accumulate) { const double2 o = dst[yg]; dx += o.x; dy += o.y; }
             dst[yg] = make_double2(dx, dy);
+        }
+    }
+}
+
+// Adjoint of the tapered periodic cut-out, accumulated into a float64 field: field[xg][yg] += sum over the tiles b and tile
+// pixels (x, y) cut from (xg, yg) — periodically — of w(x) w(y) (ta - tb)[b][x][y].  One workgroup per field row, fixed order.
+__global__ __launch_bounds__(256) void k_tiles_gather_adjoint_diff64(TileMixArgs a) {
+    __shared__ int lb[BDOF_TILE_MAXLIST], lx[BDOF_TILE_MAXLIST];
+    __shared__ int nlist;
+    for (int xg = blockIdx.x; xg < a.FX; xg += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int n = 0;
+            for (int b = 0; b < a.B; ++b) {
+                int x = wrap_idx(xg - a.x0[b], a.FX);
+                for (; x < a.TX && n < BDOF_TILE_MAXLIST; x += a.FX) { lb[n] = b; lx[n] = x; ++n; }
+            }
+            nlist = n;
+        }
+        __syncthreads();
+        const int n = nlist;
+        for (int yg = threadIdx.x; yg < a.FY; yg += blockDim.x) {
+            double sx = 0.0, sy = 0.0;
+            for (int e = 0; e < n; ++e) {
+                const int b = lb[e], x = lx[e];
+                const double wx = taper_weight64(x, a.TX, a.taper);
+                for (int y = wrap_idx(yg - a.y0[b], a.FY); y < a.TY; y += a.FY) {
+                    const double w = wx * taper_weight64(y, a.TY, a.taper);
+                    const size_t o = ((size_t)b * a.TX + x) * a.TY + y;
+                    const cf va = a.ta[o];
+                    double dx = (double)va.x, dy = (double)va.y;
+                    if (a.tb) { const cf vb = a.tb[o]; dx -= (double)vb.x; dy -= (double)vb.y; }
+                    sx += w * dx;
+                    sy += w * dy;
+                }
+            }
+            double2* dst = a.field + (size_t)xg * a.FY + yg;
+            if (a.accumulate) { sx += dst->x; sy += dst->y; }
+            *dst = make_double2(sx, sy);
         }
     }
 }

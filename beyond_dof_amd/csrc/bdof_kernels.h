@@ -325,6 +325,9 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void k_row_pro
     __shared__ cf smem_tw[FftTw<NX>::LDS_CNT * (EX ? 2 : 1)];
     FftTw<NX> tw;
     __shared__ cf smem_tail[7 * C::T * (EX ? 2 : 1)];
+    // (Filling the tables under the first row's loads instead of in front of them — `if (!tables) tw.load(...)` after the loads — was
+    // measured twice: round 3 in the bench, round 4 alternating in tools/kbench, best of 7: 23.2-24.5 us as here, 24.1-25.1 us with
+    // the fill deferred.  The fill is short; the branch and the later barrier cost more than the overlap returns.)
     tw.template load<EX>(a.twiddle, tid, smem_tw, smem_tail);
     tw.sq = a.sq;
     const int ntiles = a.B * a.NY / C::TILE;

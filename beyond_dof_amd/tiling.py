@@ -50,8 +50,8 @@ class TiledPropagator(object):
         outer `taper` pixels (default halo / 2) are ramped to zero so that the tile's periodic boundary has no jump.
         slices_per_exchange: slices between two stitches; default safety * (halo - taper) / (lambda dz / (2 dx^2)), or, with
         the long-range correction, the band edge's phase-winding length 4 dx^2 / (lambda dz) if that is shorter.
-        long_range: True / False / 'auto' (on for the forward model of stacks deeper than one default stitch range; the
-        gradient sweep does not carry it yet).  precision: 'float32' / 'float64' / 'auto' (float64 beyond 384 slices)."""
+        long_range: True / False / 'auto' (on for stacks deeper than one default stitch range, forward model and gradient).
+        precision: 'float32' / 'float64' / 'auto' (float64 tiles beyond 2048 slices; forward model only)."""
         self.fy, self.fx = int(field_shape[0]), int(field_shape[1])
         self.n_slice, self.tile, self.halo = int(n_slice), int(tile), int(halo)
         if 2 * self.halo >= self.tile:
@@ -65,11 +65,9 @@ class TiledPropagator(object):
         geometric = max(1, int(safety * (self.halo - self.taper) / self.spread_px)) if self.halo > 0 else self.n_slice
         self.with_grad = bool(with_grad)
         if long_range == 'auto':
-            long_range = (not self.with_grad) and self.halo > 0 and self.n_slice > geometric and (comm is None or comm.size == 1) and \
+            long_range = self.halo > 0 and self.n_slice > geometric and (comm is None or comm.size == 1) and \
                 (slices_per_exchange is None or slices_per_exchange < self.n_slice)
         self.long_range = bool(long_range)
-        if self.long_range and self.with_grad:
-            raise ValueError('the long-range correction is implemented for the forward model (with_grad=False)')
         if self.long_range and (comm is not None and comm.size > 1):
             raise ValueError('the long-range correction runs on one rank (it transforms the whole field)')
         if precision == 'auto':
@@ -127,6 +125,7 @@ class TiledPropagator(object):
             # tiles that see vacuum whatever the object: window origins beyond the volume (the fused free-space step)
             self.vac = DeviceBuffer.from_host(self.ctx, np.stack([np.zeros(self.n_tiles, dtype=np.int32),
                                                                   np.full(self.n_tiles, 1 << 28, dtype=np.int32), self.y0]))
+            self._conj_tables = {}
 
     def _free_table(self, power, shape, ctype, fused_layout=False):
         """The `power`-th power of one slice step's transfer function on a (ny, nx) grid of this field, un-shifted, 1 / (NX NY)
@@ -268,6 +267,8 @@ class TiledPropagator(object):
         float [x][y]; returns (loss, device buffer of the volume gradient in the object's row layout)."""
         if not self.with_grad:
             raise RuntimeError('TiledPropagator(with_grad=True) needed')
+        if self.long_range:
+            return self._loss_and_grad_long_range(meas_dev)
         import ctypes
         lib, h, p = self.lib, self.h, self.idx.ptr
         a, xo, yo = p, p + 4 * self.n_tiles, p + 8 * self.n_tiles
@@ -291,6 +292,66 @@ class TiledPropagator(object):
             self.ctx.check(lib.bdof_tiles_gather_adjoint(h, self.tiles_out.ptr, self.field.ptr, self.fx, self.fy, B, T, T, xo, yo, self.taper))
             self._sum_over_ranks(self.field)
         self._sum_over_ranks(gvol)
+        loss = ctypes.c_double(0)
+        self.ctx.check(lib.bdof_get_loss(h, ctypes.byref(loss)))
+        return loss.value, gvol
+
+    def _conj_table(self, power):
+        """conj(H^power) for the tiles, in the fused kernels' layout: the adjoint of their free-space step over a range."""
+        if power not in self._conj_tables:
+            self._conj_tables[power] = DeviceBuffer.from_host(
+                self.ctx, np.conj(self._free_table(power, (self.tile, self.tile), np.complex128, fused_layout=True)).astype(np.complex64))
+        return self._conj_tables[power]
+
+    def _loss_and_grad_long_range(self, meas_dev):
+        """loss_and_grad_device through the CORRECTED tiled model  psi_out = W psi_in + Stitch(T Cut psi_in - F Cut psi_in)  per range
+        (W: the field's free-space step over the range, in double; Cut: tapered periodic cut-out; T: the tiles' multislice
+        sweep; F: their free-space step; Stitch: cores back).  Adjoint, last range first:
+            G_in = W^H G_out + Cut^H ( T^H - F^H ) Stitch^H G_out ,
+        T^H by bdof_adjoint_range (which also leaves the object-gradient rows), F^H the fused free-space step with conj(H^n),
+        W^H bdof_fields_free_step(conj_h = 1); the field-level adjoint stays in complex128 like the field."""
+        import ctypes
+        lib, h, p = self.lib, self.h, self.idx.ptr
+        a, xo, yo = p, p + 4 * self.n_tiles, p + 8 * self.n_tiles
+        v = self.vac.ptr
+        va, vx, vy = v, v + 4 * self.n_tiles, v + 8 * self.n_tiles
+        T, B, npx = self.tile, self.n_tiles, self.fx * self.fy
+        segs = self.segments()
+        if getattr(self, '_ends', None) is None or len(self._ends) != len(segs):
+            self._ends = [DeviceBuffer(self.ctx, B * T * T * 8, np.complex64, (B, T, T)) for _ in segs]
+            self._grot = DeviceBuffer(self.ctx, B * max(nz for _, nz in segs) * T * T * 8, np.float32)
+            self._gvol = DeviceBuffer.zeros(self.ctx, self.eng._keep['obj'].shape, np.float32)
+        f, w = self.field64, self.whole64
+        self.ctx.check(lib.bdof_c_convert(h, f.ptr, self.field.ptr, npx, 1))
+        for (z0, nz), end in zip(segs, self._ends):
+            t_tab, f_tab = self._tables(nz)                   # tf_all: a step after every slice
+            self.ctx.check(lib.bdof_tiles_gather_mixed(h, f.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.taper))
+            self.ctx.check(lib.bdof_memcpy_d2d(h, w.ptr, f.ptr, npx * 16))
+            self.ctx.check(lib.bdof_fields_free_step(h, w.ptr, 1, self.fx, self.fy, f_tab.ptr, 0, 1))
+            self.ctx.check(lib.bdof_forward_range_h(h, B, va, vx, vy, z0, 1, self.tiles_in.ptr, self.tiles_free.ptr, 1, t_tab.ptr))
+            self.ctx.check(lib.bdof_forward_range(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, end.ptr, 1))
+            self.ctx.check(lib.bdof_tiles_scatter_diff64(h, end.ptr, self.tiles_free.ptr, w.ptr, self.fx, self.fy, B, T, T, xo, yo,
+                                                         self.halo, self.halo, 1))
+            f, w = w, f
+        self.ctx.check(lib.bdof_c_convert(h, self.field.ptr, f.ptr, npx, 0))
+        self.ctx.check(lib.bdof_field_loss_seed(h, self.field.ptr, _lib._ptr(meas_dev), self.fx, self.fy))
+        g, w = f, w                                            # the field-level adjoint takes over the two float64 buffers
+        self.ctx.check(lib.bdof_c_convert(h, g.ptr, self.field.ptr, npx, 1))
+        gvol = self._gvol
+        self.ctx.check(lib.bdof_memset(h, gvol.ptr, 0, gvol.nbytes))
+        for (z0, nz), end in reversed(list(zip(segs, self._ends))):
+            _, f_tab = self._tables(nz)
+            self.ctx.check(lib.bdof_tiles_scatter_adjoint_mixed(h, g.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.halo, self.halo))
+            # F^H Stitch^H G: vacuum, conj(H^n)
+            self.ctx.check(lib.bdof_forward_range_h(h, B, va, vx, vy, z0, 1, self.tiles_in.ptr, self.tiles_free.ptr, 1, self._conj_table(nz).ptr))
+            # T^H Stitch^H G, and the object gradient of the range
+            self.ctx.check(lib.bdof_adjoint_range(h, B, a, xo, yo, z0, nz, end.ptr, self.tiles_in.ptr, self.tiles_out.ptr, self._grot.ptr))
+            self.ctx.check(lib.bdof_tiles_grad_add(h, self._grot.ptr, gvol.ptr, B, T, T, xo, yo, z0, nz))
+            # W^H G in place, then += Cut^H (T^H - F^H) ...
+            self.ctx.check(lib.bdof_fields_free_step(h, g.ptr, 1, self.fx, self.fy, f_tab.ptr, 1, 1))
+            self.ctx.check(lib.bdof_tiles_gather_adjoint_diff64(h, self.tiles_out.ptr, self.tiles_free.ptr, g.ptr, self.fx, self.fy, B, T, T, xo, yo,
+                                                                self.taper, 1))
+        self.ctx.check(lib.bdof_c_convert(h, self.field.ptr, g.ptr, npx, 0))            # G(probe), as the plain path leaves it
         loss = ctypes.c_double(0)
         self.ctx.check(lib.bdof_get_loss(h, ctypes.byref(loss)))
         return loss.value, gvol

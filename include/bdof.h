@@ -206,6 +206,13 @@ int bdof_tiles_gather_mixed(bdof_ctx* ctx, const void* field64, int FX, int FY, 
                             const int* y0, int taper);
 int bdof_tiles_scatter_diff64(bdof_ctx* ctx, const void* tiles_a, const void* tiles_b, void* field64, int FX, int FY, int B, int TX, int TY,
                               const int* x0, const int* y0, int halo_x, int halo_y, int accumulate);
+/* Their adjoints, for the gradient through the corrected tiled model: bdof_tiles_scatter_adjoint_mixed (complex64 tiles = the
+ * complex128 field on every tile's core, zero elsewhere) and bdof_tiles_gather_adjoint_diff64 (field64 (+)= the tapered, periodic
+ * scatter-add of tiles_a - tiles_b; deterministic gather form). */
+int bdof_tiles_scatter_adjoint_mixed(bdof_ctx* ctx, const void* field64, int FX, int FY, void* tiles, int B, int TX, int TY, const int* x0,
+                                     const int* y0, int halo_x, int halo_y);
+int bdof_tiles_gather_adjoint_diff64(bdof_ctx* ctx, const void* tiles_a, const void* tiles_b, void* field64, int FX, int FY, int B, int TX,
+                                     int TY, const int* x0, const int* y0, int taper, int accumulate);
 int bdof_forward_range_f64(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
                            void* fields, const void* h, double k, int prop_last);
 

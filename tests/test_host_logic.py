@@ -164,3 +164,47 @@ def test_point_probe_is_refused_by_both_entry_points(tmp_path):
     with pytest.raises(ValueError, match='point'):
         reconstruct_fullfield('data.h5', save_path=str(tmp_path), n_epochs=1, minibatch_size=1, probe_type='point',
                               initial_guess=[np.zeros((8, 8, 8)), np.zeros((8, 8, 8))])
+
+
+def test_detector_kernel_choice_and_impulse_response_table(golden_dir):
+    """SURVEY §8 a3 on the host: 'TF' / 'IR' / 'auto' for the detector step (cnn_propagator/np_funcs.py:51-61: the criterion is
+    computed there and then overridden with 'TF'); the device table of the 'IR' choice is get_kernel_ir (golden vector G8) in
+    the layout of every other table; the oracle's 'IR' branch multiplies by that kernel."""
+    import os
+    import pytest
+    from oracle import bdof_oracle as orc
+    assert util.detector_kernel_kind('TF', 1e3, 0.248, [1., 1., 1.], (64, 64)) == 'TF'
+    assert util.detector_kernel_kind('IR', 1.0, 0.248, [1., 1., 1.], (64, 64)) == 'IR'
+    assert util.detector_kernel_kind('auto', 1e3, 0.248, [1., 1., 1.], (64, 64)) == 'IR'      # lambda z / L = 3.9 nm > 1 nm voxels
+    assert util.detector_kernel_kind('auto', 10., 0.248, [1., 1., 1.], (64, 64)) == 'TF'
+    with pytest.raises(ValueError):
+        util.detector_kernel_kind('exact', 1e3, 0.248, [1., 1., 1.], (64, 64))
+    g = np.load(os.path.join(golden_dir, 'g8_kernel_ir_upsample.npz'))
+    t = util.device_transfer_function(1000., 0.248, [1., 1., 1.], 32, 32, kernel='IR', dtype=np.complex128)
+    np.testing.assert_allclose(t, np.fft.ifftshift(g['Hir_32_32_1000']) / 1024., rtol=0, atol=1e-12 * np.abs(g['Hir_32_32_1000']).max())
+    dc = util.transfer_function_dc(1000., 0.248, [1., 1., 1.], 32, 32, kernel='IR')
+    assert abs(complex(*dc) - np.fft.ifftshift(g['Hir_32_32_1000'])[0, 0]) <= 1e-12 * abs(complex(*dc))
+    with pytest.raises(ValueError):
+        util.device_transfer_function(1000., 0.248, [1., 1., 1.], 32, 32, kernel='IR', field_shape=(64, 64))
+    # oracle: the IR branch is the same propagation with the other multiplier
+    rng = np.random.default_rng(0)
+    d = rng.uniform(0, 1e-5, size=(1, 16, 16, 3))
+    one, zero = np.ones((16, 16)), np.zeros((16, 16))
+    none, _ = orc.multislice_propagate_batch_numpy(d, 0.1 * d, one, zero, 5000., 1e-7, None, d.shape)
+    ir, _ = orc.multislice_propagate_batch_numpy(d, 0.1 * d, one, zero, 5000., 1e-7, 1e-4, d.shape, detector_kernel='IR')
+    want = orc._propagate(none, orc.get_kernel_ir(1000., 0.248, np.array([1., 1., 1.]), (16, 16, 3)))
+    np.testing.assert_allclose(ir, want, rtol=0, atol=1e-13)
+
+
+def test_summary_columns_and_build_id(tmp_path):
+    """summary.txt keeps the reference's '{:<20}{}' layout (cnn_propagator/misc.py:61-77) and still separates a name that fills the
+    column from its value; _lib.build_id names what a measurement belongs to."""
+    from beyond_dof_amd.misc import create_summary
+    from beyond_dof_amd import _lib
+    create_summary(str(tmp_path), {'obj_size': (8, 8, 8), 'adjoint_precision': 'first-step', 'adjoint_precision_effective': 'float32'}, preset='ptycho')
+    rows = dict(line.split(None, 1) for line in open(str(tmp_path / 'summary.txt')).read().splitlines() if len(line.split(None, 1)) == 2)
+    assert rows['obj_size'].strip() == '(8, 8, 8)' and rows['adjoint_precision'].strip() == 'first-step'
+    assert rows['adjoint_precision_effective'].strip() == 'float32'
+    assert open(str(tmp_path / 'summary.txt')).read().splitlines()[0] == '{:<20}{}'.format('obj_size', '(8, 8, 8)')
+    b = _lib.build_id()
+    assert set(b) == {'source_sha256', 'flags', 'lib_sha256'} and len(b['source_sha256']) == 16

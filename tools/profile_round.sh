@@ -27,7 +27,7 @@ if [ -z "$quick" ]; then
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --recompute > $out/bench_recompute.json 2> $out/bench_recompute.err; echo "recompute rc $?"; cp $out/bench_recompute.json profiles/${tag}_bench_tape_free.json
   python bench.py --steps 10 --warmup 2 --no-cpu-baseline --size 256 --angles-per-gpu 50 --n-theta 50 > $out/bench_cfg2.json 2> $out/bench_cfg2.err; echo "cfg2 rc $?"; cp $out/bench_cfg2.json profiles/${tag}_bench_cfg2.json
   python tools/bench_ptycho.py 72 20 5 > $out/ptycho_cfg5_bench.txt 2>&1; tail -n 1 $out/ptycho_cfg5_bench.txt; cp $out/ptycho_cfg5_bench.txt profiles/${tag}_ptycho_cfg5_bench.txt
-  python tools/bench_cfg4.py 4096 1024 $out/cfg4.json > $out/cfg4.txt 2>&1; tail -n 8 $out/cfg4.txt; cp $out/cfg4.json profiles/${tag}_cfg4_tiled.json
+  CFG4_GRAD=1 python tools/bench_cfg4.py 4096 1024 $out/cfg4.json > $out/cfg4.txt 2>&1; tail -n 10 $out/cfg4.txt; cp $out/cfg4.json profiles/${tag}_cfg4_tiled.json
 fi
 python - <<PY
 import json, glob, os
