@@ -287,7 +287,7 @@ def roofline_pass(solver, batch, hyper, n, mb, S, conv=False):
     eng.set_streams(-1)
     px = mb * n * n
     launches_per_step = {'row_fwd': S, 'col_prop': 2 * S, 'row_bwd': S, 'rot_adjoint': 1}
-    # the real-space propagator has one kernel per slice and direction (k_conv: 24 B/px forward, 40 B/px backward, DESIGN §5),
+    # the real-space propagator has one kernel per slice and direction (k_conv: 24 B/px forward, 40 B/px backward, DESIGN §3),
     # timed under the same two classes; no transfer-function launches
     byte_model = {k: v for k, v in BYTES_PER_PX.items() if not (conv and k == 'col_prop')}
     per_class = {}
@@ -458,7 +458,7 @@ def main():
                           'propagator': args.propagator, 'rotation': args.rotation,
                           'adjoint': 'recompute (tape-free)' if args.recompute else 'tape',
                           'transform_constants': 'one float32 table' if os.environ.get('BDOF_TW_DITHER') in ('0', '1') else
-                          'dithered over the slices, {} copies (DESIGN 4)'.format(os.environ.get('BDOF_TW_DITHER', '64')),
+                          'dithered over the slices, {} copies (DESIGN §5)'.format(os.environ.get('BDOF_TW_DITHER', '64')),
                           'transfer_function': 'one float32 table' if os.environ.get('BDOF_H_DITHER') in ('0', '1') else
                           'dithered over the slices, {} copies'.format(os.environ.get('BDOF_H_DITHER', '64')),
                           'build': _lib.build_id(),

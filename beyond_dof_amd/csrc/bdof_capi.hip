@@ -996,7 +996,7 @@ int bdof_sync(bdof_ctx* c) {
 // exp(-2 pi i j / N) in float32, rounded so that the MODULUS is as close to one as float32 allows: among the roundings
 // of (cos, sin) up or down (each candidate within one ulp of the true value) the pair with the smallest | |w|^2 - 1 |.
 // Plain round-to-nearest leaves every twiddle with a modulus error of +-3e-8; the factors do not average out along the
-// paths of a transform, a chain of hundreds of transforms then drifts in energy (DESIGN §4).
+// paths of a transform, a chain of hundreds of transforms then drifts in energy (DESIGN §5).
 static cf unit_twiddle(double c, double s) {
     const float c0 = (float)c, s0 = (float)s;
     const float cc[3] = {c0, std::nextafterf(c0, 2.f), std::nextafterf(c0, -2.f)};

@@ -79,7 +79,7 @@ template <int SIGN> __device__ __forceinline__ void dft4(cf& a0, cf& a1, cf& a2,
 
 // Irrational butterfly constants.  float32(sqrt(1/2)) is 1.7e-8 short (float32(sqrt(3)/2) 1.8e-8): every product with it
 // shrinks the amplitude by that much, the defects add up along a chain of transforms and a multislice stack drifts in
-// energy (-1.25e-7 per slice at 72^2, DESIGN §4).  The remedies:
+// energy (-1.25e-7 per slice at 72^2, DESIGN §5).  The remedies:
 //   sq != nullptr (the per-slice kernels of the streaming engine): the constant of THIS launch comes from the host, sq[0] for the
 //      transforms instantiated with ROUND 1 and sq[1] for those with ROUND 2 — the host walks the two neighbouring float32 values
 //      over the slices so that their mean is sqrt(1/2) (dithered constants, above), at no cost in instructions;

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_g_bwd(GBwdArgs a) {
 // The adjoint field G is as large as the wave itself and has no known part to split off (it is driven by the data's noise), so
 // its float32 transform chain sets a floor of ~3e-6 under the gradient (64 slices) — and Adam's first step of every epoch,
 // lr g / (|g| + 1e-8), turns an absolute error of 1e-8 at a voxel where the gradient changes sign into a fraction of a whole
-// step (DESIGN §4).  With this option the seed, the adjoint transforms (rocFFT double precision), the transfer function and
+// step (DESIGN §5).  With this option the seed, the adjoint transforms (rocFFT double precision), the transfer function and
 // the products conj(phi) G are float64; the forward sweep (scattered wave on its carrier) and the tape stay float32.
 struct GBwd64Args {
     double2* g;          // G(phi_z) in, G(psi_z) out

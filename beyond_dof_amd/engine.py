@@ -31,7 +31,7 @@ class MultisliceEngine(object):
         or the batch is large; every other size on the generic engine (rocFFT).  engine='generic' (= force_generic=True),
         'streaming' (never resident) or 'resident' (resident for every batch size) pin the choice for cross-checks.
         adjoint64=True (env BDOF_ADJOINT64=1): the adjoint sweep in float64 (bdof_configure flag 64; generic engine) — the
-        accuracy option for reconstructions that must follow the reference's float64 loop voxel by voxel (DESIGN §4)."""
+        accuracy option for reconstructions that must follow the reference's float64 loop voxel by voxel (DESIGN §5)."""
         if engine not in ('auto', 'generic', 'streaming', 'resident'):
             raise ValueError('engine must be auto, generic, streaming or resident')
         force_generic = force_generic or engine == 'generic'

@@ -72,7 +72,7 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
     # the reference's own choice in this entry point, with `kernel_size` taps per axis
     propagator = kwargs.get('propagator', 'fft')
     # 'float64': the adjoint sweep in float64 (bdof_configure flag 64, transfer-function propagator only) — follows the
-    # reference's float64 loop voxel by voxel where float32's 3e-6 on the gradient is too coarse (DESIGN §4)
+    # reference's float64 loop voxel by voxel where float32's 3e-6 on the gradient is too coarse (DESIGN §5)
     adjoint_precision = kwargs.get('adjoint_precision', 'float32')
     if adjoint_precision not in ('float32', 'float64'):
         raise ValueError("adjoint_precision must be 'float32' or 'float64'")

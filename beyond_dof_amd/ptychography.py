@@ -77,7 +77,7 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
     # 'fft' (default): transfer-function propagator of np_funcs.py; 'conv': truncated real-space kernel of propagation.py,
     # the reference's own choice in this entry point, with `kernel_size` taps per axis
     propagator = kwargs.get('propagator', 'fft')
-    # 'float64': the adjoint sweep in float64 (bdof_configure flag 64, transfer-function propagator only; DESIGN §4);
+    # 'float64': the adjoint sweep in float64 (bdof_configure flag 64, transfer-function propagator only; DESIGN §5);
     # 'first-step': in float64 for the first minibatch of every epoch only — Adam's first step after its per-epoch restart is
     # lr g / (|g| + 1e-8), the one step in which the float32 rounding of the gradient reaches the volume
     # (the default with the transfer-function propagator: reconstructed delta within 2.1e-6 of the reference's float64 loop on golden

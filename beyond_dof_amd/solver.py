@@ -525,7 +525,7 @@ class PtychoSolver(_VolumeSolver):
         self.eng.set_probe(probe_real, probe_imag)
         # adjoint64='first': a second engine with the float64 adjoint sweep for the FIRST minibatch of every epoch — Adam's first
         # step after a restart is lr g / (|g| + 1e-8), the only one in which a 1e-8 error of the gradient moves a voxel by a
-        # fraction of a whole step (DESIGN §4); every later step runs on the fast engine
+        # fraction of a whole step (DESIGN §5); every later step runs on the fast engine
         self.eng64 = None
         if adjoint64 == 'first':
             self.eng64 = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream, adjoint64=True)

@@ -42,7 +42,7 @@ int bdof_device_count(void);
 /* Host only (no device is touched): the twiddle tables bdof_configure uploads for transforms of length N, as D copies of
  * [N hi (re, im)][N lo (re, im)] float32 — exp(-2 pi i j / N) with lo = the rounding error of hi.  D >= 2: the dithered copies
  * (entry j of copy d is the float32 below or above the float64 value, the upper one in the fraction of the copies that makes the
- * mean over the copies equal the float64 value to ulp / D; DESIGN §4 "Dithered transform constants"); D = 0 or 1: one copy,
+ * mean over the copies equal the float64 value to ulp / D; DESIGN §5 "Dithered transform constants"); D = 0 or 1: one copy,
  * rounded to nearest with the modulus kept closest to one.  out: 4 N max(D, 1) floats.  Exposed for the tests. */
 int bdof_twiddle_tables(int N, int D, float* out);
 int bdof_device_pci_bus_id(int device, char* out, int len);      /* "0000:c1:00.0": which physical GPU a rank really got */
@@ -66,7 +66,7 @@ int bdof_timer_elapsed(bdof_ctx* ctx, int slot_a, int slot_b, double* ms);
  * float32 — what autograd's float64 tape gives the reference (cnn_propagator/fullfield.py:329, ptychography.py:248);
  * follow bdof_set_physics with bdof_set_physics_f64.
  * Environment read here: BDOF_TW_DITHER=D — number of dithered copies of the transform constants the per-slice kernels walk
- * (default 64; 0: one plain float32 table, round 2's behaviour; DESIGN §4 "Dithered transform constants").
+ * (default 64; 0: one plain float32 table, round 2's behaviour; DESIGN §5 "Dithered transform constants").
  * Replaces the per-call allocations of multislice_propagate_batch_numpy
  * (cnn_propagator/np_funcs.py:20,43) and of autograd's tape (cnn_propagator/fullfield.py:329). */
 int bdof_configure(bdof_ctx* ctx, int NY, int NX, int S, int Bmax, int with_grad);

@@ -99,7 +99,7 @@ def test_no_spill_under_restricted_exec():
 
 @pytest.mark.parametrize('n', [64, 512, 1024])
 def test_dithered_twiddle_tables(built_lib, n):
-    """The transform constants of the per-slice kernels (DESIGN §4 "Dithered transform constants"; host code, no device): in each
+    """The transform constants of the per-slice kernels (DESIGN §5 "Dithered transform constants"; host code, no device): in each
     of the D copies every component is one of the two float32 neighbours of the float64 value, hi + lo of every copy is that value,
     and the mean over ANY run of L consecutive copies (the slices a wave passes through) is the value to ulp / L — where one
     round-to-nearest table is off by up to ulp / 2 in every slice."""

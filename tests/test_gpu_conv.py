@@ -196,7 +196,7 @@ def test_reconstruct_ptychography_vs_the_reference_loop(engine_mod, tmp_path, mo
     # float32 convolutions and |d| - m was taken in float32.  Round 3 gave the real-space path a carrier FIELD (the probe carried
     # through empty space by the padded convolution in float64, bdof_set_conv_probe_stack) and the float64 residual at the
     # detector: first-minibatch gradient 1.8e-4 -> 4.9e-6, delta after the eight steps 1.6e-5, beta 3.1e-6, no voxel more than
-    # 0.009 of a step away — where the transfer-function path stands with float32 adjoint arithmetic (G17: 1.7e-5, DESIGN §4).
+    # 0.009 of a step away — where the transfer-function path stands with float32 adjoint arithmetic (G17: 1.7e-5, DESIGN §5).
     assert stats[0] <= 0.05 and stats[1] <= 3e-5 and stats[3] <= 1e-5 and stats[4] == 0.0, stats
 
 

@@ -316,7 +316,7 @@ def test_reconstruct_fullfield_vs_the_reference_loop_at_cfg2_size(tmp_path, monk
     print('G18 stats' if not noise else 'G19 stats', stats)
     # measured (round 3, dithered transform constants — the default): G18 (noise-free data) delta 6.6e-6, beta 4.3e-5; G19 (2 % noise)
     # delta 7.4e-6, beta 2.7e-5 — both inside the north star's 1e-5 (hi + lo tables in every transform, -DBDOF_EXACT_TRANSFORMS:
-    # 5.8e-6 / 7.0e-6; one plain table, BDOF_TW_DITHER=0: 2.1e-5 / 1.68e-5; DESIGN §4)
+    # 5.8e-6 / 7.0e-6; one plain table, BDOF_TW_DITHER=0: 2.1e-5 / 1.68e-5; DESIGN §5)
     assert stats[0] <= 0.05 and stats[1] <= 1e-5 and stats[3] <= 1e-4, stats
 
 

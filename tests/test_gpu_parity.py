@@ -409,7 +409,7 @@ def test_cfg3_full_depth_vs_oracle(engine_mod, monkeypatch):
     """BASELINE's headline wavefield at its full size: one 512 x 512 wavefield through all 512 slices (plane probe,
     charcoal-like object of bench.py, near-field detector) against the float64 oracle — the oracle needs ~20 s for it.
     Carrier splitting keeps the float32 forward within 1.2e-7 of the reference in intensity (north star: 1e-5); the dithered
-    transform constants (DESIGN §4) keep the gradient within 6.0e-6 where one fixed float32 table per transform leaves
+    transform constants (DESIGN §5) keep the gradient within 6.0e-6 where one fixed float32 table per transform leaves
     1.61e-5 (tools/gpu_check_cfg3_depth.py) — both are measured here, on the same oracle."""
     from scipy.ndimage import uniform_filter
     n = S = 512

@@ -86,7 +86,7 @@ def test_plane_probe_far_field_other_engines():
 def test_reconstructed_delta_after_three_adam_steps(fp, n_theta, mb, bound_d, bound_step):
     """Reconstructed delta against the oracle-driven loop (cnn_propagator/fullfield.py:345-362) after three Adam steps with
     the regulariser, mask and clip.  Real-space detectors: <= 2e-5 relative L2 (measured 1.4-1.6e-5), no voxel more than a
-    tenth of a step away.  What separates that from the north star's 1e-5 (DESIGN §4): Adam's first steps are
+    tenth of a step away.  What separates that from the north star's 1e-5 (DESIGN §5): Adam's first steps are
     lr * g / (|g| + 1e-8), so at voxels whose gradient is within float32 round-off of zero (absolute error 2e-6 of the
     typical |g|) the step differs by up to lr * dg / 1e-8.
     Plane probe + far field: the detector is one bright bin that does not see phase to first order; the delta-gradient is

@@ -55,7 +55,7 @@ def test_ptycho_forward_and_gradient_vs_oracle(psz, force_resident, monkeypatch)
     w = s.forward(i_theta, sel)
     # 96 slices, localised probe (no carrier to split off): float32 round-off of the 192 transforms accumulates to
     # 4e-6 (60^2) ... 1.0e-5 (72^2 on the rocFFT engine) in the intensities (tools/gpu_check_pty_err.py) — it was 1.4e-5
-    # before the systematic energy drift of float32 transform chains was taken out (DESIGN §4); the bound stays at 1.2e-5,
+    # before the systematic energy drift of float32 transform chains was taken out (DESIGN §5); the bound stays at 1.2e-5,
     # above the 1e-5 of the short-stack comparisons in test_gpu_parity.py / test_gpu_resident.py.
     on_resident = s.eng.probe_stack            # carrier field of the probe (bdof_set_probe_stack): every engine carries it
     assert on_resident
@@ -148,7 +148,7 @@ def test_reconstruct_ptychography_vs_the_reference_loop_fft(tmp_path, monkeypatc
 
     What separates a float32 device from the reference's float64 loop here is Adam's FIRST step of every epoch,
     lr g / (|g| + 1e-8): at the ~100 voxels (of 262144) where the gradient changes sign within 1e-7 of zero an absolute error of
-    1e-8 — 1e-6 of the gradient's rms — is a fraction of a whole step (tools/gpu_diag_g17_steps.py; DESIGN §4).  Round 3 took the
+    1e-8 — 1e-6 of the gradient's rms — is a fraction of a whole step (tools/gpu_diag_g17_steps.py; DESIGN §5).  Round 3 took the
     largest term out (the residual |d| - m is formed in float64 against the float64 carrier field: 4.9e-5 -> 1.7e-5); what is
     left is the float32 rounding of the adjoint sweep's transforms (3e-6 on the gradient), which has no known part to split
     off.  adjoint_precision='float64' runs that sweep in float64 and lands within 1.6e-6 — inside the north star's 1e-5."""
