@@ -81,6 +81,29 @@ int main(int argc, char** argv) {
         CK(hipFree(ca)); CK(hipFree(cb));
     }
     const int tiles = B * N / RowCfg<N>::TILE;
+    if (argc > 3) {      // grid sweep: how many workgroups should share the launch's tiles (alternated, best of 5)
+        RowFwdArgs fa{in, probe, out, tape, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};
+        RowPropArgs pa{in, out, h, B, N, 1.f, 0, tw};
+        RowBwdArgs ba{in, tape, out, grot, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};
+        fa.sq[0] = fa.sq[1] = pa.sq[0] = pa.sq[1] = ba.sq[0] = ba.sq[1] = 0.70710678f;
+        const int grids[] = {400, 448, 512, 640, 800};
+        float best[3][5];
+        for (auto& r : best) for (float& v : r) v = 1e9f;
+        for (int rep = 0; rep < 5; ++rep)
+            for (int gi = 0; gi < 5; ++gi) {
+                const int g = grids[gi];
+                best[0][gi] = std::min(best[0][gi], time_it([&] { hipLaunchKernelGGL((k_row_fwd<N, false, true>), dim3(g), dim3(BDOF_THREADS), 0, 0, fa); }, iters));
+                best[1][gi] = std::min(best[1][gi], time_it([&] { hipLaunchKernelGGL((k_row_prop<N>), dim3(g), dim3(BDOF_THREADS), 0, 0, pa); }, iters));
+                best[2][gi] = std::min(best[2][gi], time_it([&] { hipLaunchKernelGGL((k_row_bwd<N, 1>), dim3(g), dim3(BDOF_THREADS), 0, 0, ba); }, iters));
+            }
+        const char* nm[3] = {"row_fwd ", "row_prop", "row_bwd "};
+        for (int k = 0; k < 3; ++k) {
+            printf("%s (%d tiles)", nm[k], tiles);
+            for (int gi = 0; gi < 5; ++gi) printf("  grid %d: %6.2f us", grids[gi], best[k][gi] * 1e3);
+            printf("\n");
+        }
+        return 0;
+    }
     for (int per_cu : {2, 3, 4}) {
         const int grid = balanced(tiles, ncu * per_cu);
         printf("-- %d WG/CU cap, grid %d (tiles %d)\n", per_cu, grid, tiles);
