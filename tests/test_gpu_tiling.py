@@ -176,6 +176,33 @@ def test_tiled_gradient_with_the_long_range_correction_vs_autograd():
     assert errs[True] < errs[False]
 
 
+@pytest.mark.parametrize('precision', ['float32', 'float64'])
+def test_long_range_correction_with_a_last_range_of_one_slice(precision):
+    """Variant numpy_skip_last with a last stitch range of ONE slice (no transfer-function step in it: nothing to correct, the
+    cores are written straight into the float64 field), non-square field, both tile precisions: the corrected exit wave against
+    the whole-field oracle, and closer to it than the uncorrected one."""
+    from beyond_dof_amd.tiling import TiledPropagator
+    fy, fx, S, tile, halo, seg = 128, 192, 9, 64, 16, 4
+    rng = np.random.default_rng(9)
+    delta = np.zeros((fy, fx, S))
+    delta[32:96, 48:144, :] = rng.uniform(0, 5e-5, size=(64, 96, S))
+    beta = 0.1 * delta
+    yy, xx = np.mgrid[:fy, :fx]
+    probe = np.exp(-((yy - fy / 2.) ** 2 / (2 * (fy / 6.) ** 2) + (xx - fx / 2.) ** 2 / (2 * (fx / 6.) ** 2)))
+    zero = np.zeros_like(probe)
+    ref, _ = orc.multislice_propagate_batch_numpy(delta[None], beta[None], probe, zero, 5000., 1e-7, None, (1,) + delta.shape, return_probe_array=False)
+    err = {}
+    for lr in (False, True):
+        tp = TiledPropagator((fy, fx), S, 5000., 1e-7, tile=tile, halo=halo, slices_per_exchange=seg, long_range=lr, precision=precision)
+        assert tp.segments() == [(0, 4), (4, 4), (8, 1)]
+        tp.set_object(delta, beta)
+        out = tp.forward(probe, zero)
+        assert out.dtype == (np.complex128 if precision == 'float64' else np.complex64)
+        err[lr] = rel(out, ref[0])
+    print('last range of one slice,', precision, ': uncorrected', err[False], 'corrected', err[True])
+    assert err[True] <= 5e-6 and err[True] < 0.5 * err[False], err
+
+
 def test_tiled_gradient_slab_object():
     """The same slab in every slice: the gradient rows of all slices and all tiles accumulate into one (FY, FX) pair of maps."""
     from beyond_dof_amd.tiling import TiledPropagator
