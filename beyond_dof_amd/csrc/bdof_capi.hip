@@ -15,6 +15,7 @@
 #include "bdof_conv2.h"
 #include "bdof_generic.h"
 #include "bdof_field.h"
+#include "bdof_conv64.h"
 #include "bdof_resident.h"
 #include "bdof_comm.h"
 #include <rocfft/rocfft.h>
@@ -51,6 +52,12 @@ struct bdof_ctx {
     int tw_dither = 0;
     unsigned tw_tick = 0;          // the slice of the last A / A' launch: the transfer-function launch that follows takes the same copy
     cf *hs = nullptr, *hdet = nullptr, *hcomb = nullptr, *probe = nullptr;
+    // float64 real-space propagator (bdof_set_conv_f64 / bdof_loss_grad_conv_f64, bdof_conv64.h)
+    double2 *c64_probe = nullptr, *c64_khat = nullptr, *c64_psi = nullptr, *c64_q = nullptr, *c64_big = nullptr, *c64_tape = nullptr,
+            *c64_scal = nullptr, *c64_part = nullptr;
+    int c64_ks = 0, c64_B = 0;
+    std::complex<double> c64_ksum{1.0, 0.0};
+    double c64_k = 0.0;
     cf* hsT_d = nullptr;           // the same copies in the LDS-resident kernel's [kx][ky] order
     cf* hs_d = nullptr;            // bdof_set_transfer_f64: hs_copies dithered float32 copies of the slice step's table (bdof_field.h)
     int hs_copies = 0;
@@ -947,6 +954,11 @@ static void free_workspace(bdof_ctx* c) {
     free_generic(c);
     if (c->hs_d) { (void)hipFree(c->hs_d); c->hs_d = nullptr; c->hs_copies = 0; }
     if (c->hsT_d) { (void)hipFree(c->hsT_d); c->hsT_d = nullptr; }
+    for (double2** q : {&c->c64_probe, &c->c64_khat, &c->c64_psi, &c->c64_q, &c->c64_big, &c->c64_tape, &c->c64_scal, &c->c64_part}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    c->c64_ks = c->c64_B = 0;
     void* ptrs[] = {c->cstack, c->cdet64, c->pdet64, c->pdetT64, c->pstack, c->pdet, c->pdetT, c->hsT, c->hdetT, c->twR, c->res_carrier, c->bufC, c->conv_scal, c->taps_dev, c->twY, c->twX, c->hs, c->hdet, c->hcomb, c->probe, c->bufA, c->bufB, c->tape, c->grot, c->gcar, c->gt0, c->gpsi0, c->partial, c->loss_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     c->hsT = c->hdetT = c->twR = c->res_carrier = nullptr;
@@ -1163,9 +1175,9 @@ int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det
 int bdof_set_transfer_f64(bdof_ctx* c, const double* hs64) {
     if (!c || !hs64) return BDOF_ERR_ARG;
     if (!c->have_physics) return fail(c, BDOF_ERR_STATE, "bdof_set_physics has not been called");
-    static const int want = [] { const char* e = std::getenv("BDOF_H_DITHER"); return e ? std::max(0, std::min(256, atoi(e))) : 64; }();
+    const char* env = std::getenv("BDOF_H_DITHER");
     const size_t n = (size_t)c->NX * c->NY;
-    int D = want;
+    int D = env ? std::max(0, std::min(256, atoi(env))) : 64;
     while (D > 1 && (size_t)D * n * sizeof(cf) > ((size_t)256 << 20)) D /= 2;
     if (D < 2) { c->hs_copies = 0; return 0; }
     HIPC(c, hipSetDevice(c->device));
@@ -1831,6 +1843,112 @@ int bdof_forward_range_f64(bdof_ctx* c, int B, const int* angle_of_b, const int*
             RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo));
         }
     }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// ---- the real-space propagator in float64 (bdof_conv64.h) -------------------------------------------------------------------
+// probe: host complex128 [NX][NY]; khat: host complex128 [M][M], M = NX + ks - 1 = NY + ks - 1, the 2-D transform of the ks x ks
+// kernel zero-padded to M x M, transposed to [kx][ky] and divided by M^2; ksum = sum of the kernel's taps (the padding constant's
+// recursion, propagation.py:91,99); k = 2 pi dz / lambda with numpy's pi (propagation.py:25)
+int bdof_set_conv_f64(bdof_ctx* c, const double* probe, const double* khat, int ks, double ksum_re, double ksum_im, double k) {
+    if (!c || !probe || !khat) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    if (c->NX != c->NY) return fail(c, BDOF_ERR_SIZE, "the float64 real-space path takes square wavefields");
+    if (ks < 1 || ks % 2 == 0 || ks >= c->NX) return fail(c, BDOF_ERR_ARG, "kernel_size must be odd and smaller than the field");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->NX * c->NY, M = (size_t)c->NX + ks - 1;
+    if (c->c64_ks != ks) {
+        for (double2** q : {&c->c64_khat, &c->c64_big}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        c->c64_B = 0;
+    }
+    if (!c->c64_probe) HIPC(c, hipMalloc(&c->c64_probe, n * sizeof(double2)));
+    if (!c->c64_khat) HIPC(c, hipMalloc(&c->c64_khat, M * M * sizeof(double2)));
+    if (!c->c64_scal) HIPC(c, hipMalloc(&c->c64_scal, 2 * sizeof(double2)));
+    if (!c->c64_part) HIPC(c, hipMalloc(&c->c64_part, (size_t)c->ncu * 16 * sizeof(double2)));
+    HIPC(c, hipMemcpy(c->c64_probe, probe, n * sizeof(double2), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->c64_khat, khat, M * M * sizeof(double2), hipMemcpyHostToDevice));
+    c->c64_ks = ks;
+    c->c64_ksum = std::complex<double>(ksum_re, ksum_im);
+    c->c64_k = k;
+    return 0;
+}
+
+// bdof_loss_grad_conv with every quantity in float64: loss left for bdof_get_loss, gradient rows in the ctx's rotated-frame
+// buffer (bdof_grot) like every other engine, so bdof_rotation_adjoint / bdof_window_rotation_adjoint follow unchanged.
+// meas: device float, laid out as for bdof_loss_grad_conv (far field: [b][ky][kx] un-shifted, else [b][x][y]); meas_ref: what
+// the host subtracted from the amplitudes (bdof_set_meas_mode 1), 0 otherwise.  Detector: none or far field.
+int bdof_loss_grad_conv_f64(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, double meas_ref) {
+    if (!c || !meas) return BDOF_ERR_ARG;
+    if (!c->c64_ks) return fail(c, BDOF_ERR_STATE, "bdof_set_conv_f64 has not been called");
+    if (!c->obj_src) return fail(c, BDOF_ERR_STATE, "bdof_set_object (with (delta, beta) rows) has not been called");
+    if (!c->grot || !c->partial) return fail(c, BDOF_ERR_STATE, "bdof_configure(with_grad = 1) needed");
+    if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
+    if (c->det_mode == BDOF_DET_NEAR) return fail(c, BDOF_ERR_STATE, "the float64 real-space path has no near-field detector step");
+    if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
+    HIPC(c, hipSetDevice(c->device));
+    const int N = c->NX, ks = c->c64_ks, p = (ks - 1) / 2, M = N + ks - 1, S = c->S;
+    const size_t per = (size_t)N * N, n = per * B, nbig = (size_t)M * M * B;
+    if (c->c64_B < B) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        for (double2** q : {&c->c64_psi, &c->c64_q, &c->c64_big, &c->c64_tape}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        HIPC(c, hipMalloc(&c->c64_psi, n * sizeof(double2)));
+        HIPC(c, hipMalloc(&c->c64_q, n * sizeof(double2)));
+        HIPC(c, hipMalloc(&c->c64_big, nbig * sizeof(double2)));
+        HIPC(c, hipMalloc(&c->c64_tape, (size_t)S * n * sizeof(double2)));
+        c->c64_B = B;
+    }
+    int r;
+    rocfft_plan pf, pi;
+    if ((r = field_plans(c, N, N, B, true, &pf, &pi))) return r;           // detector transforms
+    ObjView o = c->obj;
+    o.vol = c->obj_src;
+    o.angle_of_b = angle_of_b;
+    o.xoff = xoff;
+    o.yoff = yoff;
+    const int eg = g_elem_grid(c, n), egb = g_elem_grid(c, nbig);
+    double2 *psi = c->c64_psi, *big = c->c64_big;
+    hipLaunchKernelGGL(k_c64_bcast, dim3(eg), dim3(256), 0, c->stream, c->c64_probe, psi, B, per);
+    std::complex<double> edge(1.0, 0.0);
+    for (int z = 0; z < S; ++z) {
+        Mod64Args m{psi, o, B, N, N, z, c->c64_k};
+        hipLaunchKernelGGL(k_f64_modulate, dim3(eg), dim3(256), 0, c->stream, m);
+        HIPC(c, hipMemcpyAsync(c->c64_tape + (size_t)z * n, psi, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(k_c64_pad, dim3(egb), dim3(256), 0, c->stream, psi, big, B, N, M, p, make_double2(edge.real(), edge.imag()));
+        if ((r = bdof_fields_free_step(c, big, B, M, M, c->c64_khat, 0, 1))) return r;
+        hipLaunchKernelGGL(k_c64_crop, dim3(eg), dim3(256), 0, c->stream, big, psi, B, N, M, ks - 1);
+        edge *= c->c64_ksum;
+    }
+    // q = s P, s = psi_0[0,0,0] / P[0,0,0] (one scalar for the batch)
+    double2 init;
+    HIPC(c, hipMemcpyAsync(&init, c->c64_probe, sizeof(double2), hipMemcpyDeviceToHost, c->stream));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_c64_corner, dim3(1), dim3(1), 0, c->stream, psi, init, c->c64_scal);
+    hipLaunchKernelGGL(k_c64_scale, dim3(eg), dim3(256), 0, c->stream, psi, n, c->c64_scal, 0);
+    HIPC(c, hipMemcpyAsync(c->c64_q, psi, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
+    const bool far = c->det_mode == BDOF_DET_FAR;
+    void* buf[1] = {psi};
+    if (far) RFC(c, rocfft_execute(pf, buf, nullptr, c->ginfo));           // un-shifted, un-normalised fft2 (propagation.py:114-115)
+    const int lgrid = std::min(eg, c->npartial);
+    hipLaunchKernelGGL(k_c64_loss, dim3(lgrid), dim3(256), 0, c->stream, psi, meas, c->partial, B, N, far ? 1 : 0, meas_ref, 2.0 / (double)n);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, lgrid, 1.0 / (double)n, c->loss_dev);
+    if (far) RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo));           // G(q) = N^2 ifft2(G(d)): the un-normalised inverse
+    // adjoint of the renormalisation through the corner pixel
+    const int dgrid = std::min(eg, c->ncu * 16);
+    hipLaunchKernelGGL(k_c64_dot, dim3(dgrid), dim3(256), 0, c->stream, psi, c->c64_q, n, c->c64_part);
+    hipLaunchKernelGGL(k_c64_scale, dim3(eg), dim3(256), 0, c->stream, psi, n, c->c64_scal, 1);
+    hipLaunchKernelGGL(k_c64_corner_adj, dim3(1), dim3(1), 0, c->stream, psi, c->c64_part, dgrid, c->c64_scal);
+    for (int z = S - 1; z >= 0; --z) {
+        // adjoint of (constant pad, valid convolution): embed, circular correlation, crop to the un-padded pixels
+        hipLaunchKernelGGL(k_c64_pad, dim3(egb), dim3(256), 0, c->stream, psi, big, B, N, M, ks - 1, make_double2(0.0, 0.0));
+        if ((r = bdof_fields_free_step(c, big, B, M, M, c->c64_khat, 1, 1))) return r;
+        hipLaunchKernelGGL(k_c64_crop, dim3(eg), dim3(256), 0, c->stream, big, psi, B, N, M, p);
+        C64BwdArgs ba{psi, c->c64_tape + (size_t)z * n, c->grot, o, B, N, S, z, c->c64_k};
+        hipLaunchKernelGGL(k_c64_bwd, dim3(eg), dim3(256), 0, c->stream, ba);
+    }
+    c->tape_valid = c->last_valid = false;
+    c->gpsi_src = nullptr;
     HIPC(c, hipGetLastError());
     return 0;
 }

@@ -274,8 +274,31 @@ class MultisliceEngine(object):
         ky64 = np.ascontiguousarray(ky.astype(np.complex128))
         kx64 = np.ascontiguousarray(kx.astype(np.complex128))
         self.ctx.check(self.lib.bdof_set_conv_taps_f64(self.h, ky64.ctypes.data, kx64.ctypes.data, float(e.real), float(e.imag)))
+        self._conv_k64 = k
         if getattr(self, '_probe_args', None) is not None:
             self.set_probe(*self._probe_args)      # the carrier (scalar or field) of the probe follows the propagator
+
+    def enable_conv_f64(self):
+        """The real-space propagator's loss + gradient entirely in float64 (bdof_loss_grad_conv_f64; loss_grad(..., conv=True,
+        f64=True)): the accuracy path for the first minibatch of an epoch (adjoint_precision='first-step' / 'float64' with
+        propagator='conv').  Square fields, detector None or far field.  Hands the probe and the transform of the zero-padded
+        ks x ks kernel over in float64 (overlap-save on the padded (N + ks - 1)^2 grid)."""
+        if not getattr(self, '_conv_set', False) or getattr(self, '_probe_args', None) is None:
+            raise RuntimeError('set_conv and set_probe first')
+        if self.nx != self.ny or self.det_mode == _lib.DET_NEAR:
+            raise ValueError('the float64 real-space path takes square wavefields and a detector at None or infinity')
+        ky, kx, e = self._conv_kernel
+        ks = len(ky)
+        m = self.nx + ks - 1
+        kpad = np.zeros((m, m), dtype=np.complex128)
+        kpad[:ks, :ks] = e * np.outer(ky, kx)                                    # K[p][q] = e ky[p] kx[q]   (numpy (Y, X) order)
+        khat = np.ascontiguousarray((np.fft.fft2(kpad) / float(m * m)).T)       # [kx][ky]
+        ksum = e * ky.sum() * kx.sum()
+        pr, pi = self._probe_args
+        probe = np.ascontiguousarray(((np.asarray(pr) + 1j * np.asarray(pi)) * np.ones((self.ny, self.nx))).T.astype(np.complex128))
+        self.ctx.check(self.lib.bdof_set_conv_f64(self.h, probe.ctypes.data, khat.ctypes.data, ks, float(ksum.real), float(ksum.imag),
+                                                  float(self._conv_k64)))
+        self.conv_f64 = True
 
     # ---- object --------------------------------------------------------------------------------
     def set_object_batch(self, grid_delta_batch, grid_beta_batch):
@@ -343,14 +366,21 @@ class MultisliceEngine(object):
         return res
 
     # ---- loss + gradient -----------------------------------------------------------------------
-    def loss_grad(self, B, meas_abs, angle_idx=None, xoff=None, yoff=None, meas_on_device=False, conv=False):
-        """Runs forward + loss + adjoint; returns the loss.  The gradient stays on the device."""
+    def loss_grad(self, B, meas_abs, angle_idx=None, xoff=None, yoff=None, meas_on_device=False, conv=False, f64=False):
+        """Runs forward + loss + adjoint; returns the loss.  The gradient stays on the device.  f64 (with conv): the float64
+        real-space path (enable_conv_f64)."""
         m = meas_abs if meas_on_device else self._meas_to_device(meas_abs)
         a = _idx_buf(self.ctx, angle_idx) if angle_idx is not None else None
         xo = _idx_buf(self.ctx, xoff) if xoff is not None else None
         yo = _idx_buf(self.ctx, yoff) if yoff is not None else None
-        fn = self.lib.bdof_loss_grad_conv if conv else self.lib.bdof_loss_grad
-        self.ctx.check(fn(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), _lib._ptr(m), None))
+        if f64:
+            if not (conv and getattr(self, 'conv_f64', False)):
+                raise RuntimeError('f64 is the real-space propagator\'s float64 path: conv=True after enable_conv_f64()')
+            self.ctx.check(self.lib.bdof_loss_grad_conv_f64(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), _lib._ptr(m),
+                                                            float(getattr(self, 'meas_ref', 0.0))))
+        else:
+            fn = self.lib.bdof_loss_grad_conv if conv else self.lib.bdof_loss_grad
+            self.ctx.check(fn(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), _lib._ptr(m), None))
         loss = ctypes.c_double(0)
         self.ctx.check(self.lib.bdof_get_loss(self.h, ctypes.byref(loss)))
         self._keep['last_idx'] = (a, xo, yo, m)

@@ -77,13 +77,13 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
     # 'fft' (default): transfer-function propagator of np_funcs.py; 'conv': truncated real-space kernel of propagation.py,
     # the reference's own choice in this entry point, with `kernel_size` taps per axis
     propagator = kwargs.get('propagator', 'fft')
-    # 'float64': the adjoint sweep in float64 (bdof_configure flag 64, transfer-function propagator only);
+    # 'float64': the adjoint sweep in float64 (bdof_configure flag 64; with propagator='conv' both sweeps, bdof_loss_grad_conv_f64);
     # 'first-step': in float64 for the first minibatch of every epoch only — Adam's first step after its per-epoch restart is
     # lr g / (|g| + 1e-8), the one step in which the float32 rounding of the gradient reaches the volume
     # (the default with the transfer-function propagator: reconstructed delta within 2.1e-6 of the reference's float64 loop on golden
     # vector G17, 7.0e-6 with 'float32' — both inside 1e-5 since the kernels take dithered copies of the transfer function;
     # one slower step per epoch)
-    adjoint_precision = kwargs.get('adjoint_precision', 'first-step' if propagator == 'fft' else 'float32')
+    adjoint_precision = kwargs.get('adjoint_precision', 'first-step')
     if adjoint_precision not in ('float32', 'float64', 'first-step'):
         raise ValueError("adjoint_precision must be 'float32', 'float64' or 'first-step'")
 

@@ -503,8 +503,6 @@ class PtychoSolver(_VolumeSolver):
                  variant='numpy_skip_last', comm=None, device=0, stream=None, coord_ls=None, propagator='fft', kernel_size=17,
                  adjoint64=None):
         self.conv = propagator == 'conv'
-        if adjoint64 and self.conv:
-            raise ValueError("adjoint64 (float64 adjoint sweep) runs with the transfer-function propagator only")
         self.dim_y, self.dim_x, self.dim_z = [int(s) for s in obj_size]
         self.py, self.px = int(probe_size[0]), int(probe_size[1])
         self.n_theta, self.mb = int(n_theta), int(minibatch_size)
@@ -517,7 +515,7 @@ class PtychoSolver(_VolumeSolver):
         pin = 'resident' if (self.py == self.px and self.py in RESIDENT_SIZES and not self.conv
                              and not os.environ.get('BDOF_NO_RESIDENT_PIN')) else 'auto'
         self.eng = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream, engine=pin,
-                                    adjoint64=adjoint64 is True)
+                                    adjoint64=adjoint64 is True and not self.conv)
         self.ctx = self.eng.ctx
         self.eng.set_physics(energy_ev, psize_cm, 'inf', variant=variant)   # free_prop_cm='inf', ptychography.py:76
         if self.conv:
@@ -527,7 +525,17 @@ class PtychoSolver(_VolumeSolver):
         # step after a restart is lr g / (|g| + 1e-8), the only one in which a 1e-8 error of the gradient moves a voxel by a
         # fraction of a whole step; every later step runs on the fast engine
         self.eng64 = None
-        if adjoint64 == 'first':
+        # real-space propagator: its float64 path lives on the SAME context (bdof_loss_grad_conv_f64: whole sweeps in double,
+        # no second engine); conv64 = 'first' / True says when it runs
+        self.conv64 = None
+        if self.conv and adjoint64 in ('first', True):
+            try:
+                self.eng.enable_conv_f64()
+            except ValueError as err:                      # a probe the float64 path does not take: let the caller decide
+                from ._lib import BdofError
+                raise BdofError(str(err))
+            self.conv64 = adjoint64
+        elif adjoint64 == 'first':
             self.eng64 = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream, adjoint64=True)
             self.eng64.set_physics(energy_ev, psize_cm, 'inf', variant=variant)
             self.eng64.set_probe(probe_real, probe_imag)
@@ -586,7 +594,13 @@ class PtychoSolver(_VolumeSolver):
 
     def _win_loss_grad(self, i_theta, pos_idx, prj_abs_batch, use64=False):
         a, xo, yo = self._stage(i_theta, pos_idx, prj_abs_batch)
-        ctx = self.eng64.ctx if use64 else self.ctx
+        if self.conv and (self.conv64 is True or (use64 and self.conv64 == 'first')):
+            self.ctx.check(self.ctx.lib.bdof_loss_grad_conv_f64(self.ctx.handle, self.mb, a, xo, yo, self.meas_stage.ptr,
+                                                                float(getattr(self.eng, 'meas_ref', 0.0))))
+            self._last = (int(i_theta), xo, yo)
+            self._last_ctx = self.ctx
+            return
+        ctx = self.eng64.ctx if (use64 and self.eng64 is not None) else self.ctx
         if ctx is not self.ctx:
             self.ctx.sync()                          # the staging buffers and the volume were written on self.ctx's stream
         fn = ctx.lib.bdof_loss_grad_conv if self.conv else ctx.lib.bdof_loss_grad
@@ -621,7 +635,8 @@ class PtychoSolver(_VolumeSolver):
     def step(self, i_batch, i_theta, pos_idx, prj_abs_batch=None, learning_rate=1.0, want_loss=False, n_slabs=None, sharded=None, clip=True):
         """One Adam iteration of ptychography.py:301-310: loss_grad, Allreduce, /size, Adam, clip (no regulariser, no mask).
         The window/rotation adjoint produces the whole volume gradient in one pass; exchange and Adam are still slab-wise."""
-        self._win_loss_grad(i_theta, pos_idx, prj_abs_batch, use64=self.eng64 is not None and i_batch == 0 and self.probe is None)
+        self._win_loss_grad(i_theta, pos_idx, prj_abs_batch,
+                            use64=(self.eng64 is not None or self.conv64 == 'first') and i_batch == 0 and self.probe is None)
         self._probe_collect()
         self._produce_all()
         self._tail(lambda x0, nx: None, i_batch, learning_rate, clip=clip, use_mask=False, n_slabs=n_slabs, sharded=sharded)

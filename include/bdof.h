@@ -264,6 +264,19 @@ int bdof_set_conv_taps_f64(bdof_ctx* ctx, const double* ky, const double* kx, do
  * psi_z = p_z + eps_z, eps zero-padded, and |d| - m is taken in float64 against s * det64.  Call bdof_set_probe with a zero
  * array and a0 = 0 first, and again after every bdof_set_conv.  NULL, NULL removes the stack. */
 int bdof_set_conv_probe_stack(bdof_ctx* ctx, const float* stack, const double* det64, double p0_re, double p0_im, double pS_re, double pS_im);
+/* The same loss + gradient entirely in float64 (bdof_conv64.h): the reference differentiates this forward model in float64
+ * (autograd on numpy float64, cnn_propagator/ptychography.py:248,301), and for far-field ptychography the float32 kernels stop at
+ * 1.5e-5 of its reconstructed delta (golden vector G14) — all of it in the wake of the corner pixel through which the
+ * renormalisation of propagation.py:109-110 feeds sum(G conj q) back into the stack.  An accuracy path for the first minibatch of
+ * an epoch (adjoint_precision='first-step'), unfused: every slice's pad + 'valid' convolution is one rocFFT double-precision
+ * transform pair on the padded (N + ks - 1)^2 grid (overlap-save; its adjoint the circular correlation of the embedded adjoint
+ * field), everything else point-wise in double.  bdof_set_conv_f64: probe host complex128 [NX][NY]; khat host complex128
+ * [M][M], M = N + ks - 1: fft2 of the kernel zero-padded to M x M, transposed to [kx][ky], / M^2; ksum = sum of its taps; k as
+ * for bdof_set_conv.  bdof_loss_grad_conv_f64: meas as for bdof_loss_grad_conv (+ meas_ref, what the host subtracted under
+ * bdof_set_meas_mode(1)); loss by bdof_get_loss; gradient rows in bdof_grot.  Square fields; detector none or far field. */
+int bdof_set_conv_f64(bdof_ctx* ctx, const double* probe, const double* khat, int ks, double ksum_re, double ksum_im, double k);
+int bdof_loss_grad_conv_f64(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas,
+                            double meas_ref);
 int bdof_forward_conv(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave);
 int bdof_loss_grad_conv(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, void* out_wave);
 void* bdof_grot(bdof_ctx* ctx);      /* device [B][S][NX][NY] pairs */

@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory_between_tests():
+    """Engines, solvers and their device buffers are freed by refcount, but a few hold reference cycles (ctypes callbacks, closures):
+    collect after every test so that the GPU suite — one process, 260 tests, several of them tens of GiB — never carries the
+    previous tests' allocations into the next one."""
+    yield
+    import gc
+    gc.collect()

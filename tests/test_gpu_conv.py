@@ -161,8 +161,42 @@ def test_reconstruct_fullfield_vs_the_reference_loop(engine_mod, tmp_path, monke
     assert stats[2] <= 0.01 and stats[3] <= 5e-5, stats
 
 
-@pytest.mark.parametrize('streams', [None, '2'])
-def test_reconstruct_ptychography_vs_the_reference_loop(engine_mod, tmp_path, monkeypatch, streams):
+@pytest.mark.parametrize('fp', [None, 'inf'])
+@pytest.mark.parametrize('ks,probe', [(5, 'random'), (17, 'gaussian')])
+def test_float64_real_space_path_vs_oracle(engine_mod, fp, ks, probe):
+    """bdof_loss_grad_conv_f64 (csrc/bdof_conv64.h): the real-space propagator's forward + loss + gradient entirely in float64 — pad
+    + 'valid' convolution as an overlap-save transform pair on the padded grid, the corner-pixel renormalisation and its adjoint,
+    magnitude loss — against the oracle's restatement of cnn_propagator/propagation.py:18-133 + its hand-derived gradient (pinned
+    by G9 and by finite differences).  Float64 throughout: the loss to 1e-12; the gradient rows are stored as float32 (6e-8)."""
+    rng = np.random.default_rng(21)
+    B, N, S = 3, 64, 7
+    delta = rng.uniform(0, 2e-5, size=(B, N, N, S))
+    beta = 0.1 * delta
+    if probe == 'gaussian':
+        pr, pi = orc.gaussian_probe((N, N), 40., 40., 0.5)
+    else:
+        pr, pi = 0.8 + 0.1 * rng.normal(size=(N, N)), 0.1 * rng.normal(size=(N, N))
+    ref = orc.multislice_propagate_cnn(delta, beta, pr, pi, 5000., [1e-7] * 3, kernel_size=ks, free_prop_cm=fp)
+    meas = (np.abs(ref) * (1 + 0.02 * rng.normal(size=ref.shape))).astype(np.float32).astype(np.float64)     # what the device is handed
+    rl, rgd, rgb = orc.cnn_loss_and_grad(delta, beta, pr, pi, 5000., [1e-7] * 3, meas, kernel_size=ks, free_prop_cm=fp)
+    eng = engine_mod.MultisliceEngine(N, N, S, B, with_grad=True)
+    eng.set_physics(5000., 1e-7, fp)
+    eng.set_conv(5000., [1e-7] * 3, ks)
+    eng.set_probe(pr, pi)
+    eng.set_object_batch(delta, beta)
+    eng.enable_conv_f64()
+    loss = eng.loss_grad(B, meas, conv=True, f64=True)
+    gd, gb = eng.grad_batch_to_host(B)
+    e = (abs(loss - rl) / rl, rel(gd, rgd), rel(gb, rgb))
+    l32 = eng.loss_grad(B, meas, conv=True)
+    gd32, gb32 = eng.grad_batch_to_host(B)
+    print('float64 real-space path, detector', fp, ks, 'taps:', e, ' float32 kernels:', (abs(l32 - rl) / rl, rel(gd32, rgd), rel(gb32, rgb)))
+    # float64 arithmetic; the gradient rows are float32 numbers (6e-8)
+    assert e[0] <= 1e-8 and e[1] <= 2e-7 and e[2] <= 2e-7, e
+
+
+@pytest.mark.parametrize('streams,adjoint_precision', [(None, 'float32'), ('2', 'float32'), (None, 'first-step'), (None, 'float64')])
+def test_reconstruct_ptychography_vs_the_reference_loop(engine_mod, tmp_path, monkeypatch, streams, adjoint_precision):
     """(streams = '2': the minibatch split over two streams, as large minibatches run — windows, carrier field and gradient rows
     of the second group at their offsets.)  The ptychography entry point against golden vector G14 directly: the reference's own reconstruct_ptychography executed
     (make_golden.py --g14: (64, 64, 64) object, 64 x 64 wide gaussian probe, 4 positions x 2 angles in minibatches of 2, two
@@ -186,18 +220,24 @@ def test_reconstruct_ptychography_vs_the_reference_loop(engine_mod, tmp_path, mo
     d, b = reconstruct_ptychography('data.h5', [tuple(int(v) for v in p) for p in g['probe_pos']], psz, obj_size, theta_st=0, theta_end=2 * np.pi,
                                     n_epochs=2, learning_rate=lr, minibatch_size=2, energy_ev=5000, psize_cm=1e-7, save_path='case',
                                     output_folder='out', initial_guess=[init_d, init_b], probe_type='gaussian', dynamic_dropping=False,
-                                    propagator='conv', kernel_size=17, seed=42, probe_mag_sigma=40., probe_phase_sigma=40., probe_phase_max=0.5)
+                                    propagator='conv', kernel_size=17, seed=42, probe_mag_sigma=40., probe_phase_sigma=40., probe_phase_max=0.5,
+                                    adjoint_precision=adjoint_precision)
     assert float(g['delta_moved_max']) >= 5 * lr                        # the volume moved by several whole steps
     d, b = d[::2, ::2, ::2], b[::2, ::2, ::2]
     dev, devb = np.abs(d - g['delta_sub']), np.abs(b - g['beta_sub'])
     stats = (dev.max() / lr, rel(d, g['delta_sub']), devb.max() / lr, rel(b, g['beta_sub']), float(np.mean(dev > 0.5 * lr)))
-    print('G14 stats', stats)
+    print('G14 stats', adjoint_precision, stats)
     # Round 2 measured delta 7.5e-3 here (a few voxels 3 steps off), beta 7e-4: the whole wave of this wide probe ran through the
     # float32 convolutions and |d| - m was taken in float32.  Round 3 gave the real-space path a carrier FIELD (the probe carried
     # through empty space by the padded convolution in float64, bdof_set_conv_probe_stack) and the float64 residual at the
     # detector: first-minibatch gradient 1.8e-4 -> 4.9e-6, delta after the eight steps 1.6e-5, beta 3.1e-6, no voxel more than
     # 0.009 of a step away — where the transfer-function path stands with float32 adjoint arithmetic (G17: 1.7e-5).
-    assert stats[0] <= 0.05 and stats[1] <= 3e-5 and stats[3] <= 1e-5 and stats[4] == 0.0, stats
+    # Round 4: the float64 real-space path (bdof_loss_grad_conv_f64) for the first minibatch of every epoch — the entry point's
+    # default, adjoint_precision='first-step': delta 4.8e-6, beta 1.8e-6 — or throughout ('float64'): 1.2e-7 / 6.6e-8.
+    if adjoint_precision == 'float32':
+        assert stats[0] <= 0.05 and stats[1] <= 3e-5 and stats[3] <= 1e-5 and stats[4] == 0.0, stats
+    else:
+        assert stats[0] <= 0.05 and stats[1] <= 1e-5 and stats[3] <= 1e-5 and stats[4] == 0.0, stats
 
 
 @pytest.mark.parametrize('ks,probe,shape', [(17, 'plane', (128, 128)), (17, 'random', (64, 256)), (9, 'random', (128, 64)),
