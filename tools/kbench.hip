@@ -81,7 +81,7 @@ int main(int argc, char** argv) {
         CK(hipFree(ca)); CK(hipFree(cb));
     }
     const int tiles = B * N / RowCfg<N>::TILE;
-    if (argc > 3) {      // grid sweep: how many workgroups should share the launch's tiles (alternated, best of 5)
+    if (argc > 3 && atoi(argv[3]) == 1) {      // grid sweep: how many workgroups should share the launch's tiles (alternated, best of 5)
         RowFwdArgs fa{in, probe, out, tape, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};
         RowPropArgs pa{in, out, h, B, N, 1.f, 0, tw};
         RowBwdArgs ba{in, tape, out, grot, obj, B, N, 3, 25.3f, make_float2(1.f, 0.f), tw};
@@ -102,6 +102,35 @@ int main(int argc, char** argv) {
             for (int gi = 0; gi < 5; ++gi) printf("  grid %d: %6.2f us", grids[gi], best[k][gi] * 1e3);
             printf("\n");
         }
+        return 0;
+    }
+    if (argc > 3 && atoi(argv[3]) == 2) {      // tile-order experiment (kvariants.h: kv_prop_order), alternated, best of 7
+        RowPropArgs pa{in, out, h, B, N, 1.f, 0, tw};
+        pa.sq[0] = pa.sq[1] = 0.70710678f;
+        const int g = tiles / 2;
+        float best[3] = {1e9f, 1e9f, 1e9f};
+        for (int rep = 0; rep < 7; ++rep) {
+            best[0] = std::min(best[0], time_it([&] { hipLaunchKernelGGL((kv_prop_order<N, 0>), dim3(g), dim3(BDOF_THREADS), 0, 0, pa); }, iters));
+            best[1] = std::min(best[1], time_it([&] { hipLaunchKernelGGL((kv_prop_order<N, 1>), dim3(g), dim3(BDOF_THREADS), 0, 0, pa); }, iters));
+            best[2] = std::min(best[2], time_it([&] { hipLaunchKernelGGL((kv_prop_order<N, 2>), dim3(g), dim3(BDOF_THREADS), 0, 0, pa); }, iters));
+        }
+        printf("tile order (grid %d, %d tiles): round-robin %6.2f us   adjacent pairs %6.2f us   pairs of pairs per XCD %6.2f us\n", g, tiles, best[0] * 1e3, best[1] * 1e3, best[2] * 1e3);
+        // the same with every launch on fresh buffers (a ring of 8 x in/out: 840 MB, beyond the Infinity Cache), as the sweep sees them
+        const int ring = 8;
+        cf *rin, *rout;
+        CK(hipMalloc(&rin, fld * 8 * ring)); CK(hipMalloc(&rout, fld * 8 * ring));
+        for (int r = 0; r < ring; ++r) CK(hipMemcpy(rin + fld * r, in, fld * 8, hipMemcpyDeviceToDevice));
+        float bst[3] = {1e9f, 1e9f, 1e9f};
+        int turn = 0;
+        auto launch = [&](int order) {
+            RowPropArgs q = pa; q.in = rin + fld * (turn % ring); q.out = rout + fld * (turn % ring); ++turn;
+            if (order == 0) hipLaunchKernelGGL((kv_prop_order<N, 0>), dim3(g), dim3(BDOF_THREADS), 0, 0, q);
+            else if (order == 1) hipLaunchKernelGGL((kv_prop_order<N, 1>), dim3(g), dim3(BDOF_THREADS), 0, 0, q);
+            else hipLaunchKernelGGL((kv_prop_order<N, 2>), dim3(g), dim3(BDOF_THREADS), 0, 0, q);
+        };
+        for (int rep = 0; rep < 7; ++rep)
+            for (int o = 0; o < 3; ++o) bst[o] = std::min(bst[o], time_it([&] { launch(o); }, iters));
+        printf("  on a ring of %d buffer pairs:    round-robin %6.2f us   adjacent pairs %6.2f us   pairs of pairs per XCD %6.2f us\n", ring, bst[0] * 1e3, bst[1] * 1e3, bst[2] * 1e3);
         return 0;
     }
     for (int per_cu : {2, 3, 4}) {

@@ -97,3 +97,52 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void kv_prop(R
         }
     }
 }
+
+// Tile order experiment (round 4): which tiles a persistent workgroup takes.  ORDER 0: blockIdx + i * grid (production);
+// 1: the adjacent pair 2 * blockIdx + i (its two 128-byte store segments of every output row make one 256-byte block);
+// 2: adjacent pairs, and the two pairs of an XCD's consecutive workgroups adjacent too (512 bytes of every output row per XCD);
+// 3: as 0 but the second tile first loaded before the first one's tail (row loads hoisted across the tile barrier)
+template <int NX, int ORDER>
+__global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void kv_prop_order(RowPropArgs a) {
+    typedef RowCfg<NX> C;
+    __shared__ cf smem[C::LDS_CF];
+    const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
+    __shared__ cf smem_tw[FftTw<NX>::LDS_CNT];
+    FftTw<NX> tw;
+    __shared__ cf smem_tail[7 * C::T];
+    tw.load(a.twiddle, tid, smem_tw, smem_tail);
+    tw.sq = a.sq;
+    const int ntiles = a.B * a.NY / C::TILE;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    for (int i = 0; i < per; ++i) {
+        int tile;
+        if (ORDER == 1) tile = per * blockIdx.x + i;
+        else if (ORDER == 2) {
+            const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+            const int p = (k >> 1) * 16 + xcd * 2 + (k & 1);
+            tile = per * p + i;
+        } else tile = blockIdx.x + i * gridDim.x;
+        if (tile >= ntiles) break;
+        const int row0 = tile * C::TILE;
+        const int b = row0 / a.NY, ky0 = row0 - b * a.NY;
+#pragma nounroll
+        for (int pass = 0; pass < C::PASSES; ++pass) {
+            const int r = pass * C::RPP + rl;
+            RowLds<C::T> lds{smem + r * C::RS};
+            cf u[8], hv[8];
+            const cf* src = a.in + (size_t)(row0 + r) * NX;
+            const cf* hrow = a.h + (size_t)(ky0 + r) * NX;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) u[m] = src[tid + m * C::T];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) hv[m] = hrow[tid + m * C::T];
+            line_fft<NX, -1>(u, tw, tid, lds);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) u[m] = cmul(u[m], cscale(hv[m], a.scale));
+            line_fft_partial<NX, +1, 2>(u, tw, tid, lds);
+        }
+        __syncthreads();
+        transposed_tail<NX, +1, 2>(smem, a.out + (size_t)b * NX * a.NY + ky0, a.NY, 1.f, smem_tail, a.sq);
+        __syncthreads();
+    }
+}
