@@ -56,6 +56,8 @@ struct bdof_ctx {
     double2 *c64_probe = nullptr, *c64_khat = nullptr, *c64_psi = nullptr, *c64_q = nullptr, *c64_big = nullptr, *c64_tape = nullptr,
             *c64_scal = nullptr, *c64_part = nullptr;
     int c64_ks = 0, c64_B = 0;
+    bool c64_tf = false;                        // the float64 path holds the transfer-function model (bdof_set_tf_f64), not the real-space one
+    double2 *c64_h = nullptr, *c64_hdet = nullptr;
     std::complex<double> c64_ksum{1.0, 0.0};
     double c64_k = 0.0;
     cf* hsT_d = nullptr;           // the same copies in the LDS-resident kernel's [kx][ky] order
@@ -954,7 +956,7 @@ static void free_workspace(bdof_ctx* c) {
     free_generic(c);
     if (c->hs_d) { (void)hipFree(c->hs_d); c->hs_d = nullptr; c->hs_copies = 0; }
     if (c->hsT_d) { (void)hipFree(c->hsT_d); c->hsT_d = nullptr; }
-    for (double2** q : {&c->c64_probe, &c->c64_khat, &c->c64_psi, &c->c64_q, &c->c64_big, &c->c64_tape, &c->c64_scal, &c->c64_part}) {
+    for (double2** q : {&c->c64_probe, &c->c64_khat, &c->c64_psi, &c->c64_q, &c->c64_big, &c->c64_tape, &c->c64_scal, &c->c64_part, &c->c64_h, &c->c64_hdet}) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
     }
@@ -1835,7 +1837,7 @@ int bdof_forward_range_f64(bdof_ctx* c, int B, const int* angle_of_b, const int*
     const size_t per = (size_t)c->NX * c->NY, n = per * B;
     void* buf[1] = {fields};
     for (int z = z0; z < z0 + nz; ++z) {
-        Mod64Args m{(double2*)fields, o, B, c->NX, c->NY, z, k};
+        Mod64Args m{(double2*)fields, o, B, c->NX, c->NY, z, k, nullptr};
         hipLaunchKernelGGL(k_f64_modulate, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, m);
         if (z < z0 + nz - 1 || prop_last) {
             RFC(c, rocfft_execute(pf, buf, nullptr, c->ginfo));
@@ -1848,6 +1850,26 @@ int bdof_forward_range_f64(bdof_ctx* c, int B, const int* angle_of_b, const int*
 }
 
 // ---- the real-space propagator in float64 (bdof_conv64.h) -------------------------------------------------------------------
+// Buffers of the float64 paths for B wavefields: the wave, the tape of S slices and, for the real-space model, the renormalised
+// exit wave and the padded grid.  Allocated when the model is handed over (for Bmax), so that a device without room for them says
+// so at set-up and not in the middle of a run.
+static int c64_room(bdof_ctx* c, int B, bool tf, size_t M) {
+    const size_t n = (size_t)c->NX * c->NY * B;
+    const bool have = c->c64_B >= B && c->c64_psi && c->c64_tape && (tf || (c->c64_q && c->c64_big));
+    if (have) return 0;
+    HIPC(c, hipStreamSynchronize(c->stream));
+    for (double2** q : {&c->c64_psi, &c->c64_q, &c->c64_big, &c->c64_tape}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    c->c64_B = 0;
+    HIPC(c, hipMalloc(&c->c64_psi, n * sizeof(double2)));
+    HIPC(c, hipMalloc(&c->c64_tape, (size_t)c->S * n * sizeof(double2)));
+    if (!tf) {
+        HIPC(c, hipMalloc(&c->c64_q, n * sizeof(double2)));
+        HIPC(c, hipMalloc(&c->c64_big, M * M * (size_t)B * sizeof(double2)));
+    }
+    c->c64_B = B;
+    return 0;
+}
+
 // probe: host complex128 [NX][NY]; khat: host complex128 [M][M], M = NX + ks - 1 = NY + ks - 1, the 2-D transform of the ks x ks
 // kernel zero-padded to M x M, transposed to [kx][ky] and divided by M^2; ksum = sum of the kernel's taps (the padding constant's
 // recursion, propagation.py:91,99); k = 2 pi dz / lambda with numpy's pi (propagation.py:25)
@@ -1870,9 +1892,10 @@ int bdof_set_conv_f64(bdof_ctx* c, const double* probe, const double* khat, int 
     HIPC(c, hipMemcpy(c->c64_probe, probe, n * sizeof(double2), hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(c->c64_khat, khat, M * M * sizeof(double2), hipMemcpyHostToDevice));
     c->c64_ks = ks;
+    c->c64_tf = false;
     c->c64_ksum = std::complex<double>(ksum_re, ksum_im);
     c->c64_k = k;
-    return 0;
+    return c64_room(c, c->Bmax, false, M);
 }
 
 // bdof_loss_grad_conv with every quantity in float64: loss left for bdof_get_loss, gradient rows in the ctx's rotated-frame
@@ -1881,7 +1904,7 @@ int bdof_set_conv_f64(bdof_ctx* c, const double* probe, const double* khat, int 
 // the host subtracted from the amplitudes (bdof_set_meas_mode 1), 0 otherwise.  Detector: none or far field.
 int bdof_loss_grad_conv_f64(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, double meas_ref) {
     if (!c || !meas) return BDOF_ERR_ARG;
-    if (!c->c64_ks) return fail(c, BDOF_ERR_STATE, "bdof_set_conv_f64 has not been called");
+    if (!c->c64_ks || c->c64_tf) return fail(c, BDOF_ERR_STATE, "bdof_set_conv_f64 has not been called");
     if (!c->obj_src) return fail(c, BDOF_ERR_STATE, "bdof_set_object (with (delta, beta) rows) has not been called");
     if (!c->grot || !c->partial) return fail(c, BDOF_ERR_STATE, "bdof_configure(with_grad = 1) needed");
     if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
@@ -1890,16 +1913,8 @@ int bdof_loss_grad_conv_f64(bdof_ctx* c, int B, const int* angle_of_b, const int
     HIPC(c, hipSetDevice(c->device));
     const int N = c->NX, ks = c->c64_ks, p = (ks - 1) / 2, M = N + ks - 1, S = c->S;
     const size_t per = (size_t)N * N, n = per * B, nbig = (size_t)M * M * B;
-    if (c->c64_B < B) {
-        HIPC(c, hipStreamSynchronize(c->stream));
-        for (double2** q : {&c->c64_psi, &c->c64_q, &c->c64_big, &c->c64_tape}) { if (*q) (void)hipFree(*q); *q = nullptr; }
-        HIPC(c, hipMalloc(&c->c64_psi, n * sizeof(double2)));
-        HIPC(c, hipMalloc(&c->c64_q, n * sizeof(double2)));
-        HIPC(c, hipMalloc(&c->c64_big, nbig * sizeof(double2)));
-        HIPC(c, hipMalloc(&c->c64_tape, (size_t)S * n * sizeof(double2)));
-        c->c64_B = B;
-    }
     int r;
+    if ((r = c64_room(c, B, false, (size_t)M))) return r;
     rocfft_plan pf, pi;
     if ((r = field_plans(c, N, N, B, true, &pf, &pi))) return r;           // detector transforms
     ObjView o = c->obj;
@@ -1912,9 +1927,8 @@ int bdof_loss_grad_conv_f64(bdof_ctx* c, int B, const int* angle_of_b, const int
     hipLaunchKernelGGL(k_c64_bcast, dim3(eg), dim3(256), 0, c->stream, c->c64_probe, psi, B, per);
     std::complex<double> edge(1.0, 0.0);
     for (int z = 0; z < S; ++z) {
-        Mod64Args m{psi, o, B, N, N, z, c->c64_k};
+        Mod64Args m{psi, o, B, N, N, z, c->c64_k, c->c64_tape + (size_t)z * n};
         hipLaunchKernelGGL(k_f64_modulate, dim3(eg), dim3(256), 0, c->stream, m);
-        HIPC(c, hipMemcpyAsync(c->c64_tape + (size_t)z * n, psi, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
         hipLaunchKernelGGL(k_c64_pad, dim3(egb), dim3(256), 0, c->stream, psi, big, B, N, M, p, make_double2(edge.real(), edge.imag()));
         if ((r = bdof_fields_free_step(c, big, B, M, M, c->c64_khat, 0, 1))) return r;
         hipLaunchKernelGGL(k_c64_crop, dim3(eg), dim3(256), 0, c->stream, big, psi, B, N, M, ks - 1);
@@ -1931,7 +1945,7 @@ int bdof_loss_grad_conv_f64(bdof_ctx* c, int B, const int* angle_of_b, const int
     void* buf[1] = {psi};
     if (far) RFC(c, rocfft_execute(pf, buf, nullptr, c->ginfo));           // un-shifted, un-normalised fft2 (propagation.py:114-115)
     const int lgrid = std::min(eg, c->npartial);
-    hipLaunchKernelGGL(k_c64_loss, dim3(lgrid), dim3(256), 0, c->stream, psi, meas, c->partial, B, N, far ? 1 : 0, meas_ref, 2.0 / (double)n);
+    hipLaunchKernelGGL(k_c64_loss, dim3(lgrid), dim3(256), 0, c->stream, psi, meas, c->partial, B, N, N, far ? 1 : 0, meas_ref, 2.0 / (double)n);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, lgrid, 1.0 / (double)n, c->loss_dev);
     if (far) RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo));           // G(q) = N^2 ifft2(G(d)): the un-normalised inverse
     // adjoint of the renormalisation through the corner pixel
@@ -1944,7 +1958,84 @@ int bdof_loss_grad_conv_f64(bdof_ctx* c, int B, const int* angle_of_b, const int
         hipLaunchKernelGGL(k_c64_pad, dim3(egb), dim3(256), 0, c->stream, psi, big, B, N, M, ks - 1, make_double2(0.0, 0.0));
         if ((r = bdof_fields_free_step(c, big, B, M, M, c->c64_khat, 1, 1))) return r;
         hipLaunchKernelGGL(k_c64_crop, dim3(eg), dim3(256), 0, c->stream, big, psi, B, N, M, p);
-        C64BwdArgs ba{psi, c->c64_tape + (size_t)z * n, c->grot, o, B, N, S, z, c->c64_k};
+        C64BwdArgs ba{psi, c->c64_tape + (size_t)z * n, c->grot, o, B, N, N, S, z, c->c64_k};
+        hipLaunchKernelGGL(k_c64_bwd, dim3(eg), dim3(256), 0, c->stream, ba);
+    }
+    c->tape_valid = c->last_valid = false;
+    c->gpsi_src = nullptr;
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// ---- the transfer-function model in float64 on the same context -------------------------------------------------------------
+// probe: host complex128 [NX][NY]; hT / hdetT (nullable: no near-field detector step): host complex128 [kx][ky], the
+// ifftshift-ed transfer functions / (NX NY); k = 2 pi dz / lambda as bdof_set_physics has it
+int bdof_set_tf_f64(bdof_ctx* c, const double* probe, const double* hT, const double* hdetT, double k) {
+    if (!c || !probe || !hT) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    if (c->det_mode == BDOF_DET_NEAR && !hdetT) return fail(c, BDOF_ERR_ARG, "a near-field detector needs its transfer function in float64 too");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->NX * c->NY;
+    if (!c->c64_probe) HIPC(c, hipMalloc(&c->c64_probe, n * sizeof(double2)));
+    if (!c->c64_h) HIPC(c, hipMalloc(&c->c64_h, n * sizeof(double2)));
+    if (hdetT && !c->c64_hdet) HIPC(c, hipMalloc(&c->c64_hdet, n * sizeof(double2)));
+    HIPC(c, hipMemcpy(c->c64_probe, probe, n * sizeof(double2), hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->c64_h, hT, n * sizeof(double2), hipMemcpyHostToDevice));
+    if (hdetT) HIPC(c, hipMemcpy(c->c64_hdet, hdetT, n * sizeof(double2), hipMemcpyHostToDevice));
+    c->c64_tf = true;
+    c->c64_ks = 1;
+    c->c64_k = k;
+    return c64_room(c, c->Bmax, true, 0);
+}
+
+// bdof_loss_grad with every quantity in float64 (np_funcs.py:15-65 as autograd differentiates it in the reference: modulation
+// from the (delta, beta) rows, F^-1 H F per slice by rocFFT in double, magnitude loss, adjoint sweep): loss for bdof_get_loss,
+// gradient rows in bdof_grot.  Unfused — the accuracy path of the first minibatch of an epoch, and a float64 twin of the fused
+// kernels on the device.  meas: device float, laid out as for bdof_loss_grad (+ meas_ref under bdof_set_meas_mode(1)).
+int bdof_loss_grad_tf_f64(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, double meas_ref) {
+    if (!c || !meas) return BDOF_ERR_ARG;
+    if (!c->c64_tf) return fail(c, BDOF_ERR_STATE, "bdof_set_tf_f64 has not been called");
+    if (!c->obj_src) return fail(c, BDOF_ERR_STATE, "bdof_set_object (with (delta, beta) rows) has not been called");
+    if (!c->grot || !c->partial) return fail(c, BDOF_ERR_STATE, "bdof_configure(with_grad = 1) needed");
+    if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
+    if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
+    HIPC(c, hipSetDevice(c->device));
+    const int NX = c->NX, NY = c->NY, S = c->S;
+    const size_t per = (size_t)NX * NY, n = per * B;
+    int r;
+    if ((r = c64_room(c, B, true, 0))) return r;
+    rocfft_plan pf, pi;
+    if ((r = field_plans(c, NX, NY, B, true, &pf, &pi))) return r;
+    ObjView o = c->obj;
+    o.vol = c->obj_src;
+    o.angle_of_b = angle_of_b;
+    o.xoff = xoff;
+    o.yoff = yoff;
+    const int eg = g_elem_grid(c, n);
+    const bool far = c->det_mode == BDOF_DET_FAR;
+    // a step after the last slice: variant tf_all, except in front of a far-field detector (|F P phi| = |H F phi| = |F phi|)
+    const bool prop_last = c->variant == BDOF_VARIANT_TF_ALL && !far;
+    double2* psi = c->c64_psi;
+    hipLaunchKernelGGL(k_c64_bcast, dim3(eg), dim3(256), 0, c->stream, c->c64_probe, psi, B, per);
+    for (int z = 0; z < S; ++z) {
+        Mod64Args m{psi, o, B, NX, NY, z, c->c64_k, c->c64_tape + (size_t)z * n};
+        hipLaunchKernelGGL(k_f64_modulate, dim3(eg), dim3(256), 0, c->stream, m);
+        if (z < S - 1 || prop_last)
+            if ((r = bdof_fields_free_step(c, psi, B, NX, NY, c->c64_h, 0, 1))) return r;
+    }
+    void* buf[1] = {psi};
+    if (c->det_mode == BDOF_DET_NEAR) { if ((r = bdof_fields_free_step(c, psi, B, NX, NY, c->c64_hdet, 0, 1))) return r; }
+    else if (far) RFC(c, rocfft_execute(pf, buf, nullptr, c->ginfo));       // un-shifted, un-normalised fft2
+    const int lgrid = std::min(eg, c->npartial);
+    hipLaunchKernelGGL(k_c64_loss, dim3(lgrid), dim3(256), 0, c->stream, psi, meas, c->partial, B, NX, NY, far ? 1 : 0, meas_ref, 2.0 / (double)n);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, lgrid, 1.0 / (double)n, c->loss_dev);
+    if (c->det_mode == BDOF_DET_NEAR) { if ((r = bdof_fields_free_step(c, psi, B, NX, NY, c->c64_hdet, 1, 1))) return r; }
+    else if (far) RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo));       // F^H: the un-normalised inverse
+    for (int z = S - 1; z >= 0; --z) {
+        if (z < S - 1 || prop_last)
+            if ((r = bdof_fields_free_step(c, psi, B, NX, NY, c->c64_h, 1, 1))) return r;
+        C64BwdArgs ba{psi, c->c64_tape + (size_t)z * n, c->grot, o, B, NX, NY, S, z, c->c64_k};
         hipLaunchKernelGGL(k_c64_bwd, dim3(eg), dim3(256), 0, c->stream, ba);
     }
     c->tape_valid = c->last_valid = false;

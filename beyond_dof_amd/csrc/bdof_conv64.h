@@ -9,6 +9,9 @@
 // padding constant does not depend on the object).  Everything else is point-wise, in double: modulation from the caller's
 // (delta, beta) rows, the corner-pixel renormalisation s = psi_0[0,0,0] / psi_S[0,0,0] (ONE scalar for the whole batch,
 // propagation.py:79,109-110) and its adjoint -sum(G conj q) / conj(P_000) into pixel (0,0,0), the magnitude loss and its seed.
+//
+// The transfer-function model of np_funcs.py:15-65 runs through the same point-wise kernels (bdof_loss_grad_tf_f64): the step
+// after a slice is then one transform pair on the field's own grid with H in float64, nothing is padded and nothing renormalised.
 #pragma once
 #include "bdof_field.h"
 
@@ -54,17 +57,17 @@ __global__ __launch_bounds__(256) void k_c64_scale(double2* f, size_t n, const d
         f[i] = make_double2(v.x * s.x - v.y * s.y, v.x * s.y + v.y * s.x);
     }
 }
-// loss partials and seed in place: d [B][N][N]; far: d is [b][kx][ky] and meas [b][ky][kx] (un-shifted), else both [b][x][y].
+// loss partials and seed in place: d [B][NX][NY]; far: d is [b][kx][ky] and meas [b][ky][kx] (un-shifted), else both [b][x][y].
 // meas holds m - meas_ref (residual splitting of the float32 path); G = 2 (|d| - m) d / |d| * seed_scale
-__global__ __launch_bounds__(256) void k_c64_loss(double2* d, const float* __restrict__ meas, double* partial, int B, int N, int far, double meas_ref,
-                                                 double seed_scale) {
-    const size_t n = (size_t)B * N * N;
+__global__ __launch_bounds__(256) void k_c64_loss(double2* d, const float* __restrict__ meas, double* partial, int B, int NX, int NY, int far,
+                                                 double meas_ref, double seed_scale) {
+    const size_t n = (size_t)B * NX * NY;
     double acc = 0.0, acc2 = 0.0;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int y = i % N;
-        const size_t r = i / N;
-        const int x = r % N, b = r / N;
-        const double m = (double)meas[far ? ((size_t)b * N + y) * N + x : i] + meas_ref;
+        const int y = i % NY;
+        const size_t r = i / NY;
+        const int x = r % NX, b = r / NX;
+        const double m = (double)meas[far ? ((size_t)b * NY + y) * NX + x : i] + meas_ref;
         const double2 v = d[i];
         const double a = sqrt(v.x * v.x + v.y * v.y);
         const double res = a - m;
@@ -110,23 +113,23 @@ __global__ void k_c64_corner_adj(double2* G, const double2* part, int npart, con
 }
 // point-wise adjoint of slice z: t = conj(phi) G; gradient rows (k Im t, -k Re t); G <- conj(c) G
 struct C64BwdArgs {
-    double2* G;             // [B][N][N] G(phi_z), overwritten by G(psi_z)
+    double2* G;             // [B][NX][NY] G(phi_z), overwritten by G(psi_z)
     const double2* phi;     // tape of slice z
-    float2* grot;           // [B][S][N][N]
+    float2* grot;           // [B][S][NX][NY]
     ObjView obj;            // .vol = (delta, beta) rows
-    int B, N, S, z;
+    int B, NX, NY, S, z;
     double k;
 };
 __global__ __launch_bounds__(256) void k_c64_bwd(C64BwdArgs a) {
-    const size_t n = (size_t)a.B * a.N * a.N;
+    const size_t n = (size_t)a.B * a.NX * a.NY;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int y = i % a.N;
-        const size_t r = i / a.N;
-        const int x = r % a.N, b = r / a.N;
+        const int y = i % a.NY;
+        const size_t r = i / a.NY;
+        const int x = r % a.NX, b = r / a.NX;
         const double2 g = a.G[i], p = a.phi[i];
         const double tx = p.x * g.x + p.y * g.y, ty = p.x * g.y - p.y * g.x;          // conj(phi) G
-        a.grot[(((size_t)b * a.S + a.z) * a.N + x) * a.N + y] = make_float2((float)(a.k * ty), (float)(-a.k * tx));
-        const float2 db = g_mod_value(a.obj, b, x, y, a.z, a.N);
+        a.grot[(((size_t)b * a.S + a.z) * a.NX + x) * a.NY + y] = make_float2((float)(a.k * ty), (float)(-a.k * tx));
+        const float2 db = g_mod_value(a.obj, b, x, y, a.z, a.NX);
         double s, cs;
         sincos(a.k * (double)db.x, &s, &cs);
         const double e = exp(-a.k * (double)db.y);

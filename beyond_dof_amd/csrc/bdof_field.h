@@ -185,6 +185,7 @@ struct Mod64Args {
     ObjView obj;         // .vol = the (delta, beta) rows themselves (not the float32 table of c - 1)
     int B, NX, NY, z;
     double k;
+    double2* tape;       // nullable: phi_z is stored here too (the float64 loss + gradient paths keep every slice's)
 };
 __global__ __launch_bounds__(256) void k_f64_modulate(Mod64Args a) {
     const size_t n = (size_t)a.B * a.NX * a.NY;
@@ -193,12 +194,17 @@ __global__ __launch_bounds__(256) void k_f64_modulate(Mod64Args a) {
         const size_t r = idx / a.NY;
         const int x = r % a.NX, b = r / a.NX;
         const float2 db = g_mod_value(a.obj, b, x, y, a.z, a.NX);
-        if (db.x == 0.f && db.y == 0.f) continue;                   // vacuum: c = 1
+        if (db.x == 0.f && db.y == 0.f) {                           // vacuum: c = 1
+            if (a.tape) a.tape[idx] = a.field[idx];
+            continue;
+        }
         double s, cs;
         sincos(a.k * (double)db.x, &s, &cs);
         const double e = exp(-a.k * (double)db.y);
         const double2 v = a.field[idx];
-        a.field[idx] = make_double2(e * (v.x * cs - v.y * s), e * (v.x * s + v.y * cs));
+        const double2 phi = make_double2(e * (v.x * cs - v.y * s), e * (v.x * s + v.y * cs));
+        a.field[idx] = phi;
+        if (a.tape) a.tape[idx] = phi;
     }
 }
 

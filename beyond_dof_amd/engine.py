@@ -88,6 +88,8 @@ class MultisliceEngine(object):
         self.k = k
         self._physics_args = (energy_ev, psize_cm, free_prop_cm, variant, pi)
         self._field_shape = field_shape
+        self._tf64_args = (hs64, free_prop_cm, lmbda_nm, voxel_nm, pi, float(k))
+        self.tf_f64 = False                     # a float64 twin bound before this call held the previous tables
         # tf_all + far field: the last transfer-function step only multiplies the far field by the
         # unit-modulus H (F P phi = H . F phi); libbdof skips it and the host applies it to returned waves
         self._far_phase = None
@@ -151,6 +153,7 @@ class MultisliceEngine(object):
 
     def set_probe(self, probe_real, probe_imag):
         self._probe_args = (np.array(probe_real, copy=True), np.array(probe_imag, copy=True))
+        self.tf_f64 = False                     # the float64 twin (enable_tf_f64) holds the previous probe
         probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.ny, self.nx))
         probe = probe.astype(np.complex64)                         # the reference rounds to complex64 too (np_funcs.py:20)
         # Carrier splitting: the wave is held as carrier + eps and only eps runs through the float32 transforms.
@@ -278,6 +281,28 @@ class MultisliceEngine(object):
         if getattr(self, '_probe_args', None) is not None:
             self.set_probe(*self._probe_args)      # the carrier (scalar or field) of the probe follows the propagator
 
+    def enable_tf_f64(self):
+        """The transfer-function model's loss + gradient entirely in float64 on this context (bdof_loss_grad_tf_f64;
+        loss_grad(..., f64=True)): what the reference's autograd differentiates (np_funcs.py:15-65 in numpy float64).  The
+        accuracy path of the first minibatch of an epoch (adjoint_precision='first-step') — no second engine — and a float64 twin
+        of the fused kernels for tests.  Hands the probe and the transfer function(s) over in float64; call again after
+        set_physics / set_probe."""
+        if getattr(self, '_tf64_args', None) is None or getattr(self, '_probe_args', None) is None:
+            raise RuntimeError('set_physics and set_probe first')
+        hs64, free_prop_cm, lmbda_nm, voxel_nm, pi, k = self._tf64_args
+        hd = None
+        if self.det_mode == _lib.DET_NEAR:
+            hd64 = util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi, dtype=np.complex128,
+                                                 kernel=self.det_kernel)
+            hd = np.ascontiguousarray(hd64.T)
+        ht = np.ascontiguousarray(hs64.T)                                       # [kx][ky]
+        pr, pi_ = self._probe_args
+        # the reference's wavefront starts as complex64 (np_funcs.py:20-21) and becomes complex128 at the first product
+        probe = np.ascontiguousarray(((np.asarray(pr) + 1j * np.asarray(pi_)) * np.ones((self.ny, self.nx))).T.astype(np.complex64)
+                                     .astype(np.complex128))
+        self.ctx.check(self.lib.bdof_set_tf_f64(self.h, probe.ctypes.data, ht.ctypes.data, hd.ctypes.data if hd is not None else None, k))
+        self.tf_f64 = True
+
     def enable_conv_f64(self):
         """The real-space propagator's loss + gradient entirely in float64 (bdof_loss_grad_conv_f64; loss_grad(..., conv=True,
         f64=True)): the accuracy path for the first minibatch of an epoch (adjoint_precision='first-step' / 'float64' with
@@ -367,17 +392,19 @@ class MultisliceEngine(object):
 
     # ---- loss + gradient -----------------------------------------------------------------------
     def loss_grad(self, B, meas_abs, angle_idx=None, xoff=None, yoff=None, meas_on_device=False, conv=False, f64=False):
-        """Runs forward + loss + adjoint; returns the loss.  The gradient stays on the device.  f64 (with conv): the float64
-        real-space path (enable_conv_f64)."""
+        """Runs forward + loss + adjoint; returns the loss.  The gradient stays on the device.  f64: the float64 path of the
+        model on the same context (enable_tf_f64 / with conv: enable_conv_f64)."""
         m = meas_abs if meas_on_device else self._meas_to_device(meas_abs)
         a = _idx_buf(self.ctx, angle_idx) if angle_idx is not None else None
         xo = _idx_buf(self.ctx, xoff) if xoff is not None else None
         yo = _idx_buf(self.ctx, yoff) if yoff is not None else None
         if f64:
-            if not (conv and getattr(self, 'conv_f64', False)):
-                raise RuntimeError('f64 is the real-space propagator\'s float64 path: conv=True after enable_conv_f64()')
-            self.ctx.check(self.lib.bdof_loss_grad_conv_f64(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), _lib._ptr(m),
-                                                            float(getattr(self, 'meas_ref', 0.0))))
+            if conv and not getattr(self, 'conv_f64', False):
+                raise RuntimeError('the real-space propagator\'s float64 path: enable_conv_f64() first')
+            if not conv and not getattr(self, 'tf_f64', False):
+                raise RuntimeError('the transfer-function model\'s float64 path: enable_tf_f64() first')
+            fn = self.lib.bdof_loss_grad_conv_f64 if conv else self.lib.bdof_loss_grad_tf_f64
+            self.ctx.check(fn(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), _lib._ptr(m), float(getattr(self, 'meas_ref', 0.0))))
         else:
             fn = self.lib.bdof_loss_grad_conv if conv else self.lib.bdof_loss_grad
             self.ctx.check(fn(self.h, B, _lib._ptr(a), _lib._ptr(xo), _lib._ptr(yo), _lib._ptr(m), None))

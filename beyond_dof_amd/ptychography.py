@@ -78,7 +78,8 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
     # the reference's own choice in this entry point, with `kernel_size` taps per axis
     propagator = kwargs.get('propagator', 'fft')
     # 'float64': the adjoint sweep in float64 (bdof_configure flag 64; with propagator='conv' both sweeps, bdof_loss_grad_conv_f64);
-    # 'first-step': in float64 for the first minibatch of every epoch only — Adam's first step after its per-epoch restart is
+    # 'first-step': the first minibatch of every epoch through the model's float64 path on the same context (bdof_loss_grad_tf_f64 /
+    # bdof_loss_grad_conv_f64: both sweeps in double, no second engine) — Adam's first step after its per-epoch restart is
     # lr g / (|g| + 1e-8), the one step in which the float32 rounding of the gradient reaches the volume
     # (the default with the transfer-function propagator: reconstructed delta within 2.1e-6 of the reference's float64 loop on golden
     # vector G17, 7.0e-6 with 'float32' — both inside 1e-5 since the kernels take dithered copies of the transfer function;
@@ -162,11 +163,11 @@ def reconstruct_ptychography(fname, probe_pos, probe_size, obj_size, theta_st=0,
                                        psize_cm * ds_level, probe_real, probe_imag, variant=variant, comm=comm, device=comm.local_rank,
                                        coord_ls=coord_ls, propagator=propagator, kernel_size=kwargs.get('kernel_size', 17),
                                        adjoint64={'float32': None, 'float64': True, 'first-step': 'first'}[prec])
-        # the DEFAULT's second engine (float64 adjoint sweep for the first minibatch of an epoch) is an accuracy refinement:
-        # where it does not fit beside the first one the run goes on in float32, SAYS so and records it (summary.txt:
-        # adjoint_precision_effective); an explicit request fails.  The retry runs outside the except block and after a
-        # collection: the exception's traceback holds the frame of PtychoSolver.__init__ — the first engine, its tape and the
-        # partly built second one — and would keep them on the device while the fallback allocates.
+        # the DEFAULT's float64 path (first minibatch of an epoch) is an accuracy refinement with buffers of its own (wave + tape in
+        # complex128, allocated when the solver is built): where they do not fit beside the engine's the run goes on in float32,
+        # SAYS so and records it (summary.txt: adjoint_precision_effective); an explicit request fails.  The retry runs outside the
+        # except block and after a collection: the exception's traceback holds the frame of PtychoSolver.__init__ — the engine, its
+        # tape and the partly allocated float64 buffers — and would keep them on the device while the fallback allocates.
         adjoint_precision_effective, setup_error = adjoint_precision, None
         try:
             solver = mk(adjoint_precision)

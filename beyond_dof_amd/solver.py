@@ -521,26 +521,21 @@ class PtychoSolver(_VolumeSolver):
         if self.conv:
             self.eng.set_conv(energy_ev, psize_cm, kernel_size)
         self.eng.set_probe(probe_real, probe_imag)
-        # adjoint64='first': a second engine with the float64 adjoint sweep for the FIRST minibatch of every epoch — Adam's first
-        # step after a restart is lr g / (|g| + 1e-8), the only one in which a 1e-8 error of the gradient moves a voxel by a
-        # fraction of a whole step; every later step runs on the fast engine
-        self.eng64 = None
-        # real-space propagator: its float64 path lives on the SAME context (bdof_loss_grad_conv_f64: whole sweeps in double,
-        # no second engine); conv64 = 'first' / True says when it runs
-        self.conv64 = None
-        if self.conv and adjoint64 in ('first', True):
+        # adjoint64='first': the FIRST minibatch of every epoch runs through the model's float64 path on the SAME context
+        # (bdof_loss_grad_tf_f64 / bdof_loss_grad_conv_f64: whole sweeps in double, no second engine) — Adam's first step after a
+        # restart is lr g / (|g| + 1e-8), the only one in which a 1e-8 error of the gradient moves a voxel by a fraction of a
+        # whole step; every later step runs on the fast engine.  f64 = 'first' / True says when it runs.
+        self.f64 = None
+        if adjoint64 == 'first' or (self.conv and adjoint64 is True):
             try:
-                self.eng.enable_conv_f64()
+                if self.conv:
+                    self.eng.enable_conv_f64()
+                else:
+                    self.eng.enable_tf_f64()
             except ValueError as err:                      # a probe the float64 path does not take: let the caller decide
                 from ._lib import BdofError
                 raise BdofError(str(err))
-            self.conv64 = adjoint64
-        elif adjoint64 == 'first':
-            self.eng64 = MultisliceEngine(self.py, self.px, self.dim_z, self.mb, with_grad=True, device=device, stream=stream, adjoint64=True)
-            self.eng64.set_physics(energy_ev, psize_cm, 'inf', variant=variant)
-            self.eng64.set_probe(probe_real, probe_imag)
-            if (getattr(self.eng64, 'meas_ref', 0.0) != getattr(self.eng, 'meas_ref', 0.0)) or self.eng64.det_mode != self.eng.det_mode:
-                raise RuntimeError('the two engines of one solver must lay the measurements out alike')
+            self.f64 = adjoint64
         elif adjoint64 not in (None, False, True):
             raise ValueError("adjoint64 must be None, False, True or 'first'")
         if coord_ls is None:
@@ -554,15 +549,7 @@ class PtychoSolver(_VolumeSolver):
         self.idx_buf = DeviceBuffer(self.ctx, 4 * self.mb * 4, np.int32, (4, self.mb))
         self._bind_volume()
         self.eng.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
-        if self.eng64 is not None:
-            self.eng64.set_rotation_adjoint(self.off, self.order, self.dim_x * self.dim_z)
         self._last = None
-        self._last_ctx = self.ctx
-
-    def _bind_volume(self):
-        _VolumeSolver._bind_volume(self)
-        if self.eng64 is not None:
-            self.eng64.set_volume(self.x[self.cur], self.dim_x * self.dim_z, self.dim_y, self.tab, self.dim_x, self.n_theta)
 
     def set_measurements(self, prj_abs_all):
         """All diffraction amplitudes |prj| (n_theta, n_pos, py, px) resident on the device (a cfg5-sized dataset is 0.75 GB):
@@ -594,32 +581,23 @@ class PtychoSolver(_VolumeSolver):
 
     def _win_loss_grad(self, i_theta, pos_idx, prj_abs_batch, use64=False):
         a, xo, yo = self._stage(i_theta, pos_idx, prj_abs_batch)
-        if self.conv and (self.conv64 is True or (use64 and self.conv64 == 'first')):
-            self.ctx.check(self.ctx.lib.bdof_loss_grad_conv_f64(self.ctx.handle, self.mb, a, xo, yo, self.meas_stage.ptr,
-                                                                float(getattr(self.eng, 'meas_ref', 0.0))))
-            self._last = (int(i_theta), xo, yo)
-            self._last_ctx = self.ctx
-            return
-        ctx = self.eng64.ctx if (use64 and self.eng64 is not None) else self.ctx
-        if ctx is not self.ctx:
-            self.ctx.sync()                          # the staging buffers and the volume were written on self.ctx's stream
-        fn = ctx.lib.bdof_loss_grad_conv if self.conv else ctx.lib.bdof_loss_grad
-        ctx.check(fn(ctx.handle, self.mb, a, xo, yo, self.meas_stage.ptr, None))
+        ctx = self.ctx
+        if self.f64 is True or (use64 and self.f64 == 'first'):
+            fn = ctx.lib.bdof_loss_grad_conv_f64 if self.conv else ctx.lib.bdof_loss_grad_tf_f64
+            ctx.check(fn(ctx.handle, self.mb, a, xo, yo, self.meas_stage.ptr, float(getattr(self.eng, 'meas_ref', 0.0))))
+        else:
+            fn = ctx.lib.bdof_loss_grad_conv if self.conv else ctx.lib.bdof_loss_grad
+            ctx.check(fn(ctx.handle, self.mb, a, xo, yo, self.meas_stage.ptr, None))
         self._last = (int(i_theta), xo, yo)
-        self._last_ctx = ctx
 
     def _produce_all(self):
-        ctx = self._last_ctx
         i_theta, xo, yo = self._last
         self._g_is_local()
-        ctx.check(ctx.lib.bdof_window_rotation_adjoint(ctx.handle, self.mb, i_theta, xo, yo, self.g.ptr, 0, 1.0))
-        if ctx is not self.ctx:
-            ctx.sync()                               # the tail of the step (exchange, Adam) runs on self.ctx's stream
+        self.ctx.check(self.ctx.lib.bdof_window_rotation_adjoint(self.ctx.handle, self.mb, i_theta, xo, yo, self.g.ptr, 0, 1.0))
 
     def _get_loss(self):
         loss = ctypes.c_double(0)
-        ctx = self._last_ctx
-        ctx.check(ctx.lib.bdof_get_loss(ctx.handle, ctypes.byref(loss)))
+        self.ctx.check(self.ctx.lib.bdof_get_loss(self.ctx.handle, ctypes.byref(loss)))
         return loss.value
 
     def loss_and_grad(self, i_theta, pos_idx, prj_abs_batch=None, want_loss=True):
@@ -636,7 +614,7 @@ class PtychoSolver(_VolumeSolver):
         """One Adam iteration of ptychography.py:301-310: loss_grad, Allreduce, /size, Adam, clip (no regulariser, no mask).
         The window/rotation adjoint produces the whole volume gradient in one pass; exchange and Adam are still slab-wise."""
         self._win_loss_grad(i_theta, pos_idx, prj_abs_batch,
-                            use64=(self.eng64 is not None or self.conv64 == 'first') and i_batch == 0 and self.probe is None)
+                            use64=self.f64 == 'first' and i_batch == 0 and self.probe is None)
         self._probe_collect()
         self._produce_all()
         self._tail(lambda x0, nx: None, i_batch, learning_rate, clip=clip, use_mask=False, n_slabs=n_slabs, sharded=sharded)

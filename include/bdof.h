@@ -277,6 +277,15 @@ int bdof_set_conv_probe_stack(bdof_ctx* ctx, const float* stack, const double* d
 int bdof_set_conv_f64(bdof_ctx* ctx, const double* probe, const double* khat, int ks, double ksum_re, double ksum_im, double k);
 int bdof_loss_grad_conv_f64(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas,
                             double meas_ref);
+/* The transfer-function model (cnn_propagator/np_funcs.py:15-65) in float64 on the same context: what autograd differentiates in
+ * the reference (cnn_propagator/ptychography.py:248,301; fullfield.py:329,345) — modulation from the (delta, beta) rows, the step
+ * after a slice as one rocFFT double-precision transform pair with H in float64, detector step (none / near field / far field),
+ * magnitude loss, adjoint sweep.  Unfused; the accuracy path for the first minibatch of an epoch (adjoint_precision='first-step')
+ * and a float64 twin of the fused kernels on the device.  bdof_set_tf_f64: probe host complex128 [NX][NY]; hT / hdetT (NULL
+ * without a near-field detector): host complex128 [kx][ky], ifftshift(H) / (NX NY); k as for bdof_set_physics.
+ * bdof_loss_grad_tf_f64: arguments as bdof_loss_grad_conv_f64; loss by bdof_get_loss, gradient rows in bdof_grot. */
+int bdof_set_tf_f64(bdof_ctx* ctx, const double* probe, const double* hT, const double* hdetT, double k);
+int bdof_loss_grad_tf_f64(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, double meas_ref);
 int bdof_forward_conv(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave);
 int bdof_loss_grad_conv(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, void* out_wave);
 void* bdof_grot(bdof_ctx* ctx);      /* device [B][S][NX][NY] pairs */

@@ -85,6 +85,34 @@ def test_forward_and_gradient_vs_oracle(engine_mod, Y, X, fp, variant):
     assert rel(gb, rgb) <= 2e-4
 
 
+@pytest.mark.parametrize('Y,X', [(64, 64), (72, 72), (64, 256)])
+@pytest.mark.parametrize('fp', [None, 1e-4, 'inf'])
+@pytest.mark.parametrize('variant', ['numpy_skip_last', 'tf_all'])
+def test_float64_transfer_function_path_vs_oracle(engine_mod, Y, X, fp, variant):
+    """bdof_loss_grad_tf_f64: the model of np_funcs.py:15-65 with every quantity in float64 on the device (modulation from the
+    (delta, beta) rows, rocFFT double-precision steps with H in float64, detector step, magnitude loss, adjoint sweep) — the path
+    of the first minibatch of an epoch under adjoint_precision='first-step', on the SAME context as the fused kernels — against
+    the float64 oracle.  The loss to 1e-10; the gradient rows are stored as float32 (6e-8); the object reaches the device as
+    float32 (delta, beta), so the oracle is given the rounded values."""
+    B, S = 2, 6
+    eng, delta, beta, pr, pi, rng = _case(engine_mod, B, Y, X, S, fp, variant, probe='gaussian' if fp == 'inf' else 'random')
+    delta, beta = delta.astype(np.float32).astype(np.float64), beta.astype(np.float32).astype(np.float64)
+    p64 = (np.asarray(pr) + 1j * np.asarray(pi)).astype(np.complex64)               # np_funcs.py:20-21
+    ref, _ = orc.multislice_propagate_batch_numpy(delta, beta, p64.real.astype(np.float64), p64.imag.astype(np.float64), 5000., 1e-7, fp,
+                                                  delta.shape, variant=variant, return_probe_array=False)
+    meas = (np.abs(ref) * (1 + 0.05 * rng.normal(size=ref.shape))).astype(np.float32).astype(np.float64)
+    rl, rgd, rgb = orc.multislice_loss_and_grad(delta, beta, p64.real.astype(np.float64), p64.imag.astype(np.float64), 5000., 1e-7, meas, fp,
+                                                variant)
+    eng.enable_tf_f64()
+    loss = eng.loss_grad(B, meas, f64=True)
+    gd, gb = eng.grad_batch_to_host(B)
+    e = (abs(loss - rl) / abs(rl), rel(gd, rgd), rel(gb, rgb))
+    l32 = eng.loss_grad(B, meas)
+    gd32, gb32 = eng.grad_batch_to_host(B)
+    print('float64 transfer-function path', (Y, X), fp, variant, e, ' fused float32 kernels:', (abs(l32 - rl) / abs(rl), rel(gd32, rgd), rel(gb32, rgb)))
+    assert e[0] <= 1e-8 and e[1] <= 2e-7 and e[2] <= 2e-7, e
+
+
 @pytest.mark.parametrize('probe,variant', [('plane', 'numpy_skip_last'), ('random', 'tf_all'), ('gaussian', 'numpy_skip_last')])
 def test_impulse_response_detector_kernel_on_the_device(engine_mod, golden_dir, probe, variant):
     """get_kernel_ir (cnn_propagator/util.py:105-127) as the detector step's multiplier — the branch of

@@ -195,8 +195,8 @@ def test_reconstruct_ptychography_vs_the_reference_loop_fft(tmp_path, monkeypatc
 
 
 def test_first_step_engine_that_cannot_be_set_up_is_reported_and_recorded(tmp_path, monkeypatch, capsys):
-    """The default adjoint_precision='first-step' builds a second engine; where that fails (it holds a float32 tape and float64
-    buffers of its own) the run continues in float32 — outside the 1e-5 bound — so it must SAY so and RECORD it: one message
+    """The default adjoint_precision='first-step' allocates the float64 path's wave and tape beside the engine's; where that fails
+    the run continues in float32 — with less margin under the 1e-5 bound — so it must SAY so and RECORD it: one message
     that names the consequence, `adjoint_precision_effective  float32` in summary.txt.  An explicit request fails instead."""
     import sys
     import __graft_entry__ as entry
@@ -297,7 +297,7 @@ def test_cfg5_solver_step_at_full_shape():
     assert np.abs(d1 - d0).max() <= 1.0001e-7                                             # Adam's first step: at most lr
 
 
-@pytest.mark.parametrize('model,adjoint64', [('fft', False), ('fft', True), ('conv', False)])
+@pytest.mark.parametrize('model,adjoint64', [('fft', False), ('fft', True), ('conv', False), ('conv', True)])
 def test_device_gradient_vs_directional_derivatives_of_the_reference_loss(model, adjoint64):
     """Golden vector G21: central differences of the REFERENCE's own calculate_loss (cnn_propagator/ptychography.py:30-81 executed
     at (64, 64, 64), first minibatch of the G17 / G14 runs; tests/golden/make_golden.py --g21) along six directions — numbers no
@@ -330,5 +330,6 @@ def test_device_gradient_vs_directional_derivatives_of_the_reference_loss(model,
           err.ravel())
     assert abs(loss - float(g[model + '_loss'])) <= 1e-5 * abs(loss)
     # measured: transfer-function model 7.7e-6 (float64 adjoint sweep 3.0e-6: the differences' own floor is 5e-6), real-space
-    # model 7.5e-5 (float32 kernel taps; far-field loss of a sigma-40 probe)
-    assert np.max(err) <= (1.5e-5 if model == 'fft' else 2e-4), (got, ref)
+    # model 7.5e-5 (float32 kernel taps; far-field loss of a sigma-40 probe) and, through the float64 real-space path of the same
+    # context (adjoint64=True: bdof_loss_grad_conv_f64, what the default 'first-step' runs once per epoch), at the differences' floor
+    assert np.max(err) <= (1.5e-5 if model == 'fft' or adjoint64 else 2e-4), (got, ref)

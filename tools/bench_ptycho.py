@@ -44,8 +44,8 @@ px = ps * ps
 print('probe %d^2, %d positions, %d slices: %.2f ms per Adam step, %.0f slice-steps/s, %.1f GB/s at the resident kernel\'s 40 B/px (%.3f of 8 TB/s)' %
       (ps, mb, n, dt * 1e3, mb * n / dt, 40.0 * px * mb * n / dt / 1e9, 40.0 * px * mb * n / dt / 8e12))
 
-# what adjoint_precision='first-step' (reconstruct_ptychography's default) adds: the first minibatch of every epoch on a second
-# engine with the float64 adjoint sweep (rocFFT double precision, unfused)
+# what adjoint_precision='first-step' (reconstruct_ptychography's default) adds: the first minibatch of every epoch through the
+# model's float64 path on the same context (bdof_loss_grad_tf_f64: rocFFT double precision, unfused)
 if os.environ.get('BDOF_BENCH_FIRST_STEP'):
     del s
     s = PtychoSolver([n, n, n], [ps, ps], pos, n_theta, mb, 5000., 1e-7, pr, pi, coord_ls=coords, adjoint64='first')
@@ -62,5 +62,5 @@ if os.environ.get('BDOF_BENCH_FIRST_STEP'):
         s.step(1, 1, np.arange(mb), None, 1e-7)
         s.ctx.sync()
         t2 = time.perf_counter()
-    print('first step of an epoch with the float64 adjoint sweep: %.1f ms (the following float32 step %.2f ms); %.1f GiB of HBM in use with both engines'
+    print('first step of an epoch through the float64 path: %.1f ms (the following float32 step %.2f ms); %.1f GiB of HBM in use with its buffers'
           % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, used))
