@@ -416,10 +416,19 @@ class FullfieldSolver(_VolumeSolver):
         self.ctx.check(lib.bdof_gather_fields(h, self.meas_stage.ptr, self.meas.ptr, self.angle_buf.ptr, self.mb,
                                               self.dim_x * self.dim_y * 4))
 
-    def _rot_loss_grad(self, angle_idx):
-        """Forward + adjoint sweeps of this rank's angles: the gradient w.r.t. the rotated objects stays in the ctx."""
+    def _rot_loss_grad(self, angle_idx, f64=False):
+        """Forward + adjoint sweeps of this rank's angles: the gradient w.r.t. the rotated objects stays in the ctx.
+        f64: through the transfer-function model's float64 path on the same context (bdof_loss_grad_tf_f64)."""
         lib, h = self.ctx.lib, self.ctx.handle
         self._stage_batch(angle_idx)
+        if f64:
+            if self.conv or self.bilinear:
+                raise ValueError("f64: the transfer-function model with the lookup-table rotation")
+            if not getattr(self.eng, 'tf_f64', False):
+                self.eng.enable_tf_f64()
+            self.ctx.check(lib.bdof_loss_grad_tf_f64(h, self.mb, self.angle_buf.ptr, None, None, self.meas_stage.ptr,
+                                                     float(getattr(self.eng, 'meas_ref', 0.0))))
+            return
         fn = lib.bdof_loss_grad_conv if self.conv else lib.bdof_loss_grad
         if self.bilinear:
             self._rotate_batch(angle_idx, self.mb)
@@ -437,9 +446,11 @@ class FullfieldSolver(_VolumeSolver):
                                                               nx * self.dim_z, int(accumulate), 1.0))
         return produce
 
-    def loss_and_grad(self, angle_idx, want_loss=True):
-        """Data-term loss and its gradient w.r.t. the volume for this rank's angles (left in self.g, not reduced)."""
-        self._rot_loss_grad(angle_idx)
+    def loss_and_grad(self, angle_idx, want_loss=True, f64=False):
+        """Data-term loss and its gradient w.r.t. the volume for this rank's angles (left in self.g, not reduced).  f64: both
+        sweeps through the model's float64 path (a float64 twin of the fused kernels on the same context, 3e-15 / 2.5e-8 from the
+        oracle at the sizes it reaches: tests/test_gpu_parity.py)."""
+        self._rot_loss_grad(angle_idx, f64=f64)
         self._g_is_local()
         self._produce()(0, self.dim_x)
         return self._get_loss() if want_loss else None

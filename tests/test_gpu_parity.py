@@ -503,6 +503,46 @@ def test_cfg2_full_size_fullfield_step_vs_oracle(engine_mod):
     assert rel(gd, rgd) <= 1e-4 and rel(gb, rgb) <= 1e-4
 
 
+_CFG3_COORDS = {}
+
+
+def _cfg3_coords(n, n_theta):
+    """The rotation tables of the 512^3 / 200-angle tests, computed once per session."""
+    if (n, n_theta) not in _CFG3_COORDS:
+        _CFG3_COORDS[(n, n_theta)] = orc.rotation_lookup([n, n, n], n_theta)
+    return _CFG3_COORDS[(n, n_theta)]
+
+
+def test_cfg3_whole_minibatch_vs_the_float64_twin(engine_mod):
+    """BASELINE configs[2] at the size bench.py times: the 512^3 volume, 200-angle tables, ALL 25 angles of one rank's minibatch
+    through 512 slices — loss and volume gradient of the fused float32 kernels against the float64 path on the same context
+    (bdof_loss_grad_tf_f64, itself 3e-15 / 2.5e-8 from the oracle where the oracle reaches:
+    test_float64_transfer_function_path_vs_oracle).  The oracle comparison at this size (two angles, a minute of host time) is
+    test_cfg3_full_size_solver_step_vs_oracle; this is the whole minibatch."""
+    from scipy.ndimage import uniform_filter
+    from beyond_dof_amd.solver import FullfieldSolver
+    n, n_theta, fp, mb = 512, 200, 1e-4, 25
+    rng = np.random.default_rng(3)
+    od = uniform_filter(rng.random((n, n, n)) * 2e-6, size=3, mode='wrap')
+    ob = 0.1 * od
+    idx = np.arange(mb) * 8 + 3                                   # 25 of the 200 angles, spread over the turn
+    s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=fp, coord_ls=_cfg3_coords(n, n_theta))
+    s.set_volume(od, ob)
+    del od, ob
+    prj = np.zeros((n_theta, n, n), dtype=np.float32)
+    prj[idx] = np.abs(s.forward_angles(idx)) * (1 + 0.05 * rng.normal(size=(mb, n, n)))
+    s.set_measurements(prj)
+    del prj
+    l32 = s.loss_and_grad(idx)
+    gd32, gb32 = s.gradient_to_host()
+    l64 = s.loss_and_grad(idx, f64=True)
+    gd64, gb64 = s.gradient_to_host()
+    e = (abs(l32 - l64) / abs(l64), rel(gd32, gd64), rel(gb32, gb64))
+    print('cfg3 whole minibatch (25 angles x 512 slices of 512^2), float32 kernels vs the float64 path: loss', e[0], 'gradient', e[1:],
+          ' HBM in use %.1f GiB' % (s.ctx.mem_used() / 2.0 ** 30))
+    assert e[0] <= 1e-6 and e[1] <= 1e-5 and e[2] <= 1e-5, e
+
+
 def test_cfg3_full_size_solver_step_vs_oracle(engine_mod):
     """BASELINE configs[2] through the SOLVER at its stated size (cnn_propagator/fullfield.py:340-362): 512^3 charcoal-like
     volume (bench.py's), the 200-angle rotation tables, a two-angle minibatch — rotation gather, forward through all 512
@@ -517,7 +557,7 @@ def test_cfg3_full_size_solver_step_vs_oracle(engine_mod):
     rng = np.random.default_rng(3)
     od = uniform_filter(rng.random((n, n, n)) * 2e-6, size=3, mode='wrap')
     ob = 0.1 * od
-    coords = orc.rotation_lookup([n, n, n], n_theta)
+    coords = _cfg3_coords(n, n_theta)
     idx = np.array([7, 134])
     one, zero = np.ones((n, n)), np.zeros((n, n))
     rot = np.stack([orc.apply_rotation(np.stack([od, ob], axis=3), coords[j]) for j in idx])
