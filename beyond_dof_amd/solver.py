@@ -611,10 +611,12 @@ class PtychoSolver(_VolumeSolver):
         self.ctx.check(self.ctx.lib.bdof_get_loss(self.ctx.handle, ctypes.byref(loss)))
         return loss.value
 
-    def loss_and_grad(self, i_theta, pos_idx, prj_abs_batch=None, want_loss=True):
+    def loss_and_grad(self, i_theta, pos_idx, prj_abs_batch=None, want_loss=True, f64=False):
         """prj_abs_batch: |this_prj_batch| (mb, py, px) for probe positions pos_idx at angle i_theta (None: from the resident
-        stack of set_measurements)."""
-        self._win_loss_grad(i_theta, pos_idx, prj_abs_batch)
+        stack of set_measurements).  f64: through the model's float64 path (solver built with adjoint64='first')."""
+        if f64 and self.f64 is None:
+            raise ValueError("f64: build the solver with adjoint64='first' (the float64 path's buffers are allocated there)")
+        self._win_loss_grad(i_theta, pos_idx, prj_abs_batch, use64=bool(f64))
         self._produce_all()
         return self._get_loss() if want_loss else None
 

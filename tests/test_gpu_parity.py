@@ -513,19 +513,21 @@ def _cfg3_coords(n, n_theta):
     return _CFG3_COORDS[(n, n_theta)]
 
 
-def test_cfg3_whole_minibatch_vs_the_float64_twin(engine_mod):
-    """BASELINE configs[2] at the size bench.py times: the 512^3 volume, 200-angle tables, ALL 25 angles of one rank's minibatch
-    through 512 slices — loss and volume gradient of the fused float32 kernels against the float64 path on the same context
-    (bdof_loss_grad_tf_f64, itself 3e-15 / 2.5e-8 from the oracle where the oracle reaches:
-    test_float64_transfer_function_path_vs_oracle).  The oracle comparison at this size (two angles, a minute of host time) is
-    test_cfg3_full_size_solver_step_vs_oracle; this is the whole minibatch."""
+@pytest.mark.parametrize('n,n_theta,mb', [(512, 200, 25), (256, 50, 50)], ids=['cfg3', 'cfg2'])
+def test_whole_minibatch_vs_the_float64_twin(engine_mod, n, n_theta, mb):
+    """BASELINE configs[2] at the size bench.py times — the 512^3 volume, 200-angle tables, ALL 25 angles of one rank's minibatch
+    through 512 slices — and configs[1] (256^3, all 50 angles in one minibatch): loss and volume gradient of the fused float32
+    kernels against the float64 path on the same context (bdof_loss_grad_tf_f64, itself 3e-15 / 2.5e-8 from the oracle where the
+    oracle reaches: test_float64_transfer_function_path_vs_oracle).  The oracle comparisons at these sizes (two angles, a minute
+    of host time) are test_cfg3_full_size_solver_step_vs_oracle / test_cfg2_full_size_fullfield_step_vs_oracle; this is the
+    whole minibatch."""
     from scipy.ndimage import uniform_filter
     from beyond_dof_amd.solver import FullfieldSolver
-    n, n_theta, fp, mb = 512, 200, 1e-4, 25
+    fp = 1e-4
     rng = np.random.default_rng(3)
     od = uniform_filter(rng.random((n, n, n)) * 2e-6, size=3, mode='wrap')
     ob = 0.1 * od
-    idx = np.arange(mb) * 8 + 3                                   # 25 of the 200 angles, spread over the turn
+    idx = np.arange(mb) * (n_theta // mb) + (3 if n_theta > mb else 0)      # spread over the turn
     s = FullfieldSolver(n, n, n, n_theta, mb, 5000., 1e-7, free_prop_cm=fp, coord_ls=_cfg3_coords(n, n_theta))
     s.set_volume(od, ob)
     del od, ob
@@ -538,7 +540,7 @@ def test_cfg3_whole_minibatch_vs_the_float64_twin(engine_mod):
     l64 = s.loss_and_grad(idx, f64=True)
     gd64, gb64 = s.gradient_to_host()
     e = (abs(l32 - l64) / abs(l64), rel(gd32, gd64), rel(gb32, gb64))
-    print('cfg3 whole minibatch (25 angles x 512 slices of 512^2), float32 kernels vs the float64 path: loss', e[0], 'gradient', e[1:],
+    print('whole minibatch (%d angles x %d slices of %d^2), float32 kernels vs the float64 path: loss' % (mb, n, n), e[0], 'gradient', e[1:],
           ' HBM in use %.1f GiB' % (s.ctx.mem_used() / 2.0 ** 30))
     assert e[0] <= 1e-6 and e[1] <= 1e-5 and e[2] <= 1e-5, e
 

@@ -268,11 +268,25 @@ def test_cfg5_solver_step_at_full_shape():
     del s3
     # (2) all 400 positions = the average of the two halves
     meas = (np.abs(rng.normal(1.0, 0.1, size=(n_theta, 400) + psz)) * 40).astype(np.float32)
-    s = PtychoSolver((n, n, n), psz, pos, n_theta, 400, 5000., 1e-7, prr, pii, coord_ls=coords)
+    s = PtychoSolver((n, n, n), psz, pos, n_theta, 400, 5000., 1e-7, prr, pii, coord_ls=coords, adjoint64='first')
     s.set_volume(od, ob)
     s.set_measurements(meas)
     l_all = s.loss_and_grad(i_theta, np.arange(400))
     g_all = s.gradient_to_host()
+    # (2b) ... and against the float64 path on the same context (bdof_loss_grad_tf_f64; 3e-15 / 2.5e-8 from the oracle at the sizes
+    # the oracle reaches, tests/test_gpu_parity.py): the whole 400-position minibatch of the LDS-resident kernel, on amplitudes
+    # the model can produce (its own diffraction patterns with 5 % noise).  With the random amplitudes above the float32 gradient is
+    # 4e-5 from the float64 one, and rightly so: they put a residual of 40 on detector pixels where the wave is 1e-7 of its
+    # peak, and the seed (|d| - m) d / |d| then needs the PHASE of a number that float32 transforms do not resolve.
+    consistent = (np.abs(s.forward(i_theta, np.arange(400))) * (1 + 0.05 * rng.normal(size=(400,) + psz))).astype(np.float32)
+    l32 = s.loss_and_grad(i_theta, np.arange(400), consistent)
+    g32 = s.gradient_to_host()
+    l64 = s.loss_and_grad(i_theta, np.arange(400), consistent, f64=True)
+    g64 = s.gradient_to_host()
+    e64 = (abs(l32 - l64) / abs(l64), rel(g32[0], g64[0]), rel(g32[1], g64[1]))
+    print('cfg5 whole minibatch, resident float32 kernel vs the float64 path: loss', e64[0], 'gradient', e64[1:])
+    assert e64[0] <= 1e-6 and e64[1] <= 1e-5 and e64[2] <= 1e-5, e64
+    del g32, g64
     h = PtychoSolver((n, n, n), psz, pos, n_theta, 200, 5000., 1e-7, prr, pii, coord_ls=coords)
     h.set_volume(od, ob)
     h.set_measurements(meas)
