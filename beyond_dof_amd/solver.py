@@ -448,8 +448,8 @@ class FullfieldSolver(_VolumeSolver):
 
     def loss_and_grad(self, angle_idx, want_loss=True, f64=False):
         """Data-term loss and its gradient w.r.t. the volume for this rank's angles (left in self.g, not reduced).  f64: both
-        sweeps through the model's float64 path (a float64 twin of the fused kernels on the same context, 3e-15 / 2.5e-8 from the
-        oracle at the sizes it reaches: tests/test_gpu_parity.py)."""
+        sweeps through the model's float64 path (a float64 twin of the fused kernels on the same context; the tests hold it to 3e-15 /
+        2.5e-8 of the host's float64 restatement at the sizes that reaches: tests/test_gpu_parity.py)."""
         self._rot_loss_grad(angle_idx, f64=f64)
         self._g_is_local()
         self._produce()(0, self.dim_x)
