@@ -72,10 +72,12 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
     # the reference's own choice in this entry point, with `kernel_size` taps per axis
     propagator = kwargs.get('propagator', 'fft')
     # 'float64': the adjoint sweep in float64 (bdof_configure flag 64, transfer-function propagator only) — follows the
-    # reference's float64 loop voxel by voxel where float32's 3e-6 on the gradient is too coarse
+    # reference's float64 loop voxel by voxel where float32's 3e-6 on the gradient is too coarse; 'first-step': the
+    # first minibatch of every epoch (Adam's restart: the one step in which a float32 gradient shows) through the model's float64
+    # path on the same context (bdof_loss_grad_tf_f64; needs room for a complex128 tape of one minibatch), the rest in float32
     adjoint_precision = kwargs.get('adjoint_precision', 'float32')
-    if adjoint_precision not in ('float32', 'float64'):
-        raise ValueError("adjoint_precision must be 'float32' or 'float64'")
+    if adjoint_precision not in ('float32', 'float64', 'first-step'):
+        raise ValueError("adjoint_precision must be 'float32', 'float64' or 'first-step'")
     # gradient accumulation over n_batch_per_update minibatches exists only in the TF twin (tensorflow_recon/fullfield.py:
     # 413-425); the cnn variant accepts the keyword and ignores it (default 5!), so it is opt-in here
     accumulate = bool(kwargs.get('accumulate_gradients', False))
@@ -175,7 +177,7 @@ def reconstruct_fullfield(fname, theta_st=0, theta_end=PI, n_epochs='auto', crit
         solver = FullfieldSolver(dim_y, dim_x, dim_z, n_theta, minibatch_size, energy_ev, psize_cm * ds_level,
                                  free_prop_cm=free_prop_cm, probe_real=probe_real, probe_imag=probe_imag, variant=variant,
                                  comm=comm, device=comm.local_rank, coord_ls=coord_ls, propagator=propagator, kernel_size=kernel_size,
-                                 rotation=rotation, theta=theta, adjoint64=adjoint_precision == 'float64',
+                                 rotation=rotation, theta=theta, adjoint64={'float32': None, 'float64': True, 'first-step': 'first'}[adjoint_precision],
                                  detector_kernel=kwargs.get('detector_kernel', 'TF'))   # 'IR' / 'auto': np_funcs.py:51-61
         solver.set_volume(obj_delta, obj_beta)
         solver.set_mask(mask)

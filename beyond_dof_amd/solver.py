@@ -343,8 +343,16 @@ class FullfieldSolver(_VolumeSolver):
         (bdof_rotate_bilinear), its adjoint is a gather (bdof_rotate_bilinear_adjoint)."""
         self.conv = propagator == 'conv'
         self.bilinear = rotation == 'bilinear'
+        if adjoint64 not in (None, False, True, 'first'):
+            raise ValueError("adjoint64 must be None, False, True or 'first'")
         if adjoint64 and self.conv:
             raise ValueError("adjoint64 (float64 adjoint sweep) runs with the transfer-function propagator only")
+        if adjoint64 == 'first' and rotation == 'bilinear':
+            raise ValueError("adjoint64='first' (the float64 path for the first minibatch of an epoch) runs with the lookup-table rotation")
+        # 'first': the first minibatch of every epoch through the model's float64 path on the same context (bdof_loss_grad_tf_f64),
+        # as PtychoSolver does it; True: the engine's float64 adjoint sweep on every minibatch
+        self.f64_first = adjoint64 == 'first'
+        adjoint64 = adjoint64 is True
         if rotation not in ('nearest', 'bilinear'):
             raise ValueError("rotation must be 'nearest' or 'bilinear'")
         if self.bilinear and theta is None:
@@ -361,6 +369,8 @@ class FullfieldSolver(_VolumeSolver):
         if probe_real is None:
             probe_real, probe_imag = np.ones((dim_y, dim_x)), np.zeros((dim_y, dim_x))   # 'plane', fullfield.py:276-278
         self.eng.set_probe(probe_real, probe_imag)
+        if self.f64_first:
+            self.eng.enable_tf_f64()                 # allocates the float64 wave + tape for the minibatch: fails here, not mid-run
         if self.bilinear:
             # per-angle projective transform of tf.contrib.image.rotate for images of height X and width Z, in float64
             th = np.asarray(theta, dtype=np.float64)
@@ -475,7 +485,7 @@ class FullfieldSolver(_VolumeSolver):
         n_batch_per_update > 1 (tensorflow_recon/fullfield.py:413-425,512-530): the volume gradient of consecutive
         minibatches is accumulated and applied (averaged) every n-th minibatch or at the last one of the epoch; the Adam
         bias-correction exponent then counts updates, not minibatches."""
-        self._rot_loss_grad(angle_idx)
+        self._rot_loss_grad(angle_idx, f64=self.f64_first and i_batch == 0 and getattr(self, 'probe', None) is None)
         self._probe_collect()
         nb = max(1, int(n_batch_per_update))
         if nb > 1:
