@@ -535,10 +535,18 @@ def test_whole_minibatch_vs_the_float64_twin(engine_mod, n, n_theta, mb):
     prj[idx] = np.abs(s.forward_angles(idx)) * (1 + 0.05 * rng.normal(size=(mb, n, n)))
     s.set_measurements(prj)
     del prj
+    import time
     l32 = s.loss_and_grad(idx)
     gd32, gb32 = s.gradient_to_host()
+    l64 = s.loss_and_grad(idx, f64=True)                          # (first call: rocFFT plans, buffers)
+    t0 = time.perf_counter()
     l64 = s.loss_and_grad(idx, f64=True)
+    t64 = time.perf_counter() - t0
     gd64, gb64 = s.gradient_to_host()
+    t0 = time.perf_counter()
+    s.loss_and_grad(idx)
+    t32 = time.perf_counter() - t0
+    print('loss + gradient of the minibatch: float32 kernels %.1f ms, float64 path %.1f ms' % (t32 * 1e3, t64 * 1e3))
     e = (abs(l32 - l64) / abs(l64), rel(gd32, gd64), rel(gb32, gb64))
     print('whole minibatch (%d angles x %d slices of %d^2), float32 kernels vs the float64 path: loss' % (mb, n, n), e[0], 'gradient', e[1:],
           ' HBM in use %.1f GiB' % (s.ctx.mem_used() / 2.0 ** 30))
