@@ -71,6 +71,7 @@ _SIGNATURES = {
     'bdof_set_conv_probe_stack': (ctypes.c_int, [_vp, _vp, _vp] + [ctypes.c_double] * 4),
     'bdof_set_conv_f64': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]),
     'bdof_loss_grad_conv_f64': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_double]),
+    'bdof_set_conv_f64_detector': (ctypes.c_int, [_vp, _vp]),
     'bdof_set_tf_f64': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_double]),
     'bdof_loss_grad_tf_f64': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_double]),
     'bdof_forward_conv': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp]),

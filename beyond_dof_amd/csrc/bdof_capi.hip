@@ -1898,17 +1898,33 @@ int bdof_set_conv_f64(bdof_ctx* c, const double* probe, const double* khat, int 
     return c64_room(c, c->Bmax, false, M);
 }
 
+// the step to a detector at a finite distance for the float64 real-space path (propagation.py:122-127: one transfer-function
+// step of the renormalised exit wave): hdetT host complex128 [kx][ky], ifftshift(H_det) / (NX NY); NULL removes it
+int bdof_set_conv_f64_detector(bdof_ctx* c, const double* hdetT) {
+    if (!c) return BDOF_ERR_ARG;
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)c->NX * c->NY;
+    if (!hdetT) { if (c->c64_hdet) (void)hipFree(c->c64_hdet); c->c64_hdet = nullptr; return 0; }
+    if (!c->c64_hdet) HIPC(c, hipMalloc(&c->c64_hdet, n * sizeof(double2)));
+    HIPC(c, hipMemcpy(c->c64_hdet, hdetT, n * sizeof(double2), hipMemcpyHostToDevice));
+    return 0;
+}
+
 // bdof_loss_grad_conv with every quantity in float64: loss left for bdof_get_loss, gradient rows in the ctx's rotated-frame
 // buffer (bdof_grot) like every other engine, so bdof_rotation_adjoint / bdof_window_rotation_adjoint follow unchanged.
 // meas: device float, laid out as for bdof_loss_grad_conv (far field: [b][ky][kx] un-shifted, else [b][x][y]); meas_ref: what
-// the host subtracted from the amplitudes (bdof_set_meas_mode 1), 0 otherwise.  Detector: none or far field.
+// the host subtracted from the amplitudes (bdof_set_meas_mode 1), 0 otherwise.  Detector: none, far field, or near field after
+// bdof_set_conv_f64_detector.
 int bdof_loss_grad_conv_f64(bdof_ctx* c, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, double meas_ref) {
     if (!c || !meas) return BDOF_ERR_ARG;
     if (!c->c64_ks || c->c64_tf) return fail(c, BDOF_ERR_STATE, "bdof_set_conv_f64 has not been called");
     if (!c->obj_src) return fail(c, BDOF_ERR_STATE, "bdof_set_object (with (delta, beta) rows) has not been called");
     if (!c->grot || !c->partial) return fail(c, BDOF_ERR_STATE, "bdof_configure(with_grad = 1) needed");
     if (B < 1 || B > c->Bmax) return fail(c, BDOF_ERR_ARG, "batch size outside [1, Bmax]");
-    if (c->det_mode == BDOF_DET_NEAR) return fail(c, BDOF_ERR_STATE, "the float64 real-space path has no near-field detector step");
+    if (c->det_mode == BDOF_DET_NEAR && !c->c64_hdet)
+        return fail(c, BDOF_ERR_STATE, "near-field detector: bdof_set_conv_f64_detector has not been called");
     if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
     HIPC(c, hipSetDevice(c->device));
     const int N = c->NX, ks = c->c64_ks, p = (ks - 1) / 2, M = N + ks - 1, S = c->S;
@@ -1943,11 +1959,14 @@ int bdof_loss_grad_conv_f64(bdof_ctx* c, int B, const int* angle_of_b, const int
     HIPC(c, hipMemcpyAsync(c->c64_q, psi, n * sizeof(double2), hipMemcpyDeviceToDevice, c->stream));
     const bool far = c->det_mode == BDOF_DET_FAR;
     void* buf[1] = {psi};
+    const bool near = c->det_mode == BDOF_DET_NEAR;
     if (far) RFC(c, rocfft_execute(pf, buf, nullptr, c->ginfo));           // un-shifted, un-normalised fft2 (propagation.py:114-115)
+    else if (near) { if ((r = bdof_fields_free_step(c, psi, B, N, N, c->c64_hdet, 0, 1))) return r; }      // propagation.py:122-124
     const int lgrid = std::min(eg, c->npartial);
     hipLaunchKernelGGL(k_c64_loss, dim3(lgrid), dim3(256), 0, c->stream, psi, meas, c->partial, B, N, N, far ? 1 : 0, meas_ref, 2.0 / (double)n);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, lgrid, 1.0 / (double)n, c->loss_dev);
     if (far) RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo));           // G(q) = N^2 ifft2(G(d)): the un-normalised inverse
+    else if (near) { if ((r = bdof_fields_free_step(c, psi, B, N, N, c->c64_hdet, 1, 1))) return r; }
     // adjoint of the renormalisation through the corner pixel
     const int dgrid = std::min(eg, c->ncu * 16);
     hipLaunchKernelGGL(k_c64_dot, dim3(dgrid), dim3(256), 0, c->stream, psi, c->c64_q, n, c->c64_part);

@@ -306,12 +306,12 @@ class MultisliceEngine(object):
     def enable_conv_f64(self):
         """The real-space propagator's loss + gradient entirely in float64 (bdof_loss_grad_conv_f64; loss_grad(..., conv=True,
         f64=True)): the accuracy path for the first minibatch of an epoch (adjoint_precision='first-step' / 'float64' with
-        propagator='conv').  Square fields, detector None or far field.  Hands the probe and the transform of the zero-padded
+        propagator='conv').  Square fields.  Hands the probe and the transform of the zero-padded
         ks x ks kernel over in float64 (overlap-save on the padded (N + ks - 1)^2 grid)."""
         if not getattr(self, '_conv_set', False) or getattr(self, '_probe_args', None) is None:
             raise RuntimeError('set_conv and set_probe first')
-        if self.nx != self.ny or self.det_mode == _lib.DET_NEAR:
-            raise ValueError('the float64 real-space path takes square wavefields and a detector at None or infinity')
+        if self.nx != self.ny:
+            raise ValueError('the float64 real-space path takes square wavefields')
         ky, kx, e = self._conv_kernel
         ks = len(ky)
         m = self.nx + ks - 1
@@ -323,6 +323,12 @@ class MultisliceEngine(object):
         probe = np.ascontiguousarray(((np.asarray(pr) + 1j * np.asarray(pi)) * np.ones((self.ny, self.nx))).T.astype(np.complex128))
         self.ctx.check(self.lib.bdof_set_conv_f64(self.h, probe.ctypes.data, khat.ctypes.data, ks, float(ksum.real), float(ksum.imag),
                                                   float(self._conv_k64)))
+        hd = None
+        if self.det_mode == _lib.DET_NEAR:                                       # propagation.py:122-124: one transfer-function step
+            _, free_prop_cm, lmbda_nm, voxel_nm, pi64, _ = self._tf64_args
+            hd = np.ascontiguousarray(util.device_transfer_function(free_prop_cm * 1e7, lmbda_nm, voxel_nm, self.ny, self.nx, pi=pi64,
+                                                                    dtype=np.complex128, kernel=self.det_kernel).T)
+        self.ctx.check(self.lib.bdof_set_conv_f64_detector(self.h, hd.ctypes.data if hd is not None else None))
         self.conv_f64 = True
 
     # ---- object --------------------------------------------------------------------------------

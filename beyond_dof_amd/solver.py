@@ -345,14 +345,13 @@ class FullfieldSolver(_VolumeSolver):
         self.bilinear = rotation == 'bilinear'
         if adjoint64 not in (None, False, True, 'first'):
             raise ValueError("adjoint64 must be None, False, True or 'first'")
-        if adjoint64 and self.conv:
-            raise ValueError("adjoint64 (float64 adjoint sweep) runs with the transfer-function propagator only")
-        if adjoint64 == 'first' and rotation == 'bilinear':
-            raise ValueError("adjoint64='first' (the float64 path for the first minibatch of an epoch) runs with the lookup-table rotation")
-        # 'first': the first minibatch of every epoch through the model's float64 path on the same context (bdof_loss_grad_tf_f64),
-        # as PtychoSolver does it; True: the engine's float64 adjoint sweep on every minibatch
-        self.f64_first = adjoint64 == 'first'
-        adjoint64 = adjoint64 is True
+        if adjoint64 and rotation == 'bilinear' and (self.conv or adjoint64 == 'first'):
+            raise ValueError("the float64 paths (adjoint64='first'; propagator='conv') run with the lookup-table rotation")
+        # 'first': the first minibatch of every epoch through the model's float64 path on the same context (bdof_loss_grad_tf_f64 /
+        # bdof_loss_grad_conv_f64), as PtychoSolver does it; True: every minibatch — the engine's float64 adjoint sweep
+        # (transfer-function model) or the float64 path (real-space model, which has no such sweep)
+        self.f64 = 'first' if adjoint64 == 'first' else (True if (adjoint64 is True and self.conv) else None)
+        adjoint64 = adjoint64 is True and not self.conv
         if rotation not in ('nearest', 'bilinear'):
             raise ValueError("rotation must be 'nearest' or 'bilinear'")
         if self.bilinear and theta is None:
@@ -369,8 +368,15 @@ class FullfieldSolver(_VolumeSolver):
         if probe_real is None:
             probe_real, probe_imag = np.ones((dim_y, dim_x)), np.zeros((dim_y, dim_x))   # 'plane', fullfield.py:276-278
         self.eng.set_probe(probe_real, probe_imag)
-        if self.f64_first:
-            self.eng.enable_tf_f64()                 # allocates the float64 wave + tape for the minibatch: fails here, not mid-run
+        if self.f64:                                 # allocates the float64 wave + tape for the minibatch: fails here, not mid-run
+            try:
+                if self.conv:
+                    self.eng.enable_conv_f64()
+                else:
+                    self.eng.enable_tf_f64()
+            except ValueError as err:
+                from ._lib import BdofError
+                raise BdofError(str(err))
         if self.bilinear:
             # per-angle projective transform of tf.contrib.image.rotate for images of height X and width Z, in float64
             th = np.asarray(theta, dtype=np.float64)
@@ -432,12 +438,14 @@ class FullfieldSolver(_VolumeSolver):
         lib, h = self.ctx.lib, self.ctx.handle
         self._stage_batch(angle_idx)
         if f64:
-            if self.conv or self.bilinear:
-                raise ValueError("f64: the transfer-function model with the lookup-table rotation")
-            if not getattr(self.eng, 'tf_f64', False):
+            if self.bilinear:
+                raise ValueError("f64: the float64 paths run with the lookup-table rotation")
+            if self.conv and not getattr(self.eng, 'conv_f64', False):
+                self.eng.enable_conv_f64()
+            if not self.conv and not getattr(self.eng, 'tf_f64', False):
                 self.eng.enable_tf_f64()
-            self.ctx.check(lib.bdof_loss_grad_tf_f64(h, self.mb, self.angle_buf.ptr, None, None, self.meas_stage.ptr,
-                                                     float(getattr(self.eng, 'meas_ref', 0.0))))
+            fn = lib.bdof_loss_grad_conv_f64 if self.conv else lib.bdof_loss_grad_tf_f64
+            self.ctx.check(fn(h, self.mb, self.angle_buf.ptr, None, None, self.meas_stage.ptr, float(getattr(self.eng, 'meas_ref', 0.0))))
             return
         fn = lib.bdof_loss_grad_conv if self.conv else lib.bdof_loss_grad
         if self.bilinear:
@@ -460,7 +468,7 @@ class FullfieldSolver(_VolumeSolver):
         """Data-term loss and its gradient w.r.t. the volume for this rank's angles (left in self.g, not reduced).  f64: both
         sweeps through the model's float64 path (a float64 twin of the fused kernels on the same context; the tests hold it to 3e-15 /
         2.5e-8 of the host's float64 restatement at the sizes that reaches: tests/test_gpu_parity.py)."""
-        self._rot_loss_grad(angle_idx, f64=f64)
+        self._rot_loss_grad(angle_idx, f64=f64 or self.f64 is True)
         self._g_is_local()
         self._produce()(0, self.dim_x)
         return self._get_loss() if want_loss else None
@@ -485,7 +493,7 @@ class FullfieldSolver(_VolumeSolver):
         n_batch_per_update > 1 (tensorflow_recon/fullfield.py:413-425,512-530): the volume gradient of consecutive
         minibatches is accumulated and applied (averaged) every n-th minibatch or at the last one of the epoch; the Adam
         bias-correction exponent then counts updates, not minibatches."""
-        self._rot_loss_grad(angle_idx, f64=self.f64_first and i_batch == 0 and getattr(self, 'probe', None) is None)
+        self._rot_loss_grad(angle_idx, f64=self.f64 is True or (self.f64 == 'first' and i_batch == 0 and getattr(self, 'probe', None) is None))
         self._probe_collect()
         nb = max(1, int(n_batch_per_update))
         if nb > 1:

@@ -273,10 +273,13 @@ int bdof_set_conv_probe_stack(bdof_ctx* ctx, const float* stack, const double* d
  * field), everything else point-wise in double.  bdof_set_conv_f64: probe host complex128 [NX][NY]; khat host complex128
  * [M][M], M = N + ks - 1: fft2 of the kernel zero-padded to M x M, transposed to [kx][ky], / M^2; ksum = sum of its taps; k as
  * for bdof_set_conv.  bdof_loss_grad_conv_f64: meas as for bdof_loss_grad_conv (+ meas_ref, what the host subtracted under
- * bdof_set_meas_mode(1)); loss by bdof_get_loss; gradient rows in bdof_grot.  Square fields; detector none or far field. */
+ * bdof_set_meas_mode(1)); loss by bdof_get_loss; gradient rows in bdof_grot.  Square fields; detector none or far field — a
+ * near-field detector (propagation.py:122-127: one transfer-function step of the renormalised exit wave) after
+ * bdof_set_conv_f64_detector(ctx, hdetT): host complex128 [kx][ky], ifftshift(H_det) / (NX NY). */
 int bdof_set_conv_f64(bdof_ctx* ctx, const double* probe, const double* khat, int ks, double ksum_re, double ksum_im, double k);
 int bdof_loss_grad_conv_f64(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas,
                             double meas_ref);
+int bdof_set_conv_f64_detector(bdof_ctx* ctx, const double* hdetT);
 /* The transfer-function model (cnn_propagator/np_funcs.py:15-65) in float64 on the same context: what autograd differentiates in
  * the reference (cnn_propagator/ptychography.py:248,301; fullfield.py:329,345) — modulation from the (delta, beta) rows, the step
  * after a slice as one rocFFT double-precision transform pair with H in float64, detector step (none / near field / far field),
