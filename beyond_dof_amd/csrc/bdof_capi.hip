@@ -1127,6 +1127,7 @@ int bdof_set_physics(bdof_ctx* c, double k, const float* hs, const float* hs_det
     if (det_mode < 0 || det_mode > 2 || variant < 0 || variant > 1) return fail(c, BDOF_ERR_ARG, "bad det_mode / variant");
     if (det_mode == BDOF_DET_NEAR && !hs_det) return fail(c, BDOF_ERR_ARG, "hs_det required for BDOF_DET_NEAR");
     const size_t bytes = sizeof(cf) * c->NX * c->NY;
+    c->c64_tf = false; c->c64_ks = 0;     // a float64 twin handed over before (bdof_set_tf_f64 / bdof_set_conv_f64) held the previous model
     HIPC(c, hipMemcpyAsync(c->hs, hs, bytes, hipMemcpyHostToDevice, c->stream));
     if (hs_det) {
         HIPC(c, hipMemcpyAsync(c->hdet, hs_det, bytes, hipMemcpyHostToDevice, c->stream));
@@ -1236,6 +1237,7 @@ int bdof_set_probe(bdof_ctx* c, const float* probe, double a0_re, double a0_im) 
     if (!c || !probe) return BDOF_ERR_ARG;
     if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
     HIPC(c, hipMemcpyAsync(c->probe, probe, sizeof(cf) * c->NX * c->NY, hipMemcpyHostToDevice, c->stream));
+    c->c64_tf = false; c->c64_ks = 0;     // a float64 twin handed over before (bdof_set_tf_f64 / bdof_set_conv_f64) held the previous model
     HIPC(c, hipStreamSynchronize(c->stream));
     c->a0 = std::complex<double>(a0_re, a0_im);
     c->res_dirty = true;
@@ -2191,6 +2193,7 @@ int bdof_set_conv(bdof_ctx* c, const float* ky, const float* kx, int ks, double 
     if (c->generic || c->NX % BDOF_CONV_TX || c->NY % BDOF_CONV_TY)
         return fail(c, BDOF_ERR_SIZE, "the conv propagator needs power-of-two wavefields (tiles are 32 x 64)");
     HIPC(c, hipSetDevice(c->device));
+    c->c64_tf = false; c->c64_ks = 0;     // a float64 twin handed over before (bdof_set_tf_f64 / bdof_set_conv_f64) held the previous model
     for (int i = 0; i < ks; ++i) {
         c->taps.ky[i] = make_float2(ky[2 * i], ky[2 * i + 1]);
         c->taps.kx[i] = make_float2(kx[2 * i], kx[2 * i + 1]);

@@ -89,7 +89,7 @@ class MultisliceEngine(object):
         self._physics_args = (energy_ev, psize_cm, free_prop_cm, variant, pi)
         self._field_shape = field_shape
         self._tf64_args = (hs64, free_prop_cm, lmbda_nm, voxel_nm, pi, float(k))
-        self.tf_f64 = False                     # a float64 twin bound before this call held the previous tables
+        self.tf_f64 = self.conv_f64 = False     # a float64 twin bound before this call held the previous tables
         # tf_all + far field: the last transfer-function step only multiplies the far field by the
         # unit-modulus H (F P phi = H . F phi); libbdof skips it and the host applies it to returned waves
         self._far_phase = None
@@ -153,7 +153,7 @@ class MultisliceEngine(object):
 
     def set_probe(self, probe_real, probe_imag):
         self._probe_args = (np.array(probe_real, copy=True), np.array(probe_imag, copy=True))
-        self.tf_f64 = False                     # the float64 twin (enable_tf_f64) holds the previous probe
+        self.tf_f64 = self.conv_f64 = False     # the float64 twins (enable_tf_f64 / enable_conv_f64) hold the previous probe
         probe = (np.asarray(probe_real) + 1j * np.asarray(probe_imag)) * np.ones((self.ny, self.nx))
         probe = probe.astype(np.complex64)                         # the reference rounds to complex64 too (np_funcs.py:20)
         # Carrier splitting: the wave is held as carrier + eps and only eps runs through the float32 transforms.

@@ -286,7 +286,9 @@ int bdof_set_conv_f64_detector(bdof_ctx* ctx, const double* hdetT);
  * magnitude loss, adjoint sweep.  Unfused; the accuracy path for the first minibatch of an epoch (adjoint_precision='first-step')
  * and a float64 twin of the fused kernels on the device.  bdof_set_tf_f64: probe host complex128 [NX][NY]; hT / hdetT (NULL
  * without a near-field detector): host complex128 [kx][ky], ifftshift(H) / (NX NY); k as for bdof_set_physics.
- * bdof_loss_grad_tf_f64: arguments as bdof_loss_grad_conv_f64; loss by bdof_get_loss, gradient rows in bdof_grot. */
+ * bdof_loss_grad_tf_f64: arguments as bdof_loss_grad_conv_f64; loss by bdof_get_loss, gradient rows in bdof_grot.
+ * bdof_set_physics, bdof_set_probe and bdof_set_conv drop what either float64 path was handed (it described the previous model):
+ * hand it over again after them, or the float64 calls fail with BDOF_ERR_STATE. */
 int bdof_set_tf_f64(bdof_ctx* ctx, const double* probe, const double* hT, const double* hdetT, double k);
 int bdof_loss_grad_tf_f64(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, const float* meas, double meas_ref);
 int bdof_forward_conv(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, void* out_wave);
