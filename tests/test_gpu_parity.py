@@ -272,6 +272,22 @@ def test_error_behaviour(engine_mod):
     rc = lib.bdof_adam_step(h, one.ptr, one.ptr, one.ptr, one.ptr, one.ptr, None, 2, 2, 2, 1.0, 0.0, 0.0, 0.0,
                             1e-3, 0.9, 0.999, 1e-8, 0, 1)
     assert rc != 0 and b'alias' in lib.bdof_last_error(h)
+    # a float64 twin describes the model it was handed: after the probe (or the physics) changed, the stale one is refused
+    g = engine_mod.MultisliceEngine(64, 64, 4, 2, with_grad=True)
+    g.set_physics(5000., 1e-7, None)
+    with pytest.raises(RuntimeError):
+        g.enable_tf_f64()                                          # no probe yet
+    g.set_probe(np.ones((64, 64)), np.zeros((64, 64)))
+    g.set_object_batch(np.zeros((2, 64, 64, 4)), np.zeros((2, 64, 64, 4)))
+    with pytest.raises(RuntimeError):
+        g.loss_grad(2, np.ones((2, 64, 64)), f64=True)             # not handed over
+    g.enable_tf_f64()
+    assert abs(g.loss_grad(2, np.ones((2, 64, 64)), f64=True)) <= 1e-20      # vacuum, unit wave, unit amplitudes
+    g.set_probe(0.5 * np.ones((64, 64)), np.zeros((64, 64)))
+    m = _lib.DeviceBuffer.from_host(g.ctx, np.ones((2, 64, 64), dtype=np.float32))
+    assert g.lib.bdof_loss_grad_tf_f64(g.h, 2, None, None, None, m.ptr, 0.0) != 0 and b'bdof_set_tf_f64' in g.lib.bdof_last_error(g.h)
+    g.enable_tf_f64()
+    assert abs(g.loss_grad(2, np.ones((2, 64, 64)), f64=True) - 0.25) <= 1e-12
 
 
 def test_fullfield_fused_rotation_and_adjoint(engine_mod):

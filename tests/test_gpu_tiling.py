@@ -75,6 +75,7 @@ def _torch_tiled_loss_grad(delta, beta, probe, meas, tile, halo, seg, taper, lon
     autograd: pins the device's hand-derived tiled adjoint.  long_range: with the correction of DESIGN §8 — per range
     new field = (the field's free-space step over the range) + stitch(tiles through the object - tiles through vacuum)."""
     import torch
+    torch.set_num_threads(8)          # a GPU box shows all of its host's cores and grants 16: the default pool oversubscribes them
     fy, fx, S = delta.shape
     voxel = np.array([1., 1., 1.])
     lmbda = 1240. / 5000.
@@ -85,8 +86,9 @@ def _torch_tiled_loss_grad(delta, beta, probe, meas, tile, halo, seg, taper, lon
     ramp = 0.5 - 0.5 * np.cos(np.pi * (np.arange(taper) + 0.5) / taper)
     w1[:taper], w1[tile - taper:] = ramp, ramp[::-1]
     win = torch.from_numpy(w1[:, None] * w1[None, :])
-    td = torch.tensor(delta, requires_grad=True)
-    tb = torch.tensor(beta, requires_grad=True)
+    # one leaf per slice: the gradient of a window cut then allocates (fy, fx) zeros, not (fy, fx, S) — 10 x faster at 1024^2 x 20
+    td = [torch.tensor(np.ascontiguousarray(delta[:, :, z]), requires_grad=True) for z in range(S)]
+    tb = [torch.tensor(np.ascontiguousarray(beta[:, :, z]), requires_grad=True) for z in range(S)]
     field = torch.tensor(probe.astype(np.complex64).astype(np.complex128))
     core = tile - 2 * halo
     oy, ox = orc.tile_origins(fy, tile, halo), orc.tile_origins(fx, tile, halo)
@@ -104,8 +106,8 @@ def _torch_tiled_loss_grad(delta, beta, probe, meas, tile, halo, seg, taper, lon
                     wfree = torch.fft.ifft2(torch.fft.fft2(w) * torch.from_numpy(h.numpy() ** nz))
                 inside = torch.from_numpy((((ry >= 0) & (ry < fy))[:, None] & ((rx >= 0) & (rx < fx))[None, :]).astype(np.float64))
                 for z in range(z0, z0 + nz):
-                    d = td[:, :, z][iy][:, ix] * inside
-                    b = tb[:, :, z][iy][:, ix] * inside
+                    d = td[z][iy][:, ix] * inside
+                    b = tb[z][iy][:, ix] * inside
                     w = w * torch.exp(1j * k * d) * torch.exp(-k * b)
                     w = torch.fft.ifft2(torch.fft.fft2(w) * h)
                 ny_c, nx_c = min(core, fy - (y0 + halo)), min(core, fx - (x0 + halo))
@@ -118,7 +120,8 @@ def _torch_tiled_loss_grad(delta, beta, probe, meas, tile, halo, seg, taper, lon
         field = new
     loss = torch.mean((torch.abs(field) - torch.from_numpy(meas)) ** 2)
     loss.backward()
-    return loss.item(), td.grad.numpy(), tb.grad.numpy(), field.detach().numpy()
+    return (loss.item(), np.stack([t.grad.numpy() for t in td], axis=2), np.stack([t.grad.numpy() for t in tb], axis=2),
+            field.detach().numpy())
 
 
 def test_tiled_gradient_vs_autograd_of_the_algorithm():
