@@ -33,6 +33,37 @@ __global__ void k_calib_copy16(const float4* in, float4* out, size_t n) {      /
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
 }
 
+// read-only and write-only ceilings (the rotation adjoint is 96 % reads, the tape is written once)
+__global__ void k_calib_read16(const float4* in, float* out, size_t n) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = in[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 123.456f) out[0] = acc.x;
+}
+// the same with four independent 16-byte loads per lane in flight
+__global__ void k_calib_read16x4(const float4* in, float* out, size_t n) {
+    float4 acc[4];
+    for (auto& a : acc) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = in[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[k].x += v[k].x; acc[k].y += v[k].y; acc[k].z += v[k].z; acc[k].w += v[k].w; }
+    }
+    for (; i < n; i += stride) { const float4 v = in[i]; acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w; }
+    float t = 0.f;
+    for (auto& a : acc) t += a.x + a.y + a.z + a.w;
+    if (t == 123.456f) out[0] = t;
+}
+__global__ void k_calib_write16(float4* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
 static int balanced(int tiles, int cap) { if (tiles <= cap) return tiles; int r = (tiles + cap - 1) / cap; return (tiles + r - 1) / r; }
 
 int main(int argc, char** argv) {
@@ -78,6 +109,14 @@ int main(int argc, char** argv) {
         printf("calib copy8  1 GiB read + 1 GiB write: %8.2f us  %7.1f GB/s\n", ms * 1e3, 2.0 * nb / ms / 1e6);
         ms = time_it([&] { hipLaunchKernelGGL(k_calib_copy16, dim3(ncu * 8), dim3(256), 0, 0, (const float4*)ca, (float4*)cb, nb / 16); }, 3);
         printf("calib copy16 1 GiB read + 1 GiB write: %8.2f us  %7.1f GB/s\n", ms * 1e3, 2.0 * nb / ms / 1e6);
+        for (int g : {8, 16, 32}) {
+            ms = time_it([&] { hipLaunchKernelGGL(k_calib_read16, dim3(ncu * g), dim3(256), 0, 0, (const float4*)ca, (float*)cb, nb / 16); }, 3);
+            printf("calib read16   1 GiB read  (grid %2d x CUs): %8.2f us  %7.1f GB/s\n", g, ms * 1e3, 1.0 * nb / ms / 1e6);
+            ms = time_it([&] { hipLaunchKernelGGL(k_calib_read16x4, dim3(ncu * g), dim3(256), 0, 0, (const float4*)ca, (float*)cb, nb / 16); }, 3);
+            printf("calib read16x4 1 GiB read  (grid %2d x CUs): %8.2f us  %7.1f GB/s\n", g, ms * 1e3, 1.0 * nb / ms / 1e6);
+        }
+        ms = time_it([&] { hipLaunchKernelGGL(k_calib_write16, dim3(ncu * 8), dim3(256), 0, 0, (float4*)cb, nb / 16); }, 3);
+        printf("calib write16  1 GiB write: %8.2f us  %7.1f GB/s\n", ms * 1e3, 1.0 * nb / ms / 1e6);
         CK(hipFree(ca)); CK(hipFree(cb));
     }
     const int tiles = B * N / RowCfg<N>::TILE;
