@@ -64,6 +64,18 @@ __global__ void k_calib_write16(float4* out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = make_float4(1.f, 2.f, 3.f, 4.f);
 }
 
+template <class T> __global__ void k_calib_write(T* out, size_t n, T v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = v;
+}
+template <class T> __global__ void k_calib_write_nt(T* out, size_t n, T v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) __builtin_nontemporal_store(v, out + i);
+}
+// each workgroup writes its own contiguous chunk (rows of 4 KB one after the other), not a grid-stride interleave
+template <class T> __global__ void k_calib_write_chunk(T* out, size_t n, T v) {
+    const size_t per = (n + gridDim.x - 1) / gridDim.x, i0 = per * blockIdx.x, i1 = i0 + per < n ? i0 + per : n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) out[i] = v;
+}
+
 static int balanced(int tiles, int cap) { if (tiles <= cap) return tiles; int r = (tiles + cap - 1) / cap; return (tiles + r - 1) / r; }
 
 int main(int argc, char** argv) {
@@ -117,6 +129,18 @@ int main(int argc, char** argv) {
         }
         ms = time_it([&] { hipLaunchKernelGGL(k_calib_write16, dim3(ncu * 8), dim3(256), 0, 0, (float4*)cb, nb / 16); }, 3);
         printf("calib write16  1 GiB write: %8.2f us  %7.1f GB/s\n", ms * 1e3, 1.0 * nb / ms / 1e6);
+        for (int g : {4, 8, 16}) {
+            ms = time_it([&] { hipLaunchKernelGGL(k_calib_write<float>, dim3(ncu * g), dim3(256), 0, 0, (float*)cb, nb / 4, 1.f); }, 3);
+            printf("calib write  4 B/lane (grid %2d x CUs): %7.1f GB/s", g, 1.0 * nb / ms / 1e6);
+            ms = time_it([&] { hipLaunchKernelGGL(k_calib_write<float2>, dim3(ncu * g), dim3(256), 0, 0, (float2*)cb, nb / 8, make_float2(1.f, 2.f)); }, 3);
+            printf("   8 B/lane: %7.1f GB/s", 1.0 * nb / ms / 1e6);
+            ms = time_it([&] { hipLaunchKernelGGL(k_calib_write<float4>, dim3(ncu * g), dim3(256), 0, 0, (float4*)cb, nb / 16, make_float4(1.f, 2.f, 3.f, 4.f)); }, 3);
+            printf("   16 B/lane: %7.1f GB/s", 1.0 * nb / ms / 1e6);
+            ms = time_it([&] { hipLaunchKernelGGL(k_calib_write_nt<float>, dim3(ncu * g), dim3(256), 0, 0, (float*)cb, nb / 4, 1.f); }, 3);
+            printf("   non-temporal 4 B: %7.1f", 1.0 * nb / ms / 1e6);
+            ms = time_it([&] { hipLaunchKernelGGL(k_calib_write_chunk<float2>, dim3(ncu * g), dim3(256), 0, 0, (float2*)cb, nb / 8, make_float2(1.f, 2.f)); }, 3);
+            printf("   8 B/lane, a contiguous chunk per workgroup: %7.1f GB/s\n", 1.0 * nb / ms / 1e6);
+        }
         CK(hipFree(ca)); CK(hipFree(cb));
     }
     const int tiles = B * N / RowCfg<N>::TILE;
