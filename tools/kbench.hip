@@ -178,6 +178,15 @@ int main(int argc, char** argv) {
             best[2] = std::min(best[2], time_it([&] { hipLaunchKernelGGL((kv_prop_order<N, 2>), dim3(g), dim3(BDOF_THREADS), 0, 0, pa); }, iters));
         }
         printf("tile order (grid %d, %d tiles): round-robin %6.2f us   adjacent pairs %6.2f us   pairs of pairs per XCD %6.2f us\n", g, tiles, best[0] * 1e3, best[1] * 1e3, best[2] * 1e3);
+        {   // which side should carry the transposition? (memory-only skeletons, alternated, best of 7; same-buffer = Infinity Cache
+            // resident like the sweep's wavefields, then the ring of fresh buffers)
+            float bs[2] = {1e9f, 1e9f};
+            for (int rep = 0; rep < 7; ++rep) {
+                bs[0] = std::min(bs[0], time_it([&] { hipLaunchKernelGGL((kv_prop_side<N, 0>), dim3(g), dim3(BDOF_THREADS), 0, 0, pa); }, iters));
+                bs[1] = std::min(bs[1], time_it([&] { hipLaunchKernelGGL((kv_prop_side<N, 1>), dim3(g), dim3(BDOF_THREADS), 0, 0, pa); }, iters));
+            }
+            printf("memory-only skeleton: rows in, 128-byte segments out (production) %6.2f us   128-byte segments in, rows out %6.2f us\n", bs[0] * 1e3, bs[1] * 1e3);
+        }
         // the same with every launch on fresh buffers (a ring of 8 x in/out: 840 MB, beyond the Infinity Cache), as the sweep sees them
         const int ring = 8;
         cf *rin, *rout;
@@ -193,6 +202,17 @@ int main(int argc, char** argv) {
         };
         for (int rep = 0; rep < 7; ++rep)
             for (int o = 0; o < 3; ++o) bst[o] = std::min(bst[o], time_it([&] { launch(o); }, iters));
+        {
+            float bs[2] = {1e9f, 1e9f};
+            auto launch2 = [&](int side) {
+                RowPropArgs q = pa; q.in = rin + fld * (turn % ring); q.out = rout + fld * (turn % ring); ++turn;
+                if (side == 0) hipLaunchKernelGGL((kv_prop_side<N, 0>), dim3(g), dim3(BDOF_THREADS), 0, 0, q);
+                else hipLaunchKernelGGL((kv_prop_side<N, 1>), dim3(g), dim3(BDOF_THREADS), 0, 0, q);
+            };
+            for (int rep = 0; rep < 7; ++rep)
+                for (int o = 0; o < 2; ++o) bs[o] = std::min(bs[o], time_it([&] { launch2(o); }, iters));
+            printf("  skeletons on the ring: production direction %6.2f us   transposed reads %6.2f us\n", bs[0] * 1e3, bs[1] * 1e3);
+        }
         printf("  on a ring of %d buffer pairs:    round-robin %6.2f us   adjacent pairs %6.2f us   pairs of pairs per XCD %6.2f us\n", ring, bst[0] * 1e3, bst[1] * 1e3, bst[2] * 1e3);
         return 0;
     }

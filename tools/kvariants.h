@@ -146,3 +146,78 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void kv_prop_o
         __syncthreads();
     }
 }
+
+// Memory-only skeleton with the transposition on the LOAD side (round 4 question: stores like one contiguous piece per workgroup —
+// 5.9 against 4.5-5.0 TB/s in the calibration kernels — so would "strided 128-byte reads, whole-row writes" beat the production
+// "whole-row reads, strided 128-byte writes"?).  Tile = 16 lines (columns of the input, 128-byte segments of every one of its
+// N rows) -> LDS -> 16 whole output rows.  TREAD 0: the production direction (as kv_prop MODE 1), 1: transposed reads.
+template <int NX, int TREAD>
+__global__ __launch_bounds__(BDOF_THREADS, RowCfg<NX>::MIN_WAVES) void kv_prop_side(RowPropArgs a) {
+    typedef RowCfg<NX> C;
+    __shared__ cf smem[C::LDS_CF];
+    const int tid = threadIdx.x % C::T, rl = threadIdx.x / C::T;
+    const int ntiles = a.B * a.NY / C::TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * C::TILE;
+        const int b = row0 / a.NY, ky0 = row0 - b * a.NY;
+        if (TREAD) {
+            // in: [b][x][ky] (ld = NY); line r of the tile = column ky0 + r; element j + m T of the line = row j + m T
+            const cf* src = a.in + (size_t)b * NX * a.NY + ky0;
+#pragma nounroll
+            for (int pass = 0; pass < C::PASSES; ++pass) {
+                const int q = threadIdx.x + pass * BDOF_THREADS;
+                const int r = q % C::TILE, j = q / C::TILE;
+                RowLds<C::T> lds{smem + r * C::RS};
+                const int bs = lds.slot(j);
+                cf u[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) u[m] = src[(size_t)(j + m * C::T) * a.NY + r];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) lds.st_at(bs, m * C::T, u[m]);
+            }
+            __syncthreads();
+#pragma nounroll
+            for (int pass = 0; pass < C::PASSES; ++pass) {
+                const int r = pass * C::RPP + rl;
+                RowLds<C::T> lds{smem + r * C::RS};
+                const cf* hrow = a.h + (size_t)(ky0 + r) * NX;
+                cf* dst = a.out + (size_t)(row0 + r) * NX;
+                const int bs = lds.slot(tid);
+                cf hv[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) hv[m] = hrow[tid + m * C::T];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) dst[tid + m * C::T] = cmul(lds.ld_at(bs, m * C::T), hv[m]);
+            }
+            __syncthreads();
+        } else {
+#pragma nounroll
+            for (int pass = 0; pass < C::PASSES; ++pass) {
+                const int r = pass * C::RPP + rl;
+                RowLds<C::T> lds{smem + r * C::RS};
+                cf u[8], hv[8];
+                const cf* src = a.in + (size_t)(row0 + r) * NX;
+                const cf* hrow = a.h + (size_t)(ky0 + r) * NX;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) u[m] = src[tid + m * C::T];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) hv[m] = hrow[tid + m * C::T];
+                const int bs = lds.slot(tid);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) lds.st_at(bs, m * C::T, cmul(u[m], hv[m]));
+            }
+            __syncthreads();
+#pragma nounroll
+            for (int pass = 0; pass < C::PASSES; ++pass) {
+                const int q = threadIdx.x + pass * BDOF_THREADS;
+                const int r = q % C::TILE, j = q / C::TILE;
+                RowLds<C::T> lds{smem + r * C::RS};
+                cf* dst = a.out + (size_t)b * NX * a.NY + ky0;
+                const int bs = lds.slot(j);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) dst[(size_t)(j + m * C::T) * a.NY + r] = lds.ld_at(bs, m * C::T);
+            }
+            __syncthreads();
+        }
+    }
+}
