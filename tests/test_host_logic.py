@@ -166,6 +166,19 @@ def test_point_probe_is_refused_by_both_entry_points(tmp_path):
                               initial_guess=[np.zeros((8, 8, 8)), np.zeros((8, 8, 8))])
 
 
+def test_adjoint_precision_values_are_checked_before_anything_touches_a_gpu(tmp_path):
+    """adjoint_precision: 'float32' | 'float64' | 'first-step' in both entry points (the first minibatch of an epoch through the
+    model's float64 path); anything else is a ValueError at the top of the call."""
+    import pytest
+    from beyond_dof_amd.fullfield import reconstruct_fullfield
+    from beyond_dof_amd.ptychography import reconstruct_ptychography
+    with pytest.raises(ValueError, match='adjoint_precision'):
+        reconstruct_fullfield('data.h5', save_path=str(tmp_path), n_epochs=1, minibatch_size=1, adjoint_precision='double')
+    with pytest.raises(ValueError, match='adjoint_precision'):
+        reconstruct_ptychography('data.h5', [(4, 4)], (4, 4), (8, 8, 8), save_path=str(tmp_path), n_epochs=1, minibatch_size=1,
+                                 adjoint_precision='first')
+
+
 def test_detector_kernel_choice_and_impulse_response_table(golden_dir):
     """SURVEY §8 a3 on the host: 'TF' / 'IR' / 'auto' for the detector step (cnn_propagator/np_funcs.py:51-61: the criterion is
     computed there and then overridden with 'TF'); the device table of the 'IR' choice is get_kernel_ir (golden vector G8) in
