@@ -65,8 +65,10 @@ res['whole_field_float32_vs_float64'] = rel(whole, ref)
 print('whole field float32 (rocFFT engine): %.1f ms, %.2e from float64' % (dt_whole * 1e3, res['whole_field_float32_vs_float64']), flush=True)
 del eng, vol, out, whole
 
-plans = [('default: float32 tiles + long-range correction, float64 field', dict(tile=512, halo=64)),
+plans = [('default: float32 tiles + long-range correction, float64 field', dict(tile=512)),        # halo='auto': 24 pixels
+         ('the same, halo 64 (the halo of plain stitching)', dict(tile=512, halo=64)),
          ('the same, halo 32', dict(tile=512, halo=32)),
+         ('the same, halo 16', dict(tile=512, halo=16)),
          ('float32 tiles, no correction (round 3 plan)', dict(tile=512, halo=64, long_range=False)),
          ('float64 tiles + correction', dict(tile=512, halo=64, precision='float64')),
          ('1024^2 tiles, halo 64', dict(tile=1024, halo=64))]
@@ -82,7 +84,7 @@ for name, kw in plans:
     tp.forward_device()
     tp.ctx.sync()
     dt = time.perf_counter() - t0
-    run = {'plan': name, 'tile': kw['tile'], 'halo': kw['halo'], 'tiles': tp.n_tiles, 'slices_per_exchange': tp.seg, 'ranges': len(tp.segments()),
+    run = {'plan': name, 'tile': kw['tile'], 'halo': tp.halo, 'tiles': tp.n_tiles, 'slices_per_exchange': tp.seg, 'ranges': len(tp.segments()),
            'long_range': tp.long_range, 'precision': tp.precision, 'ms': dt * 1e3, 'wave_vs_float64': rel(o, ref),
            'intensity_vs_float64': rel(np.abs(o) ** 2, np.abs(ref) ** 2)}
     res['runs'].append(run)
@@ -94,7 +96,8 @@ if out_json:
 
 # ---- forward + adjoint through the tiles (variant tf_all; tape-free range sweeps) --------------------------------------------
 if os.environ.get('CFG4_GRAD'):
-    for name, kw in (('corrected model', dict(tile=512, halo=64)), ('no correction', dict(tile=512, halo=64, long_range=False))):
+    for name, kw in (('corrected model', dict(tile=512)), ('corrected model, halo 64', dict(tile=512, halo=64)),
+                     ('no correction', dict(tile=512, halo=64, long_range=False))):
         tp = TiledPropagator((n, n), S, 5000., 1e-7, variant='tf_all', with_grad=True, **kw)
         tp.set_object_slab(slab, 0.1 * slab)
         exit_wave = tp.forward(pr, zero)
