@@ -179,6 +179,22 @@ def test_adjoint_precision_values_are_checked_before_anything_touches_a_gpu(tmp_
                                  adjoint_precision='first')
 
 
+def test_tiled_propagator_auto_halo():
+    """TiledPropagator(halo='auto') (host arithmetic only): 64 pixels for plain stitching; with the long-range correction twice the
+    band edge's reach over one 16-slice range plus 16 pixels — 24 at 5 keV / 1 nm (cfg4: 81 tiles of 512^2 on the 4096^2 field)."""
+    from beyond_dof_amd.tiling import TiledPropagator
+
+    class Probe(TiledPropagator):
+        def __init__(self, n_slice, tile):
+            self.n_slice, self.tile = n_slice, tile
+    assert Probe(1024, 512)._auto_halo(5000., 1e-7, 0.5, None, 'auto', None) == 24
+    assert Probe(1024, 512)._auto_halo(5000., 1e-7, 0.5, None, False, None) == 64
+    assert Probe(96, 512)._auto_halo(5000., 1e-7, 0.5, None, 'auto', None) == 64            # one plain range: no correction
+    assert Probe(1024, 128)._auto_halo(5000., 1e-7, 0.5, None, 'auto', None) == 24
+    assert Probe(1024, 64)._auto_halo(5000., 1e-7, 0.5, None, True, None) == 16             # never more than a quarter of the tile
+    assert (-(-4096 // (512 - 2 * 24))) ** 2 == 81
+
+
 def test_detector_kernel_choice_and_impulse_response_table(golden_dir):
     """SURVEY §8 a3 on the host: 'TF' / 'IR' / 'auto' for the detector step (cnn_propagator/np_funcs.py:51-61: the criterion is
     computed there and then overridden with 'TF'); the device table of the 'IR' choice is get_kernel_ir (golden vector G8) in
