@@ -45,7 +45,7 @@ from .engine import MultisliceEngine
 class TiledPropagator(object):
     def __init__(self, field_shape, n_slice, energy_ev, psize_cm, tile=512, halo='auto', slices_per_exchange=None, safety=0.5,
                  taper=None, variant='numpy_skip_last', device=0, pi=util.PI, with_grad=False, comm=None, long_range='auto',
-                 precision='auto'):
+                 precision='auto', skip_vacuum=True):
         """field_shape (FY, FX); tile: fused plan size (64 ... 1024); halo: pixels per side that are recomputed, not kept; its
         outer `taper` pixels (default halo / 2) are ramped to zero so that the tile's periodic boundary has no jump.  halo='auto':
         64 for plain stitching (ranges of ~130 slices at 5 keV / 1 nm); with the long-range correction, whose ranges are the
@@ -54,7 +54,10 @@ class TiledPropagator(object):
         slices_per_exchange: slices between two stitches; default safety * (halo - taper) / (lambda dz / (2 dx^2)), or, with
         the long-range correction, the band edge's phase-winding length 4 dx^2 / (lambda dz) if that is shorter.
         long_range: True / False / 'auto' (on for stacks deeper than one default stitch range, forward model and gradient).
-        precision: 'float32' / 'float64' / 'auto' (float64 tiles beyond 2048 slices; forward model only)."""
+        precision: 'float32' / 'float64' / 'auto' (float64 tiles beyond 2048 slices; forward model only).
+        skip_vacuum (forward model with the long-range correction, float32 tiles): a tile whose whole window is vacuum over a
+        range contributes T psi - T_free psi = 0 to it — the field's own free-space step already carries the wave there — and is
+        left out of that range's launches (a 512^2 zone plate in a 4096^2 padded field: 9 tiles of 81)."""
         self.fy, self.fx = int(field_shape[0]), int(field_shape[1])
         self.n_slice, self.tile = int(n_slice), int(tile)
         if isinstance(halo, str):
@@ -113,6 +116,9 @@ class TiledPropagator(object):
         self.eng.set_physics(energy_ev, psize_cm, None, variant=variant, pi=pi, field_shape=(self.fy, self.fx))
         self.eng.set_probe_none()
         self.idx = DeviceBuffer.from_host(self.ctx, np.stack([np.zeros(self.n_tiles, dtype=np.int32), self.x0, self.y0]))
+        self.skip_vacuum = bool(skip_vacuum)
+        self._active = None               # per stitch range: indices of the tiles whose window holds any object (set_object*)
+        self._active_bufs = {}
         n = self.n_tiles * self.tile * self.tile
         self.dbl = precision == 'float64'
         ctype = np.complex128 if self.dbl else np.complex64
@@ -165,6 +171,20 @@ class TiledPropagator(object):
         vol = DeviceBuffer.from_host(self.ctx, rows)
         tab = np.ascontiguousarray(np.tile(np.arange(self.fx, dtype=np.int32), (1, self.n_slice, 1)))             # [1][S][x] -> row x
         self.eng.set_volume(vol, self.fx, self.fy, DeviceBuffer.from_host(self.ctx, tab), self.fx, 1)
+        if getattr(self, 'skip_vacuum', False):             # (WholeFieldPropagator borrows this method: it has no tiles)
+            act = self._tiles_with_object((np.asarray(delta2d) != 0) | (np.asarray(beta2d) != 0))
+            self._active = [act] * len(self.segments())
+
+    def _tiles_with_object(self, occupied):
+        """Indices of this rank's tiles whose (periodic) window touches a pixel of the (FY, FX) mask `occupied`."""
+        T = self.tile
+        ext = np.pad(occupied.astype(np.int64), ((0, T), (0, T)), mode='wrap')
+        sat = np.zeros((ext.shape[0] + 1, ext.shape[1] + 1), dtype=np.int64)
+        sat[1:, 1:] = ext.cumsum(axis=0).cumsum(axis=1)
+        y = np.mod(self.y0, self.fy)
+        x = np.mod(self.x0, self.fx)
+        n = sat[y + T, x + T] - sat[y, x + T] - sat[y + T, x] + sat[y, x]
+        return np.flatnonzero(n > 0).astype(np.int32)
 
     def set_object(self, delta, beta):
         """(FY, FX, S) object: rows [x][z][y] of pairs and the identity table row(z, x) = x * S + z."""
@@ -174,6 +194,31 @@ class TiledPropagator(object):
         z = np.arange(self.n_slice, dtype=np.int32)
         tab = np.ascontiguousarray((x[None, :] * self.n_slice + z[:, None])[None].astype(np.int32))               # [1][S][X]
         self.eng.set_volume(vol, self.fx * self.n_slice, self.fy, DeviceBuffer.from_host(self.ctx, tab), self.fx, 1)
+        if getattr(self, 'skip_vacuum', False):
+            d, b = np.asarray(delta), np.asarray(beta)
+            self._active = [self._tiles_with_object(np.any(d[:, :, z0:z0 + nz] != 0, axis=2) | np.any(b[:, :, z0:z0 + nz] != 0, axis=2))
+                            for z0, nz in self.segments()]
+
+    def _range_tiles(self, i_range):
+        """(B, a, xo, yo, va, vx, vy) of stitch range i_range: every tile, or only those that see any object (skip_vacuum)."""
+        p, v, B = self.idx.ptr, self.vac.ptr, self.n_tiles
+        every = (B, p, p + 4 * B, p + 8 * B, v, v + 4 * B, v + 8 * B)
+        if not self.skip_vacuum or self._active is None or self.dbl or self.with_grad:
+            return every
+        act = self._active[i_range]
+        if len(act) == B:
+            return every
+        if len(act) == 0:
+            return (0,) * 7
+        key = act.tobytes()
+        if key not in self._active_bufs:
+            n = len(act)
+            zeros = np.zeros(n, dtype=np.int32)
+            self._active_bufs[key] = (DeviceBuffer.from_host(self.ctx, np.stack([zeros, self.x0[act], self.y0[act]])),
+                                      DeviceBuffer.from_host(self.ctx, np.stack([zeros, np.full(n, 1 << 28, dtype=np.int32), self.y0[act]])))
+        ib, vb = self._active_bufs[key]
+        n = len(act)
+        return (n, ib.ptr, ib.ptr + 4 * n, ib.ptr + 8 * n, vb.ptr, vb.ptr + 4 * n, vb.ptr + 8 * n)
 
     # ---- forward -------------------------------------------------------------------------------
     def _auto_halo(self, energy_ev, psize_cm, safety, slices_per_exchange, long_range, comm):
@@ -223,9 +268,15 @@ class TiledPropagator(object):
         if not self.dbl:
             self.ctx.check(lib.bdof_c_convert(h, self.field64.ptr, self.field.ptr, npx, 1))
         f, w = self.field64, self.whole64
-        for z0, nz in self.segments():
+        for i_range, (z0, nz) in enumerate(self.segments()):
             prop_last = int(z0 + nz < self.n_slice or self.variant == 'tf_all')
             nprop = nz - 1 + prop_last                       # transfer-function steps of this range
+            B, a, xo, yo, va, vx, vy = self._range_tiles(i_range)      # (tiles whose window is vacuum over the range add nothing)
+            if B == 0:
+                if nprop:
+                    _, f_tab = self._tables(nprop)
+                    self.ctx.check(lib.bdof_fields_free_step(h, f.ptr, 1, self.fx, self.fy, f_tab.ptr, 0, 1))
+                continue
             if self.dbl:
                 self.ctx.check(lib.bdof_tiles_gather_f64(h, f.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.taper))
             else:

@@ -65,13 +65,14 @@ res['whole_field_float32_vs_float64'] = rel(whole, ref)
 print('whole field float32 (rocFFT engine): %.1f ms, %.2e from float64' % (dt_whole * 1e3, res['whole_field_float32_vs_float64']), flush=True)
 del eng, vol, out, whole
 
-plans = [('default: float32 tiles + long-range correction, float64 field', dict(tile=512)),        # halo='auto': 24 pixels
-         ('the same, halo 64 (the halo of plain stitching)', dict(tile=512, halo=64)),
-         ('the same, halo 32', dict(tile=512, halo=32)),
-         ('the same, halo 16', dict(tile=512, halo=16)),
+plans = [('default: float32 tiles + correction, float64 field; vacuum tiles left out', dict(tile=512)),   # halo='auto': 24 pixels
+         ('the same with every tile running', dict(tile=512, skip_vacuum=False)),
+         ('every tile, halo 64 (the halo of plain stitching)', dict(tile=512, halo=64, skip_vacuum=False)),
+         ('every tile, halo 32', dict(tile=512, halo=32, skip_vacuum=False)),
+         ('every tile, halo 16', dict(tile=512, halo=16, skip_vacuum=False)),
          ('float32 tiles, no correction (round 3 plan)', dict(tile=512, halo=64, long_range=False)),
          ('float64 tiles + correction', dict(tile=512, halo=64, precision='float64')),
-         ('1024^2 tiles, halo 64', dict(tile=1024, halo=64))]
+         ('1024^2 tiles, halo 64, every tile', dict(tile=1024, halo=64, skip_vacuum=False))]
 for name, kw in plans:
     if kw['tile'] > n:
         continue
@@ -85,7 +86,9 @@ for name, kw in plans:
     tp.ctx.sync()
     dt = time.perf_counter() - t0
     run = {'plan': name, 'tile': kw['tile'], 'halo': tp.halo, 'tiles': tp.n_tiles, 'slices_per_exchange': tp.seg, 'ranges': len(tp.segments()),
-           'long_range': tp.long_range, 'precision': tp.precision, 'ms': dt * 1e3, 'wave_vs_float64': rel(o, ref),
+           'long_range': tp.long_range, 'precision': tp.precision, 'tiles_run_per_range': (float(np.mean([len(a) for a in tp._active]))
+                                                                                         if (tp._active is not None and tp.skip_vacuum and tp.long_range and not tp.dbl) else float(tp.n_tiles)),
+           'ms': dt * 1e3, 'wave_vs_float64': rel(o, ref),
            'intensity_vs_float64': rel(np.abs(o) ** 2, np.abs(ref) ** 2)}
     res['runs'].append(run)
     print('%-68s %4d tiles, every %3d slices: %7.1f ms  wave %.2e intensity %.2e' % (
