@@ -56,6 +56,8 @@ struct bdof_ctx {
     double2 *c64_probe = nullptr, *c64_khat = nullptr, *c64_psi = nullptr, *c64_q = nullptr, *c64_big = nullptr, *c64_tape = nullptr,
             *c64_scal = nullptr, *c64_part = nullptr;
     int c64_ks = 0, c64_B = 0;
+    const cf* range_car = nullptr;              // bdof_set_range_carrier: [nz][B][NX][NY] carrier fields of the range being swept
+    int range_car_B = 0, range_car_z0 = 0;
     bool c64_tf = false;                        // the float64 path holds the transfer-function model (bdof_set_tf_f64), not the real-space one
     double2 *c64_h = nullptr, *c64_hdet = nullptr;
     std::complex<double> c64_ksum{1.0, 0.0};
@@ -400,6 +402,11 @@ static void launch_row_fwd(bdof_ctx* c, int B, int z, const cf* in, cf* out, boo
     RowFwdArgs a{sub_field(c, in), start ? sub_field(c, start) : c->probe, sub_field(c, out), sub_field(c, phi_out), sub_obj(c), B, c->NX, z,
                  c->k, carrier_at(c, z), tw_of(c, c->twY, c->NY, (unsigned)z), slice_carrier_field(c, z), cshift_at(c, z), 0, 1.f, start ? 1 : 0};
     sq_of(c, (unsigned)z, a.sq);
+    a.pz_b = 0;
+    if (c->range_car) {          // every wavefield of the range rides on its own carrier field
+        a.pz = c->range_car + ((size_t)(z - c->range_car_z0) * c->range_car_B + c->sub_b0) * c->NX * c->NY;
+        a.pz_b = c->NX;
+    }
     c->tw_tick = (unsigned)z;
     const bool pf = a.pz != nullptr;
     DISPATCH_N(c->NY, {
@@ -428,6 +435,7 @@ static void launch_row_unmod(bdof_ctx* c, int B, int z, const cf* in, cf* out, b
     ProfScope ps(c, BDOF_K_ROW_FWD, true);
     RowFwdArgs a{sub_field(c, in), c->probe, sub_field(c, out), nullptr, sub_obj(c), B, c->NX, z, c->k, carrier_at(c, z), tw_of(c, c->twY, c->NY, (unsigned)z),
                  slice_carrier_field(c, z), cshift_at(c, z), real_in ? 1 : 0, in_scale, 0};
+    a.pz_b = 0;
     sq_of(c, (unsigned)z, a.sq);
     c->tw_tick = (unsigned)z;
     DISPATCH_N(c->NY, {
@@ -1480,6 +1488,8 @@ int bdof_forward_range(bdof_ctx* c, int B, const int* angle_of_b, const int* xof
     if (z0 < 0 || nz < 1 || z0 + nz > c->S) return fail(c, BDOF_ERR_ARG, "slice range outside [0, S)");
     if (c->generic) return fail(c, BDOF_ERR_SIZE, "bdof_forward_range runs on the fused streaming kernels (NY, NX powers of two in 64..1024)");
     if (c->obj.tab && !angle_of_b) return fail(c, BDOF_ERR_ARG, "angle_of_b required with a rotation table");
+    if (c->range_car && (B != c->range_car_B || z0 != c->range_car_z0))
+        return fail(c, BDOF_ERR_ARG, "the range carriers (bdof_set_range_carrier) were handed over for another batch / first slice");
     HIPC(c, hipSetDevice(c->device));
     set_batch_views(c, angle_of_b, xoff, yoff);
     if ((r = ensure_modulation_k(c, c->k_fft))) return r;
@@ -1514,6 +1524,24 @@ int bdof_forward_range(bdof_ctx* c, int B, const int* angle_of_b, const int* xof
     if ((r = join_streams(c, ng))) return r;
     c->tape_valid = c->last_valid = false;
     HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// Carrier fields for the NEXT bdof_forward_range calls over slices z0 .. z0 + nz - 1 of B wavefields: stack [nz][B][NX][NY] complex64
+// (device), wavefield b's free-space propagation to the entrance of each of those slices.  The range is then swept on
+// psi_z = p_z + eps_z with only eps in the float32 transforms, `in_real` is the scattered part entering the range (zeros when the
+// carrier IS the incoming wave) and `out_real` receives the scattered part leaving it — for the tiles of a corrected stitch range
+// exactly T psi - T_free psi, without the round-off of two full-amplitude sweeps.  NULL removes the stack.
+int bdof_set_range_carrier(bdof_ctx* c, const void* stack, int B, int z0, int nz) {
+    if (!c) return BDOF_ERR_ARG;
+    if (!stack) { c->range_car = nullptr; c->range_car_B = 0; return 0; }
+    if (c->NY == 0) return fail(c, BDOF_ERR_STATE, "bdof_configure has not been called");
+    if (c->pstack || c->a0 != std::complex<double>(0.0, 0.0))
+        return fail(c, BDOF_ERR_STATE, "range carriers replace the ctx's own probe carrier: bind a zero probe (bdof_set_probe, a0 = 0) and no probe stack");
+    if (B < 1 || B > c->Bmax || z0 < 0 || nz < 1 || z0 + nz > c->S) return fail(c, BDOF_ERR_ARG, "batch / slice range outside the configuration");
+    c->range_car = (const cf*)stack;
+    c->range_car_B = B;
+    c->range_car_z0 = z0;
     return 0;
 }
 

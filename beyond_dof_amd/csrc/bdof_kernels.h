@@ -217,6 +217,8 @@ struct RowFwdArgs {
     float in_scale;    // INV kernels: factor on the (transformed) input
     int probe_batched; // FIRST kernels: `probe` is [B][NX][NY], one starting field per wavefield (bdof_forward_range)
     float sq[2];       // sqrt(1/2) of this launch for the transforms with ROUND 1 / ROUND 2 (dithered over the slices, bdof_fft.h)
+    int pz_b;          // PF kernels: rows per wavefield in `pz` — 0: one carrier field shared by the batch; NX: [B][NX][NY], one per
+                       // wavefield (the tiles of a stitch range, each riding on its own free-space propagation: bdof_set_range_carrier)
 };
 
 // Inverse of the modulation, for the tape-free adjoint (bdof_configure flag 16): from the scattered part of phi_z = c psi_z
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(BDOF_THREADS, RowCfg<NY>::MIN_WAVES) void k_row_fwd
             if constexpr (PF) {
                 cf pc[8];
 #pragma unroll
-                for (int m = 0; m < 8; ++m) pc[m] = a.pz[(size_t)x * NY + tid + m * C::T];
+                for (int m = 0; m < 8; ++m) pc[m] = a.pz[((size_t)b * a.pz_b + x) * NY + tid + m * C::T];
                 if constexpr (INV) {
                     if (!a.real_in) line_fft<NY, +1, 1, EX>(u, tw, tid, lds);
 #pragma unroll

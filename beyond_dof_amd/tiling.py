@@ -45,25 +45,30 @@ from .engine import MultisliceEngine
 class TiledPropagator(object):
     def __init__(self, field_shape, n_slice, energy_ev, psize_cm, tile=512, halo='auto', slices_per_exchange=None, safety=0.5,
                  taper=None, variant='numpy_skip_last', device=0, pi=util.PI, with_grad=False, comm=None, long_range='auto',
-                 precision='auto', skip_vacuum=True):
+                 precision='auto', skip_vacuum=True, carrier='auto'):
         """field_shape (FY, FX); tile: fused plan size (64 ... 1024); halo: pixels per side that are recomputed, not kept; its
         outer `taper` pixels (default halo / 2) are ramped to zero so that the tile's periodic boundary has no jump.  halo='auto':
         64 for plain stitching (ranges of ~130 slices at 5 keV / 1 nm); with the long-range correction, whose ranges are the
-        winding length (16 slices), what one range needs — the band edge's reach over it, twice over, plus 16 pixels of ramp and
-        margin: 24 at 5 keV / 1 nm (cfg4: 81 tiles instead of 121, 257 instead of 332 ms, the same 5.8e-6; 16 pixels: 7.4e-6).
+        winding length (16 slices), what one range needs — the band edge's reach over it, twice over, plus ramp and margin: 40
+        pixels with per-tile carriers (48 at 5 keV / 1 nm; cfg4: 7.7e-7), 16 without (24: the float32 round-off of full-amplitude
+        sweeps, 6e-6, hides what more would buy).
         slices_per_exchange: slices between two stitches; default safety * (halo - taper) / (lambda dz / (2 dx^2)), or, with
         the long-range correction, the band edge's phase-winding length 4 dx^2 / (lambda dz) if that is shorter.
         long_range: True / False / 'auto' (on for stacks deeper than one default stitch range, forward model and gradient).
         precision: 'float32' / 'float64' / 'auto' (float64 tiles beyond 2048 slices; forward model only).
         skip_vacuum (forward model with the long-range correction, float32 tiles): a tile whose whole window is vacuum over a
         range contributes T psi - T_free psi = 0 to it — the field's own free-space step already carries the wave there — and is
-        left out of that range's launches (a 512^2 zone plate in a 4096^2 padded field: 9 tiles of 81)."""
+        left out of that range's launches (a 512^2 zone plate in a 4096^2 padded field: 6 tiles of 81).
+        carrier (same mode): every tile of a range rides on its own free-space propagation through the range, formed in double
+        (bdof_set_range_carrier); the float32 kernels then carry only the scattered part, whose round-off is what is left of
+        T psi - T_free psi.  'auto': on."""
         self.fy, self.fx = int(field_shape[0]), int(field_shape[1])
         self.n_slice, self.tile = int(n_slice), int(tile)
         if isinstance(halo, str):
             if halo != 'auto':
                 raise ValueError("halo: a number of pixels or 'auto'")
-            halo = self._auto_halo(energy_ev, psize_cm, safety, slices_per_exchange, long_range, comm)
+            carriers = carrier in ('auto', True) and not with_grad and precision in ('auto', 'float32')
+            halo = self._auto_halo(energy_ev, psize_cm, safety, slices_per_exchange, long_range, comm, carriers)
         self.halo = int(halo)
         if 2 * self.halo >= self.tile:
             raise ValueError('the halo must leave a core')
@@ -83,7 +88,8 @@ class TiledPropagator(object):
             raise ValueError('the long-range correction runs on one rank (it transforms the whole field)')
         if precision == 'auto':
             # fused float32 kernels (dithered transform constants and transfer function): 5.8e-6 at 1024 slices, growing like sqrt(S)
-            precision = 'float64' if (self.n_slice > 2048 and not self.with_grad and (comm is None or comm.size == 1)) else 'float32'
+            precision = 'float64' if (self.n_slice > 2048 and not self.with_grad and (comm is None or comm.size == 1)
+                                      and carrier is False) else 'float32'
         if precision not in ('float32', 'float64'):
             raise ValueError("precision must be 'float32', 'float64' or 'auto'")
         if precision == 'float64' and (self.with_grad or (comm is not None and comm.size > 1)):
@@ -117,6 +123,7 @@ class TiledPropagator(object):
         self.eng.set_probe_none()
         self.idx = DeviceBuffer.from_host(self.ctx, np.stack([np.zeros(self.n_tiles, dtype=np.int32), self.x0, self.y0]))
         self.skip_vacuum = bool(skip_vacuum)
+        self._carrier_arg = carrier
         self._active = None               # per stitch range: indices of the tiles whose window holds any object (set_object*)
         self._active_bufs = {}
         n = self.n_tiles * self.tile * self.tile
@@ -140,6 +147,12 @@ class TiledPropagator(object):
             self.vac = DeviceBuffer.from_host(self.ctx, np.stack([np.zeros(self.n_tiles, dtype=np.int32),
                                                                   np.full(self.n_tiles, 1 << 28, dtype=np.int32), self.y0]))
             self._conj_tables = {}
+        self.carrier = (self.long_range and not self.dbl and not self.with_grad) if self._carrier_arg == 'auto' else bool(self._carrier_arg)
+        if self.carrier and not (self.long_range and not self.dbl and not self.with_grad):
+            raise ValueError('carrier fields per tile run in the forward model with the long-range correction and float32 tiles')
+        self._car64 = self._car_stack = None
+        if self.carrier:
+            self._h64_tile = DeviceBuffer.from_host(self.ctx, self._free_table(1, (self.tile, self.tile), np.complex128))
 
     def _free_table(self, power, shape, ctype, fused_layout=False):
         """The `power`-th power of one slice step's transfer function on a (ny, nx) grid of this field, un-shifted, 1 / (NX NY)
@@ -199,6 +212,31 @@ class TiledPropagator(object):
             self._active = [self._tiles_with_object(np.any(d[:, :, z0:z0 + nz] != 0, axis=2) | np.any(b[:, :, z0:z0 + nz] != 0, axis=2))
                             for z0, nz in self.segments()]
 
+    def _scattered_range(self, f, w, B, a, xo, yo, z0, nz, prop_last):
+        """stitch(T psi - T_free psi) of one range added into w (prop_last) / the modulation's scattered part added into f (a last
+        single slice without a step), the tiles riding on their own free-space propagation in double."""
+        lib, h, T = self.lib, self.h, self.tile
+        px = B * T * T
+        if self._car64 is None or self._car64.nbytes < px * 16:
+            self._car64 = DeviceBuffer(self.ctx, px * 16, np.complex128, (B, T, T))
+        if self._car_stack is None or self._car_stack.nbytes < px * 8 * nz:
+            self._car_stack = DeviceBuffer(self.ctx, px * 8 * max(nz, self.seg), np.complex64, (max(nz, self.seg), B, T, T))
+        car, stack = self._car64, self._car_stack
+        self.ctx.check(lib.bdof_tiles_gather_f64(h, f.ptr, self.fx, self.fy, car.ptr, B, T, T, xo, yo, self.taper))
+        for j in range(nz):
+            self.ctx.check(lib.bdof_c_convert(h, stack.ptr + j * px * 8, car.ptr, px, 0))
+            if j < nz - 1:
+                self.ctx.check(lib.bdof_fields_free_step(h, car.ptr, B, T, T, self._h64_tile.ptr, 0, 1))
+        self.ctx.check(lib.bdof_memset(h, self.tiles_in.ptr, 0, px * 8))              # the scattered part entering the range: none
+        self.ctx.check(lib.bdof_set_range_carrier(h, stack.ptr, B, z0, nz))
+        try:
+            self.ctx.check(lib.bdof_forward_range(h, B, a, xo, yo, z0, nz, self.tiles_in.ptr, self.tiles_out.ptr, prop_last))
+        finally:
+            lib.bdof_set_range_carrier(h, None, 0, 0, 0)
+        dst = w if prop_last or nz > 1 else f
+        self.ctx.check(lib.bdof_tiles_scatter_diff64(h, self.tiles_out.ptr, None, dst.ptr, self.fx, self.fy, B, T, T, xo, yo,
+                                                     self.halo, self.halo, 1))
+
     def _range_tiles(self, i_range):
         """(B, a, xo, yo, va, vx, vy) of stitch range i_range: every tile, or only those that see any object (skip_vacuum)."""
         p, v, B = self.idx.ptr, self.vac.ptr, self.n_tiles
@@ -221,7 +259,7 @@ class TiledPropagator(object):
         return (n, ib.ptr, ib.ptr + 4 * n, ib.ptr + 8 * n, vb.ptr, vb.ptr + 4 * n, vb.ptr + 8 * n)
 
     # ---- forward -------------------------------------------------------------------------------
-    def _auto_halo(self, energy_ev, psize_cm, safety, slices_per_exchange, long_range, comm):
+    def _auto_halo(self, energy_ev, psize_cm, safety, slices_per_exchange, long_range, comm, carriers=False):
         voxel_nm = np.array([psize_cm] * 3) * 1.e7 if np.isscalar(psize_cm) else np.array(psize_cm) * 1.e7
         lmbda_nm = 1240. / energy_ev
         spread = lmbda_nm * voxel_nm[2] / (2. * voxel_nm[0] ** 2)
@@ -234,7 +272,9 @@ class TiledPropagator(object):
             return plain
         winding = max(1, int(4. * voxel_nm[0] ** 2 / (lmbda_nm * voxel_nm[2])))
         seg = winding if slices_per_exchange is None else int(slices_per_exchange)
-        need = 2 * int(np.ceil(spread * seg / safety)) + 16
+        # without per-tile carriers the float32 round-off of the sweeps (6e-6 at cfg4's depth) hides what a wider ramp would buy;
+        # with them the tiling error is what is left, and 40 pixels of ramp and margin bring it under 1e-6
+        need = 2 * int(np.ceil(spread * seg / safety)) + (40 if carriers else 16)
         return int(min(max(need, 16), plain))
 
     def segments(self):
@@ -276,6 +316,16 @@ class TiledPropagator(object):
                 if nprop:
                     _, f_tab = self._tables(nprop)
                     self.ctx.check(lib.bdof_fields_free_step(h, f.ptr, 1, self.fx, self.fy, f_tab.ptr, 0, 1))
+                continue
+            if self.carrier:
+                if nprop == 0:                               # a last single slice without a step: f += (c - 1) psi on the cores
+                    self._scattered_range(f, f, B, a, xo, yo, z0, nz, 0)
+                    continue
+                _, f_tab = self._tables(nprop)
+                self.ctx.check(lib.bdof_memcpy_d2d(h, w.ptr, f.ptr, npx * 16))
+                self.ctx.check(lib.bdof_fields_free_step(h, w.ptr, 1, self.fx, self.fy, f_tab.ptr, 0, 1))
+                self._scattered_range(f, w, B, a, xo, yo, z0, nz, prop_last)
+                f, w = w, f
                 continue
             if self.dbl:
                 self.ctx.check(lib.bdof_tiles_gather_f64(h, f.ptr, self.fx, self.fy, self.tiles_in.ptr, B, T, T, xo, yo, self.taper))

@@ -189,6 +189,13 @@ int bdof_field_loss_seed(bdof_ctx* ctx, void* field, const float* meas, int FX, 
 int bdof_set_transfer_f64(bdof_ctx* ctx, const double* hs64);
 /* bdof_forward_range with the table of its transfer-function steps supplied by the caller (device, [ky][kx] complex64 like hs):
  * the tiled propagator's free-space step over a whole stitch range (H^n) through the fused kernels. */
+/* Carrier fields for the next bdof_forward_range calls over slices z0 .. z0 + nz - 1 of B wavefields: device stack [nz][B][NX][NY]
+ * complex64, wavefield b's free-space propagation to the entrance of each slice (formed in double by the caller:
+ * bdof_fields_free_step + bdof_c_convert).  The range is swept on psi_z = p_z + eps_z with only eps in the float32 transforms;
+ * in_real is the scattered part entering the range, out_real the scattered part leaving it — for the tiles of a corrected stitch
+ * range (np_funcs.py:36-43 on a tile) T psi - T_free psi itself.  Needs a zero ctx probe (bdof_set_probe with a0 = 0, no probe
+ * stack).  NULL removes the stack. */
+int bdof_set_range_carrier(bdof_ctx* ctx, const void* stack, int B, int z0, int nz);
 int bdof_forward_range_h(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
                          const void* in_real, void* out_real, int prop_last, const void* h);
 int bdof_fields_free_step(bdof_ctx* ctx, void* fields, int B, int NX, int NY, const void* h, int conj_h, int is_double);

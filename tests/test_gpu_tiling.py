@@ -339,10 +339,10 @@ def test_cfg4_at_its_stated_depth_1024_slices():
     The host's float64 run of this depth takes 393 s, so the reference is the library's own float64 WHOLE-FIELD propagation
     (WholeFieldPropagator: rocFFT double transforms of the 4096^2 field, float64 modulation) — first validated here against the
     host's float64 run at 96 slices (<= 1e-12), then run at 1024.
-    * the default plan at this depth — fused float32 tiles with dithered constants and transfer function, the long-range
-      correction with the field in float64, stitched every 16 slices (64 ranges): exit wave and intensity within the north
-      star's 1e-5 (measured 5.8e-6), with 64-pixel halos (121 tiles) and with the constructor's own halo for corrected ranges
-      (24 pixels, 81 tiles: a quarter less work, the same error);
+    * fused float32 tiles with dithered constants and transfer function, the long-range correction with the field in float64,
+      stitched every 16 slices (64 ranges), the full wave through the float32 sweeps: exit wave and intensity within the north
+      star's 1e-5 (measured 5.8e-6) with 64-pixel halos (121 tiles), with 24-pixel halos (81 tiles) and with the vacuum tiles left out;
+    * the DEFAULT plan: the same with every tile riding on its own carrier field (bdof_set_range_carrier) — within 2e-6 (7.7e-7);
     * precision='float64' (rocFFT double tiles): within 2e-6 (measured 9.1e-7: what is left of the tiling error);
     * float64 tiles WITHOUT the correction at round 3's interval: the tiling error proper, 2.2e-5 — the whole-field
       propagator's long-range tails, which no tile sees; on record with its bounds, it is what the correction removes."""
@@ -361,18 +361,21 @@ def test_cfg4_at_its_stated_depth_1024_slices():
     ref = wf.forward(probe, zero)
     del wf
     res = {}
-    for name, kw in (('default', dict(halo=64, skip_vacuum=False)), ('auto_halo', dict(skip_vacuum=False)), ('skip_vacuum', {}),
+    for name, kw in (('default', dict(halo=64, skip_vacuum=False, carrier=False)), ('auto_halo', dict(halo=24, skip_vacuum=False, carrier=False)),
+                     ('skip_vacuum', dict(halo=24, carrier=False)), ('carrier', {}),
                      ('float64', dict(halo=64, precision='float64')), ('no_correction', dict(halo=64, precision='float64', long_range=False))):
         tp = TiledPropagator((n, n), S, 5000., 1e-7, tile=512, **kw)
         if name == 'default':
             assert tp.precision == 'float32' and tp.long_range and tp.seg == 16 and len(tp.segments()) == 64 and tp.n_tiles == 121
-        elif name in ('auto_halo', 'skip_vacuum'):   # the constructor's own choice for this geometry: 24-pixel halos, 81 tiles, same ranges
-            assert tp.halo == 24 and tp.taper == 12 and tp.long_range and tp.seg == 16 and tp.n_tiles == 81
-        elif name == 'no_correction':
-            assert tp.seg == 129 and len(tp.segments()) == 8
+        elif name in ('auto_halo', 'skip_vacuum'):   # 24-pixel halos: what corrected ranges of full-amplitude float32 sweeps need
+            assert tp.halo == 24 and tp.taper == 12 and tp.long_range and tp.seg == 16 and tp.n_tiles == 81 and not tp.carrier
+        elif name == 'carrier':                      # the constructor's defaults: per-tile carriers, 48-pixel halos, vacuum tiles left out
+            assert tp.carrier and tp.skip_vacuum and tp.halo == 48 and tp.precision == 'float32' and tp.seg == 16 and tp.n_tiles == 100
         tp.set_object_slab(slab, 0.1 * slab)
-        if name == 'skip_vacuum':                    # the constructor's defaults: only the tiles whose window touches the zone plate run
+        if name == 'skip_vacuum':                    # only the tiles whose window touches the zone plate run
             assert len(tp._active) == 64 and all(len(a) == 6 for a in tp._active), [len(a) for a in tp._active]
+        if name == 'carrier':
+            assert all(len(a) <= 9 for a in tp._active), [len(a) for a in tp._active]
         out = tp.forward(probe, zero)
         del tp
         res[name] = (rel(out, ref), rel(np.abs(out) ** 2, np.abs(ref) ** 2))
@@ -383,6 +386,10 @@ def test_cfg4_at_its_stated_depth_1024_slices():
     # two histories 1e-15 apart leave T psi 6.8e-7 apart after one range), and the 75 vacuum tiles move the double-precision field
     # by 1e-19.  5.8e-6 with every tile, 6.5e-6 with the six (intensity 6.3e-6 / 7.7e-6): both 0.7e-6 x sqrt(64 ranges).
     assert max(res['skip_vacuum']) <= 1e-5, res
+    # per-tile carriers (the default): each tile of a range rides on its own free-space propagation in double and the float32
+    # kernels carry the scattered part only — the round-off above is gone and what is left is the tiling error of the halo:
+    # measured 7.7e-7 (intensity 8.7e-7) at 48 pixels, the figure of float64 tiles
+    assert max(res['carrier']) <= 2e-6, res
     assert max(res['float64']) <= 2e-6, res
     assert 1.5e-5 <= res['no_correction'][0] <= 3e-5, res
 

@@ -181,18 +181,20 @@ def test_adjoint_precision_values_are_checked_before_anything_touches_a_gpu(tmp_
 
 def test_tiled_propagator_auto_halo():
     """TiledPropagator(halo='auto') (host arithmetic only): 64 pixels for plain stitching; with the long-range correction twice the
-    band edge's reach over one 16-slice range plus 16 pixels — 24 at 5 keV / 1 nm (cfg4: 81 tiles of 512^2 on the 4096^2 field)."""
+    band edge's reach over one 16-slice range plus 16 pixels — 24 at 5 keV / 1 nm (81 tiles of 512^2 on the 4096^2 field) — or plus 40
+    where the tiles ride on per-tile carriers (48: 100 tiles, of which the few that touch the object run)."""
     from beyond_dof_amd.tiling import TiledPropagator
 
     class Probe(TiledPropagator):
         def __init__(self, n_slice, tile):
             self.n_slice, self.tile = n_slice, tile
-    assert Probe(1024, 512)._auto_halo(5000., 1e-7, 0.5, None, 'auto', None) == 24
+    assert Probe(1024, 512)._auto_halo(5000., 1e-7, 0.5, None, 'auto', None) == 24           # full-amplitude float32 sweeps (gradient)
+    assert Probe(1024, 512)._auto_halo(5000., 1e-7, 0.5, None, 'auto', None, True) == 48     # per-tile carriers (the forward model)
     assert Probe(1024, 512)._auto_halo(5000., 1e-7, 0.5, None, False, None) == 64
-    assert Probe(96, 512)._auto_halo(5000., 1e-7, 0.5, None, 'auto', None) == 64            # one plain range: no correction
+    assert Probe(96, 512)._auto_halo(5000., 1e-7, 0.5, None, 'auto', None, True) == 64       # one plain range: no correction
     assert Probe(1024, 128)._auto_halo(5000., 1e-7, 0.5, None, 'auto', None) == 24
-    assert Probe(1024, 64)._auto_halo(5000., 1e-7, 0.5, None, True, None) == 16             # never more than a quarter of the tile
-    assert (-(-4096 // (512 - 2 * 24))) ** 2 == 81
+    assert Probe(1024, 64)._auto_halo(5000., 1e-7, 0.5, None, True, None, True) == 16        # never more than a quarter of the tile
+    assert (-(-4096 // (512 - 2 * 24))) ** 2 == 81 and (-(-4096 // (512 - 2 * 48))) ** 2 == 100
 
 
 def test_detector_kernel_choice_and_impulse_response_table(golden_dir):

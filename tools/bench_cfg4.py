@@ -65,14 +65,17 @@ res['whole_field_float32_vs_float64'] = rel(whole, ref)
 print('whole field float32 (rocFFT engine): %.1f ms, %.2e from float64' % (dt_whole * 1e3, res['whole_field_float32_vs_float64']), flush=True)
 del eng, vol, out, whole
 
-plans = [('default: float32 tiles + correction, float64 field; vacuum tiles left out', dict(tile=512)),   # halo='auto': 24 pixels
-         ('the same with every tile running', dict(tile=512, skip_vacuum=False)),
-         ('every tile, halo 64 (the halo of plain stitching)', dict(tile=512, halo=64, skip_vacuum=False)),
-         ('every tile, halo 32', dict(tile=512, halo=32, skip_vacuum=False)),
-         ('every tile, halo 16', dict(tile=512, halo=16, skip_vacuum=False)),
+plans = [('default: float32 tiles on per-tile carriers + correction, float64 field; vacuum tiles left out', dict(tile=512)),   # halo='auto': 48
+         ('the same, halo 24', dict(tile=512, halo=24)),
+         ('the same, halo 32', dict(tile=512, halo=32)),
+         ('the same, halo 64', dict(tile=512, halo=64)),
+         ('the same, halo 96', dict(tile=512, halo=96)),
+         ('halo 24, the full wave through the float32 sweeps (no carriers), vacuum tiles left out', dict(tile=512, halo=24, carrier=False)),
+         ('the same with every tile running', dict(tile=512, halo=24, skip_vacuum=False, carrier=False)),
+         ('every tile, halo 64 (the halo of plain stitching), no carriers', dict(tile=512, halo=64, skip_vacuum=False, carrier=False)),
          ('float32 tiles, no correction (round 3 plan)', dict(tile=512, halo=64, long_range=False)),
          ('float64 tiles + correction', dict(tile=512, halo=64, precision='float64')),
-         ('1024^2 tiles, halo 64, every tile', dict(tile=1024, halo=64, skip_vacuum=False))]
+         ('1024^2 tiles, halo 64', dict(tile=1024, halo=64))]
 for name, kw in plans:
     if kw['tile'] > n:
         continue
@@ -91,7 +94,7 @@ for name, kw in plans:
            'ms': dt * 1e3, 'wave_vs_float64': rel(o, ref),
            'intensity_vs_float64': rel(np.abs(o) ** 2, np.abs(ref) ** 2)}
     res['runs'].append(run)
-    print('%-68s %4d tiles, every %3d slices: %7.1f ms  wave %.2e intensity %.2e' % (
+    print('%-100s %4d tiles, every %3d slices: %7.1f ms  wave %.2e intensity %.2e' % (
         name, tp.n_tiles, tp.seg, dt * 1e3, run['wave_vs_float64'], run['intensity_vs_float64']), flush=True)
     del tp
 if out_json:
