@@ -288,6 +288,17 @@ def test_error_behaviour(engine_mod):
     assert g.lib.bdof_loss_grad_tf_f64(g.h, 2, None, None, None, m.ptr, 0.0) != 0 and b'bdof_set_tf_f64' in g.lib.bdof_last_error(g.h)
     g.enable_tf_f64()
     assert abs(g.loss_grad(2, np.ones((2, 64, 64)), f64=True) - 0.25) <= 1e-12
+    # range carriers (bdof_set_range_carrier) replace the ctx's own probe carrier, and bind one batch / first slice
+    stack = _lib.DeviceBuffer.zeros(g.ctx, (2, 2, 64, 64), np.complex64)
+    assert g.lib.bdof_set_range_carrier(g.h, stack.ptr, 2, 0, 2) != 0 and b'zero probe' in g.lib.bdof_last_error(g.h)
+    g.set_probe_none()
+    assert g.lib.bdof_set_range_carrier(g.h, stack.ptr, 3, 0, 2) != 0                     # B > Bmax
+    assert g.lib.bdof_set_range_carrier(g.h, stack.ptr, 2, 3, 2) != 0                     # slices outside [0, S)
+    assert g.lib.bdof_set_range_carrier(g.h, stack.ptr, 2, 0, 2) == 0
+    fin, fout = _lib.DeviceBuffer.zeros(g.ctx, (2, 64, 64), np.complex64), _lib.DeviceBuffer.zeros(g.ctx, (2, 64, 64), np.complex64)
+    assert g.lib.bdof_forward_range(g.h, 1, None, None, None, 0, 2, fin.ptr, fout.ptr, 1) != 0      # another batch size
+    assert b'range carriers' in g.lib.bdof_last_error(g.h)
+    assert g.lib.bdof_set_range_carrier(g.h, None, 0, 0, 0) == 0
 
 
 def test_fullfield_fused_rotation_and_adjoint(engine_mod):
