@@ -72,6 +72,9 @@ _SIGNATURES = {
     'bdof_set_conv_f64': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_double]),
     'bdof_loss_grad_conv_f64': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_double]),
     'bdof_set_conv_f64_detector': (ctypes.c_int, [_vp, _vp]),
+    'bdof_fields_free_step_aux': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int]),
+    'bdof_aux_join': (ctypes.c_int, [_vp]),
+    'bdof_range_carrier_build': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, ctypes.c_int]),
     'bdof_set_range_carrier': (ctypes.c_int, [_vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     'bdof_set_tf_f64': (ctypes.c_int, [_vp, _vp, _vp, _vp, ctypes.c_double]),
     'bdof_loss_grad_tf_f64': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_double]),

@@ -56,6 +56,14 @@ struct bdof_ctx {
     double2 *c64_probe = nullptr, *c64_khat = nullptr, *c64_psi = nullptr, *c64_q = nullptr, *c64_big = nullptr, *c64_tape = nullptr,
             *c64_scal = nullptr, *c64_part = nullptr;
     int c64_ks = 0, c64_B = 0;
+    double2* car_scratch = nullptr;             // bdof_range_carrier_build: [nz - 1][B][NX][NY] complex128
+    size_t car_scratch_n = 0;
+    hipStream_t aux = nullptr;                  // bdof_fields_free_step_aux: the whole-field step of a stitch range beside the tiles' sweeps
+    hipEvent_t ev_aux_fork = nullptr, ev_aux_join = nullptr;
+    rocfft_execution_info ginfo_aux = nullptr;
+    void* gwork_aux = nullptr;
+    size_t gwork_aux_sz = 0;
+    bool aux_pending = false;
     const cf* range_car = nullptr;              // bdof_set_range_carrier: [nz][B][NX][NY] carrier fields of the range being swept
     int range_car_B = 0, range_car_z0 = 0;
     bool c64_tf = false;                        // the float64 path holds the transfer-function model (bdof_set_tf_f64), not the real-space one
@@ -1000,6 +1008,12 @@ void bdof_ctx_destroy(bdof_ctx* c) {
     for (auto& e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto& e : c->timer) if (e) (void)hipEventDestroy(e);
     for (hipStream_t s : c->side_all) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    if (c->aux) { (void)hipStreamSynchronize(c->aux); (void)hipStreamDestroy(c->aux); }
+    if (c->ev_aux_fork) (void)hipEventDestroy(c->ev_aux_fork);
+    if (c->ev_aux_join) (void)hipEventDestroy(c->ev_aux_join);
+    if (c->ginfo_aux) (void)rocfft_execution_info_destroy(c->ginfo_aux);
+    if (c->gwork_aux) (void)hipFree(c->gwork_aux);
+    if (c->car_scratch) (void)hipFree(c->car_scratch);
     for (int i = 0; i < BDOF_MAX_GROUPS - 1; ++i)
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1744,6 +1758,96 @@ int bdof_fields_free_step(bdof_ctx* c, void* fields, int B, int NX, int NY, cons
     else hipLaunchKernelGGL(k_f_hmul<float2>, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, (float2*)fields, (const float2*)h, per, n, conj_h);
     RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo));
     HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// The same step on an AUXILIARY stream: it starts after everything queued on the ctx's stream so far (first copying `src` into
+// `fields` there, if given) and runs beside what the ctx's stream is handed next — the whole-field step of a stitch range beside the
+// tiles' carrier steps and sweeps (tiling.TiledPropagator).  bdof_aux_join makes the ctx's stream wait for it.  One step in
+// flight at a time; own rocFFT execution info and work buffer.
+int bdof_fields_free_step_aux(bdof_ctx* c, void* fields, const void* src, int B, int NX, int NY, const void* h, int conj_h, int is_double) {
+    if (!c || !fields || !h || B < 1 || NX < 1 || NY < 1) return BDOF_ERR_ARG;
+    if (c->aux_pending) return fail(c, BDOF_ERR_STATE, "an auxiliary step is in flight: bdof_aux_join first");
+    HIPC(c, hipSetDevice(c->device));
+    rocfft_plan pf, pi;
+    int r = field_plans(c, NX, NY, B, is_double != 0, &pf, &pi);
+    if (r) return r;
+    if (!c->aux) {
+        HIPC(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+        HIPC(c, hipEventCreateWithFlags(&c->ev_aux_fork, hipEventDisableTiming));
+        HIPC(c, hipEventCreateWithFlags(&c->ev_aux_join, hipEventDisableTiming));
+        RFC(c, rocfft_execution_info_create(&c->ginfo_aux));
+        RFC(c, rocfft_execution_info_set_stream(c->ginfo_aux, (void*)c->aux));
+    }
+    size_t w1 = 0, w2 = 0;
+    RFC(c, rocfft_plan_get_work_buffer_size(pf, &w1));
+    RFC(c, rocfft_plan_get_work_buffer_size(pi, &w2));
+    const size_t need = std::max(w1, w2);
+    if (need > c->gwork_aux_sz) {
+        HIPC(c, hipStreamSynchronize(c->aux));
+        if (c->gwork_aux) (void)hipFree(c->gwork_aux);
+        c->gwork_aux = nullptr; c->gwork_aux_sz = 0;
+        HIPC(c, hipMalloc(&c->gwork_aux, need));
+        c->gwork_aux_sz = need;
+    }
+    if (c->gwork_aux_sz) RFC(c, rocfft_execution_info_set_work_buffer(c->ginfo_aux, c->gwork_aux, c->gwork_aux_sz));
+    const size_t per = (size_t)NX * NY, n = per * B, esz = is_double ? sizeof(double2) : sizeof(float2);
+    HIPC(c, hipEventRecord(c->ev_aux_fork, c->stream));
+    HIPC(c, hipStreamWaitEvent(c->aux, c->ev_aux_fork, 0));
+    c->aux_pending = true;
+    if (src) HIPC(c, hipMemcpyAsync(fields, src, n * esz, hipMemcpyDeviceToDevice, c->aux));
+    void* buf[1] = {fields};
+    RFC(c, rocfft_execute(pf, buf, nullptr, c->ginfo_aux));
+    if (is_double) hipLaunchKernelGGL(k_f_hmul<double2>, dim3(g_elem_grid(c, n)), dim3(256), 0, c->aux, (double2*)fields, (const double2*)h, per, n, conj_h);
+    else hipLaunchKernelGGL(k_f_hmul<float2>, dim3(g_elem_grid(c, n)), dim3(256), 0, c->aux, (float2*)fields, (const float2*)h, per, n, conj_h);
+    RFC(c, rocfft_execute(pi, buf, nullptr, c->ginfo_aux));
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+// The carrier stack of a stitch range (bdof_set_range_carrier) in one call: p0 [B][NX][NY] complex128 (device; overwritten) are
+// the wavefields entering the range; stack [nz][B][NX][NY] complex64 receives p_z = F^-1(H^z F p0), z = 0 .. nz - 1 — the
+// free-space propagation of each to the entrance of every slice of the range, formed in double: one forward transform, the nz - 1
+// spectra s_hat H^z by a running product, ONE batched inverse transform of all of them, one conversion.  h: complex128 [kx][ky],
+// ifftshift(H) / (NX NY).
+int bdof_range_carrier_build(bdof_ctx* c, void* p0, void* stack, int B, int NX, int NY, const void* h, int nz) {
+    if (!c || !p0 || !stack || !h || B < 1 || NX < 1 || NY < 1 || nz < 1) return BDOF_ERR_ARG;
+    HIPC(c, hipSetDevice(c->device));
+    const size_t per = (size_t)NX * NY, n = per * B;
+    hipLaunchKernelGGL(k_f_to_float, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, (const double2*)p0, (cf*)stack, n);
+    if (nz > 1) {
+        const size_t need = n * (size_t)(nz - 1);
+        if (need > c->car_scratch_n) {
+            HIPC(c, hipStreamSynchronize(c->stream));
+            if (c->car_scratch) (void)hipFree(c->car_scratch);
+            c->car_scratch = nullptr; c->car_scratch_n = 0;
+            HIPC(c, hipMalloc(&c->car_scratch, need * sizeof(double2)));
+            c->car_scratch_n = need;
+        }
+        rocfft_plan pf, pi, qf, qi;
+        int r = field_plans(c, NX, NY, B, true, &pf, &pi);
+        if (r) return r;
+        if ((r = field_plans(c, NX, NY, B * (nz - 1), true, &qf, &qi))) return r;       // (sizes the shared work buffer for both)
+        if ((r = field_plans(c, NX, NY, B, true, &pf, &pi))) return r;
+        void* b0[1] = {p0};
+        RFC(c, rocfft_execute(pf, b0, nullptr, c->ginfo));
+        hipLaunchKernelGGL(k_carrier_spectra, dim3(g_elem_grid(c, n)), dim3(256), 0, c->stream, (const double2*)p0, (const double2*)h, c->car_scratch,
+                           per, B, nz, (double)NX * (double)NY);
+        void* b1[1] = {c->car_scratch};
+        RFC(c, rocfft_execute(qi, b1, nullptr, c->ginfo));
+        hipLaunchKernelGGL(k_f_to_float, dim3(g_elem_grid(c, need)), dim3(256), 0, c->stream, (const double2*)c->car_scratch, (cf*)stack + n, need);
+    }
+    HIPC(c, hipGetLastError());
+    return 0;
+}
+
+int bdof_aux_join(bdof_ctx* c) {
+    if (!c) return BDOF_ERR_ARG;
+    if (!c->aux_pending) return 0;
+    HIPC(c, hipSetDevice(c->device));
+    c->aux_pending = false;
+    HIPC(c, hipEventRecord(c->ev_aux_join, c->aux));
+    HIPC(c, hipStreamWaitEvent(c->stream, c->ev_aux_join, 0));
     return 0;
 }
 

@@ -230,3 +230,21 @@ __global__ __launch_bounds__(256) void k_dither_copies(const double2* __restrict
         for (int d = 0; d < D; ++d) dst[(size_t)d * n + i] = make_float2(dither_round(v.x, d, ph), dither_round(v.y, d, ph2));
     }
 }
+
+// Carrier stack of a stitch range from the spectrum of the tiles' input: S_z = s_hat * H^z for z = 1 .. nz - 1, all of them in one
+// pass (running product in double); h carries 1 / (NX NY), H = h * (NX NY).  spec [B][per] -> out [nz - 1][B][per]
+__global__ __launch_bounds__(256) void k_carrier_spectra(const double2* __restrict__ spec, const double2* __restrict__ h, double2* __restrict__ out,
+                                                         size_t per, int B, int nz, double scale_up) {
+    const size_t n = per * B;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double2 hk = h[i % per];
+        const double hx = hk.x * scale_up, hy = hk.y * scale_up;            // the un-normalised H
+        const double2 s0 = spec[i];
+        double wx = hk.x, wy = hk.y;                                        // H^z / (NX NY), z = 1
+        for (int z = 1; z < nz; ++z) {
+            out[(size_t)(z - 1) * n + i] = make_double2(s0.x * wx - s0.y * wy, s0.x * wy + s0.y * wx);
+            const double tx = wx * hx - wy * hy, ty = wx * hy + wy * hx;
+            wx = tx; wy = ty;
+        }
+    }
+}

@@ -213,7 +213,7 @@ class TiledPropagator(object):
             self._active = [self._tiles_with_object(np.any(d[:, :, z0:z0 + nz] != 0, axis=2) | np.any(b[:, :, z0:z0 + nz] != 0, axis=2))
                             for z0, nz in self.segments()]
 
-    def _scattered_range(self, f, w, B, a, xo, yo, z0, nz, prop_last):
+    def _scattered_range(self, f, w, B, a, xo, yo, z0, nz, prop_last, before_scatter=None):
         """stitch(T psi - T_free psi) of one range added into w (prop_last) / the modulation's scattered part added into f (a last
         single slice without a step), the tiles riding on their own free-space propagation in double."""
         lib, h, T = self.lib, self.h, self.tile
@@ -224,10 +224,8 @@ class TiledPropagator(object):
             self._car_stack = DeviceBuffer(self.ctx, px * 8 * max(nz, self.seg), np.complex64, (max(nz, self.seg), B, T, T))
         car, stack = self._car64, self._car_stack
         self.ctx.check(lib.bdof_tiles_gather_f64(h, f.ptr, self.fx, self.fy, car.ptr, B, T, T, xo, yo, self.taper))
-        for j in range(nz):
-            self.ctx.check(lib.bdof_c_convert(h, stack.ptr + j * px * 8, car.ptr, px, 0))
-            if j < nz - 1:
-                self.ctx.check(lib.bdof_fields_free_step(h, car.ptr, B, T, T, self._h64_tile.ptr, 0, 1))
+        # p_z = F^-1(H^z F p_0), z = 0 .. nz - 1, in double: one forward transform, one batched inverse one (bdof_range_carrier_build)
+        self.ctx.check(lib.bdof_range_carrier_build(h, car.ptr, stack.ptr, B, T, T, self._h64_tile.ptr, nz))
         self.ctx.check(lib.bdof_memset(h, self.tiles_in.ptr, 0, px * 8))              # the scattered part entering the range: none
         self.ctx.check(lib.bdof_set_range_carrier(h, stack.ptr, B, z0, nz))
         try:
@@ -235,6 +233,8 @@ class TiledPropagator(object):
         finally:
             lib.bdof_set_range_carrier(h, None, 0, 0, 0)
         dst = w if prop_last or nz > 1 else f
+        if before_scatter is not None:
+            before_scatter()
         self.ctx.check(lib.bdof_tiles_scatter_diff64(h, self.tiles_out.ptr, None, dst.ptr, self.fx, self.fy, B, T, T, xo, yo,
                                                      self.halo, self.halo, 1))
 
@@ -324,10 +324,14 @@ class TiledPropagator(object):
                 if nprop == 0:                               # a last single slice without a step: f += (c - 1) psi on the cores
                     self._scattered_range(f, f, B, a, xo, yo, z0, nz, 0)
                     continue
+                # the field's own step (one double transform pair of the whole field) on the auxiliary stream, beside the few
+                # tiles' carrier steps and sweeps: the one saturates HBM, the others are small launches
                 _, f_tab = self._tables(nprop)
-                self.ctx.check(lib.bdof_memcpy_d2d(h, w.ptr, f.ptr, npx * 16))
-                self.ctx.check(lib.bdof_fields_free_step(h, w.ptr, 1, self.fx, self.fy, f_tab.ptr, 0, 1))
-                self._scattered_range(f, w, B, a, xo, yo, z0, nz, prop_last)
+                self.ctx.check(lib.bdof_fields_free_step_aux(h, w.ptr, f.ptr, 1, self.fx, self.fy, f_tab.ptr, 0, 1))
+                try:
+                    self._scattered_range(f, w, B, a, xo, yo, z0, nz, prop_last, before_scatter=lambda: self.ctx.check(lib.bdof_aux_join(h)))
+                finally:
+                    lib.bdof_aux_join(h)                     # (a no-op after the join above; an error on the way must not leave it open)
                 f, w = w, f
                 continue
             if self.dbl:

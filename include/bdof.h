@@ -196,6 +196,16 @@ int bdof_set_transfer_f64(bdof_ctx* ctx, const double* hs64);
  * range (np_funcs.py:36-43 on a tile) T psi - T_free psi itself.  Needs a zero ctx probe (bdof_set_probe with a0 = 0, no probe
  * stack).  NULL removes the stack. */
 int bdof_set_range_carrier(bdof_ctx* ctx, const void* stack, int B, int z0, int nz);
+/* bdof_fields_free_step on an auxiliary stream: starts after everything queued on the ctx's stream so far (first copying `src`
+ * into `fields` there, if not NULL) and runs beside what the ctx's stream is handed next; bdof_aux_join makes the ctx's stream
+ * wait for it.  One step in flight at a time.  (The whole-field free-space step of a stitch range, F^-1 H^n F of np_funcs.py:42,
+ * beside the tiles' sweeps.) */
+int bdof_fields_free_step_aux(bdof_ctx* ctx, void* fields, const void* src, int B, int NX, int NY, const void* h, int conj_h, int is_double);
+int bdof_aux_join(bdof_ctx* ctx);
+/* The carrier stack of bdof_set_range_carrier in one call: p0 device complex128 [B][NX][NY] (the wavefields entering the range;
+ * overwritten), stack device complex64 [nz][B][NX][NY] <- F^-1(H^z F p0), z = 0 .. nz - 1, formed in double (one forward
+ * transform, the spectra by a running product, one batched inverse transform); h complex128 [kx][ky], ifftshift(H) / (NX NY). */
+int bdof_range_carrier_build(bdof_ctx* ctx, void* p0, void* stack, int B, int NX, int NY, const void* h, int nz);
 int bdof_forward_range_h(bdof_ctx* ctx, int B, const int* angle_of_b, const int* xoff, const int* yoff, int z0, int nz,
                          const void* in_real, void* out_real, int prop_last, const void* h);
 int bdof_fields_free_step(bdof_ctx* ctx, void* fields, int B, int NX, int NY, const void* h, int conj_h, int is_double);
