@@ -433,3 +433,35 @@ def test_cfg4_tile_size_two_ranges_and_gradient_vs_oracle():
     w = (abs(loss - wl) / abs(wl), rel(gd, wgd[0]), rel(gb, wgb[0]))
     print('tile 512 vs the whole-field oracle: loss', w[0], 'g_delta', w[1], 'g_beta', w[2])
     assert w[0] <= 1e-5 and w[1] <= 3e-3 and w[2] <= 3e-3, w
+
+
+def test_range_carrier_stack_in_one_call_equals_the_step_by_step_one():
+    """bdof_range_carrier_build (p_z = F^-1(H^z F p_0): one forward transform, the spectra by a running product, one batched inverse
+    transform) against the same stack made slice by slice with bdof_fields_free_step + bdof_c_convert, and against numpy."""
+    import __graft_entry__ as entry
+    entry.build()
+    from beyond_dof_amd import _lib, util
+    from beyond_dof_amd.engine import MultisliceEngine
+    B, T, nz = 3, 128, 6
+    rng = np.random.default_rng(8)
+    p0 = (rng.normal(size=(B, T, T)) + 1j * rng.normal(size=(B, T, T))).astype(np.complex128)          # [b][x][y]
+    eng = MultisliceEngine(T, T, 8, B, with_grad=False)
+    ctx, lib, h = eng.ctx, eng.lib, eng.h
+    hk = np.fft.ifftshift(util.get_kernel(1., 0.248, np.array([1., 1., 1.]), (T, T))) / float(T * T)
+    ht = np.ascontiguousarray(hk.T.astype(np.complex128))                                               # [kx][ky]
+    hbuf = _lib.DeviceBuffer.from_host(ctx, ht)
+    a = _lib.DeviceBuffer.from_host(ctx, p0)
+    one = _lib.DeviceBuffer(ctx, nz * B * T * T * 8, np.complex64, (nz, B, T, T))
+    ctx.check(lib.bdof_range_carrier_build(h, a.ptr, one.ptr, B, T, T, hbuf.ptr, nz))
+    b = _lib.DeviceBuffer.from_host(ctx, p0)
+    steps = _lib.DeviceBuffer(ctx, nz * B * T * T * 8, np.complex64, (nz, B, T, T))
+    for j in range(nz):
+        ctx.check(lib.bdof_c_convert(h, steps.ptr + j * B * T * T * 8, b.ptr, B * T * T, 0))
+        if j < nz - 1:
+            ctx.check(lib.bdof_fields_free_step(h, b.ptr, B, T, T, hbuf.ptr, 0, 1))
+    ctx.sync()
+    s1, s2 = one.download(), steps.download()
+    ref = np.stack([np.fft.ifft2(np.fft.fft2(p0) * (ht * T * T) ** z) for z in range(nz)])              # axes (x, y) <-> (kx, ky)
+    e = (rel(s1, s2), rel(s1, ref), rel(s2, ref))
+    print('carrier stack: one call vs step by step', e[0], ' vs numpy float64:', e[1:])
+    assert e[0] <= 2e-7 and e[1] <= 1e-7 and e[2] <= 1e-7, e        # complex64 storage: 6e-8
